@@ -1,0 +1,108 @@
+"""ctypes binding of libbhg.so (the C ABI declared in include/bhg.h).
+
+The library is the product: there is no CPU fallback.  If the shared object is missing the
+import of anything that needs it raises :class:`NativeLibraryError` with the build command.
+Symbols declared in ``include/bhg.h`` are listed in :data:`SYMBOLS`; tests check that every one
+of them resolves.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbhg.so")
+
+BHG_CHUNK_ELEMS = 4096
+BHG_FLAT_ALIGN = 64
+BHG_CG_AUTO, BHG_CG_STREAM, BHG_CG_RESIDENT = 0, 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    """libbhg.so is missing or a call into it failed."""
+
+
+class Chunk(ctypes.Structure):
+    """Mirror of ``bhg_chunk`` (include/bhg.h)."""
+
+    _fields_ = [
+        ("flat_off", c_int64),
+        ("src_off", c_int64),
+        ("tensor", c_int32),
+        ("len", c_int32),
+    ]
+
+
+_PP = POINTER(c_void_p)  # const void* const*
+_CH = c_void_p  # const bhg_chunk* (device)
+
+# name -> (restype, argtypes); mirrors include/bhg.h one to one.
+SYMBOLS = {
+    "bhg_version": (c_int, []),
+    "bhg_last_error": (c_char_p, []),
+    "bhg_layout_flat_size": (c_int64, [POINTER(c_int64), c_int]),
+    "bhg_layout_num_chunks": (c_int64, [POINTER(c_int64), c_int]),
+    "bhg_layout_build": (c_int, [POINTER(c_int64), c_int, POINTER(c_int64), POINTER(Chunk)]),
+    "bhg_workspace_bytes": (c_size_t, [c_int]),
+    "bhg_flatten": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "bhg_scatter": (c_int, [c_void_p, _PP, c_int, _CH, c_int, c_float, c_void_p, c_void_p]),
+    "bhg_neumann_init": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bhg_neumann_step": (
+        c_int,
+        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p],
+    ),
+    "bhg_cg_init": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bhg_cg_step": (
+        c_int,
+        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_void_p, c_void_p],
+    ),
+    "bhg_cg_resident_capacity_chunks": (c_int, []),
+    "bhg_cg_scalars_dev": (c_void_p, [c_void_p]),
+    "bhg_scale_flat": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "bhg_darts_eps": (c_int, [_PP, c_int, _CH, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bhg_axpy_multi": (c_int, [_PP, _PP, c_int, _CH, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "bhg_logreg_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bhg_logreg_tmp_floats": (c_size_t, [c_int, c_int]),
+    "bhg_logreg_hvp": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libbhg.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C betty_amd/csrc`. "
+            "betty_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:  # pragma: no cover - build/ABI mismatch
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().bhg_last_error()
+        raise NativeLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (``const void* const*``)."""
+    arr = (c_void_p * len(ptrs))(*ptrs)
+    return ctypes.cast(arr, _PP), arr

@@ -1,0 +1,189 @@
+"""Vector backend: the only place Python calls into libbhg's kernels.
+
+There is exactly one product backend, :class:`HipBackend` (gfx950 kernels through the C ABI of
+``include/bhg.h``).  It refuses to run when the library is missing, when no GPU is visible or
+when a tensor is not a contiguous fp32 device tensor — there is no CPU path in the product.
+
+``use_backend`` exists so that the *tests* can drive the host orchestration (sync semantics,
+DDP/gloo behaviour) with a checker backend living under ``tests/``; nothing in the package ever
+selects anything but :class:`HipBackend`.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _native
+from .flat import FlatLayout, layout_for
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _native.load()
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError(
+                "betty_amd needs a visible MI355X (torch.cuda.is_available() is False); "
+                "there is no CPU fallback."
+            )
+        self.cg_variant = _native.BHG_CG_AUTO
+
+    # -- helpers ---------------------------------------------------------------------------
+    def layout(self, tensors: Sequence[torch.Tensor]) -> FlatLayout:
+        return layout_for(tensors)
+
+    @staticmethod
+    def _prep(tensors: Sequence[torch.Tensor], layout: FlatLayout, writable: bool = False) -> List[torch.Tensor]:
+        """Validate / normalise a tensor list for the kernels: fp32, contiguous, 16-B aligned,
+        on the layout's device, sizes matching the layout.  Read-only inputs are converted when
+        needed; writable ones must already comply."""
+        if len(tensors) != layout.T:
+            raise ValueError(f"expected {layout.T} tensors, got {len(tensors)}")
+        out = []
+        for t, n in zip(tensors, layout.numels):
+            if t.numel() != n:
+                raise ValueError("tensor sizes do not match the flat layout")
+            if not t.is_cuda:
+                raise _native.NativeLibraryError("HipBackend got a CPU tensor; there is no CPU fallback")
+            ok = t.dtype == torch.float32 and t.is_contiguous() and (t.data_ptr() % 16 == 0 or n == 0)
+            if not ok:
+                if writable:
+                    raise ValueError("in-place target must be a contiguous, 16-byte aligned fp32 tensor")
+                t = t.detach().to(torch.float32).contiguous()
+                if t.data_ptr() % 16 != 0:
+                    t = t.clone(memory_format=torch.contiguous_format)
+            out.append(t)
+        return out
+
+    @staticmethod
+    def _table(tensors: Sequence[torch.Tensor]):
+        return _native.ptr_array([t.data_ptr() for t in tensors])
+
+    # -- multi-tensor <-> flat ----------------------------------------------------------------
+    def flatten(self, layout: FlatLayout, tensors, flat: torch.Tensor, scale: float = 1.0) -> None:
+        ts = self._prep(tensors, layout)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_flatten(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, flat.data_ptr(),
+                                 scale, layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_flatten",
+        )
+
+    def scatter(self, layout: FlatLayout, flat: torch.Tensor, tensors, scale: float = 1.0) -> None:
+        ts = self._prep(tensors, layout, writable=True)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_scatter(flat.data_ptr(), tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks,
+                                 scale, layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_scatter",
+        )
+
+    def scale_flat(self, flat: torch.Tensor, scale: float) -> None:
+        _native.check(self.lib.bhg_scale_flat(flat.data_ptr(), flat.numel(), scale, _stream_ptr()), "bhg_scale_flat")
+
+    # -- Neumann ---------------------------------------------------------------------------------
+    def neumann_init(self, layout, vector, v, p) -> None:
+        ts = self._prep(vector, layout)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_neumann_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, v.data_ptr(),
+                                      p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_neumann_init",
+        )
+
+    def neumann_step(self, layout, hvp, v, p, alpha: float, out_scale: float = 0.0) -> None:
+        ts = self._prep(hvp, layout)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_neumann_step(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, v.data_ptr(),
+                                      p.data_ptr(), alpha, out_scale, layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_neumann_step",
+        )
+
+    # -- CG ------------------------------------------------------------------------------------------
+    def cg_init(self, layout, vector, x, r, p) -> None:
+        ts = self._prep(vector, layout)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_cg_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
+                                 r.data_ptr(), p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_cg_init",
+        )
+
+    def cg_step(self, layout, hvp, x, r, p, cg_alpha: float, it: int, out_scale: float = 0.0,
+                variant: Optional[int] = None) -> None:
+        ts = self._prep(hvp, layout)
+        tab, _keep = self._table(ts)
+        _native.check(
+            self.lib.bhg_cg_step(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
+                                 r.data_ptr(), p.data_ptr(), cg_alpha, it, out_scale,
+                                 self.cg_variant if variant is None else variant,
+                                 layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_cg_step",
+        )
+
+    def cg_scalars(self, layout) -> torch.Tensor:
+        """{rr_old, pHp, alpha, rr_new, beta} of the last CG step (device -> host copy; debug)."""
+        ws = layout.workspace
+        return ws[:64].view(torch.float64)[:5].clone()
+
+    # -- DARTS ---------------------------------------------------------------------------------------
+    def darts_eps(self, layout, vector, R: float):
+        """Returns (eps_f32, eps_f64) as 0-dim device tensors; no host synchronisation."""
+        ts = self._prep(vector, layout)
+        tab, _keep = self._table(ts)
+        out = torch.empty(2, dtype=torch.float64, device=layout.device)
+        eps32 = torch.empty(1, dtype=torch.float32, device=layout.device)
+        _native.check(
+            self.lib.bhg_darts_eps(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, float(R),
+                                   out.data_ptr(), eps32.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_darts_eps",
+        )
+        return eps32[0], out[1]
+
+    def axpy_multi(self, layout, dst, src, coef: Optional[torch.Tensor], mul: float) -> None:
+        d = self._prep(dst, layout, writable=True)
+        s = self._prep(src, layout)
+        td, _k1 = self._table(d)
+        ts, _k2 = self._table(s)
+        _native.check(
+            self.lib.bhg_axpy_multi(td, ts, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks,
+                                    coef.data_ptr() if coef is not None else None, mul,
+                                    layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_axpy_multi",
+        )
+
+
+_backend = None
+_override = None
+
+
+def get_backend():
+    """The active vector backend: :class:`HipBackend` unless a test installed a checker."""
+    global _backend
+    if _override is not None:
+        return _override
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+@contextlib.contextmanager
+def use_backend(backend):
+    """TEST HOOK ONLY: run host orchestration against another object with HipBackend's
+    interface (see tests/_cpu_checker_backend.py).  Never used inside the package."""
+    global _override
+    prev = _override
+    _override = backend
+    try:
+        yield backend
+    finally:
+        _override = prev

@@ -1,0 +1,121 @@
+// bhg_common.hpp — shared device/host helpers for libbhg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "bhg.h"
+
+namespace bhg {
+
+constexpr int kThreads = 256;             // 4 waves of 64
+constexpr int kWaves = kThreads / 64;
+constexpr int kChunk = BHG_CHUNK_ELEMS;   // 4096 fp32 = 16 KiB per vector per chunk
+constexpr int kVecPerThread = kChunk / (kThreads * 4);  // float4 per thread per chunk = 4
+constexpr int kMaxBlocks = 1024;          // 4 blocks per CU x 256 CUs
+constexpr int kInlineT = 32;              // tensor pointers passed inline in kernargs
+constexpr int kWriterT = 448;             // pointers per table-writer launch (< 4 KiB kernarg)
+
+// ---- workspace layout (byte offsets) -------------------------------------------
+constexpr size_t kWsScal = 0;                                 // 16 doubles
+constexpr size_t kWsPartP = 128;                              // kMaxBlocks doubles
+constexpr size_t kWsPartR = kWsPartP + 8 * kMaxBlocks;        // 2 x kMaxBlocks doubles
+constexpr size_t kWsBarrier = kWsPartR + 16 * kMaxBlocks;     // 64 x u32
+constexpr size_t kWsTables = kWsBarrier + 256;                // 2 x T pointers
+inline size_t ws_bytes(int T) {
+  size_t b = kWsTables + 2 * sizeof(void*) * (size_t)(T > 0 ? T : 0);
+  return (b + 255) & ~(size_t)255;
+}
+
+// scalar slots
+enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_NPART0 = 8 /* and 9 */ };
+
+// ---- error plumbing -------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define BHG_HIP_CHECK(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      ::bhg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                       __LINE__);                                                  \
+      return BHG_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+#define BHG_REQUIRE(cond, msg)                                                     \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      ::bhg::set_error("%s: %s", __func__, msg);                                   \
+      return BHG_ERR_ARG;                                                          \
+    }                                                                              \
+  } while (0)
+
+// ---- tensor pointer table ---------------------------------------------------------
+// T <= kInlineT: pointers travel in the kernel arguments (no copy, no extra launch).
+// Otherwise they are written into the workspace by k_write_table launches (stream
+// ordered, no host sync, no pinned staging) and read through `dev`.
+struct PtrTab {
+  const void* const* dev;
+  const void* inl[kInlineT];
+};
+
+int make_table(PtrTab* out, const void* const* host_ptrs, int T, void* ws, int slot,
+               hipStream_t stream);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float* tab_ptr(const PtrTab& t, int i) {
+  const void* p = t.dev ? t.dev[i] : t.inl[i];
+  return (float*)p;
+}
+
+// ---- vector access within a chunk ---------------------------------------------------
+// `e` is the element offset inside the chunk (multiple of 4); base is 16-B aligned at
+// e = 0 because chunk starts are multiples of kChunk elements from a 16-B aligned tensor
+// base (checked on the host) and flat starts are multiples of BHG_FLAT_ALIGN.
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, int e, int len) {
+  if (e + 4 <= len) return *reinterpret_cast<const float4*>(base + e);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < len) r.x = base[e];
+  if (e + 1 < len) r.y = base[e + 1];
+  if (e + 2 < len) r.z = base[e + 2];
+  return r;
+}
+__device__ __forceinline__ void st4(float* __restrict__ base, int e, int len, float4 v) {
+  if (e + 4 <= len) {
+    *reinterpret_cast<float4*>(base + e) = v;
+    return;
+  }
+  if (e < len) base[e] = v.x;
+  if (e + 1 < len) base[e + 1] = v.y;
+  if (e + 2 < len) base[e + 2] = v.z;
+}
+
+// ---- deterministic block reductions (fp64) --------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+// Sum over the block; result valid in every thread.  `red` is kWaves doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` against the previous use
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) s += red[i];
+  return s;
+}
+// Fixed-order sum of n (<= kMaxBlocks) per-block partials written by an EARLIER kernel.
+// Every block computes bit-identical results.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n,
+                                               double* red) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += kThreads) a += part[i];
+  return block_sum(a, red);
+}
+#endif  // __HIPCC__
+
+}  // namespace bhg

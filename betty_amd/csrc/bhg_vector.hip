@@ -1,0 +1,778 @@
+// bhg_vector.hip — fused multi-tensor vector recurrences of the hypergradient hot path.
+//
+// Replaces the per-tensor ATen launches of betty/hypergradient/cg.py:34-56,
+// neumann.py:59-66 and darts.py:29-38,49-50,62-63 (plus betty/utils.py:117-118 to_vec)
+// with a handful of HBM-streaming kernels over flat fp32 state vectors.  Written for
+// gfx950 only: wave64 reductions, 16-B (dwordx4) coalesced accesses, fp64 partial sums,
+// fixed-order two-stage reductions (no float atomics => run-to-run bitwise determinism).
+//
+// Arithmetic follows the reference's rounding sequence (a*b rounded, then +/-; never
+// contracted into an fma) so that the only differences to the CPU autograd reference are
+// the reduction order of the dot products (we accumulate in fp64) and the HVP itself.
+#include "bhg_common.hpp"
+
+namespace bhg {
+namespace {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+#define BHG_FOR4(stmt_x, stmt_y, stmt_z, stmt_w) \
+  do {                                           \
+    stmt_x;                                      \
+    stmt_y;                                      \
+    stmt_z;                                      \
+    stmt_w;                                      \
+  } while (0)
+
+// ---- pointer-table writer (T > kInlineT) -----------------------------------------------
+struct WriterArgs {
+  const void* p[kWriterT];
+};
+__global__ void k_write_table(const void** dst, WriterArgs a, int count) {
+  const int i = threadIdx.x;
+  if (i < count) dst[i] = a.p[i];
+}
+
+// ---- flatten / scatter -------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_flatten(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                      int n_chunks, float* __restrict__ flat,
+                                                      float scale) {
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* src = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float* dst = flat + ck.flat_off;
+    float4 v[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) v[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      float4 o = v[i];
+      o.x = mul_rn(scale, o.x); o.y = mul_rn(scale, o.y); o.z = mul_rn(scale, o.z); o.w = mul_rn(scale, o.w);
+      st4(dst, 4 * (threadIdx.x + kThreads * i), ck.len, o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scatter(const float* __restrict__ flat, PtrTab tab,
+                                                      const bhg_chunk* __restrict__ chunks,
+                                                      int n_chunks, float scale) {
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    float* dst = tab_ptr(tab, ck.tensor) + ck.src_off;
+    const float* src = flat + ck.flat_off;
+    float4 v[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) v[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      float4 o = v[i];
+      o.x = mul_rn(scale, o.x); o.y = mul_rn(scale, o.y); o.z = mul_rn(scale, o.z); o.w = mul_rn(scale, o.w);
+      st4(dst, 4 * (threadIdx.x + kThreads * i), ck.len, o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale_flat(float* __restrict__ flat, int64_t n4, int64_t n,
+                                                         float scale) {
+  // n4 = number of whole float4; tail handled by the last thread range
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kThreads) {
+    float4 v = reinterpret_cast<float4*>(flat)[i];
+    v.x = mul_rn(scale, v.x); v.y = mul_rn(scale, v.y); v.z = mul_rn(scale, v.z); v.w = mul_rn(scale, v.w);
+    reinterpret_cast<float4*>(flat)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) {
+    const int64_t j = 4 * n4 + threadIdx.x;
+    flat[j] = mul_rn(scale, flat[j]);
+  }
+}
+
+// ---- Neumann ----------------------------------------------------------------------------------
+// neumann.py:60  p = v (the reference aliases; we keep two flat buffers)
+__global__ __launch_bounds__(kThreads) void k_neumann_init(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                           int n_chunks, float* __restrict__ v,
+                                                           float* __restrict__ p) {
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* src = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float4 t[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) t[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      st4(v + ck.flat_off, 4 * (threadIdx.x + kThreads * i), ck.len, t[i]);
+      st4(p + ck.flat_off, 4 * (threadIdx.x + kThreads * i), ck.len, t[i]);
+    }
+  }
+}
+
+// neumann.py:62-64 (+66 and the negation of 45/54 folded in when out_scale != 0):
+//   v <- v - alpha*Hv ; p <- p + v ; [p <- out_scale * p]
+// 20*N algorithmic bytes: read Hv, v, p; write v, p.
+__global__ __launch_bounds__(kThreads) void k_neumann_step(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                           int n_chunks, float* __restrict__ v,
+                                                           float* __restrict__ p, float alpha,
+                                                           float out_scale) {
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* hsrc = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float* vv = v + ck.flat_off;
+    float* pp = p + ck.flat_off;
+    float4 h[kVecPerThread], a[kVecPerThread], b[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      h[i] = ld4(hsrc, e, ck.len);
+      a[i] = ld4(vv, e, ck.len);
+      b[i] = ld4(pp, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      float4 nv, np;
+      nv.x = sub_rn(a[i].x, mul_rn(alpha, h[i].x)); nv.y = sub_rn(a[i].y, mul_rn(alpha, h[i].y));
+      nv.z = sub_rn(a[i].z, mul_rn(alpha, h[i].z)); nv.w = sub_rn(a[i].w, mul_rn(alpha, h[i].w));
+      np.x = add_rn(nv.x, b[i].x); np.y = add_rn(nv.y, b[i].y);
+      np.z = add_rn(nv.z, b[i].z); np.w = add_rn(nv.w, b[i].w);
+      if (out_scale != 0.f) {
+        np.x = mul_rn(out_scale, np.x); np.y = mul_rn(out_scale, np.y);
+        np.z = mul_rn(out_scale, np.z); np.w = mul_rn(out_scale, np.w);
+      }
+      st4(vv, e, ck.len, nv);
+      st4(pp, e, ck.len, np);
+    }
+  }
+}
+
+// ---- CG: streaming variant (3 kernels per iteration, 40*N bytes) -------------------------------
+// cg.py:34-36: x = 0, r = p = vector; also the first numerator r.r (cg.py:45).
+__global__ __launch_bounds__(kThreads) void k_cg_init(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                      int n_chunks, float* __restrict__ x,
+                                                      float* __restrict__ r, float* __restrict__ p,
+                                                      double* __restrict__ partR0,
+                                                      unsigned* __restrict__ barrier_words,
+                                                      double* __restrict__ scal) {
+  __shared__ double red[kWaves];
+  double acc = 0.0;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* src = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float4 t[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) t[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      st4(x + ck.flat_off, e, ck.len, zero);
+      st4(r + ck.flat_off, e, ck.len, t[i]);
+      st4(p + ck.flat_off, e, ck.len, t[i]);
+      acc += (double)t[i].x * t[i].x + (double)t[i].y * t[i].y + (double)t[i].z * t[i].z +
+             (double)t[i].w * t[i].w;
+    }
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partR0[blockIdx.x] = s;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) barrier_words[threadIdx.x] = 0u;  // grid-barrier state of the resident kernel
+    if (threadIdx.x < 16) scal[threadIdx.x] = (threadIdx.x == S_NPART0) ? (double)gridDim.x : 0.0;
+  }
+}
+
+// K1: den = (cg_alpha*Hp).p   (cg.py:42,44,46) — reads Hp, p: 8*N bytes.
+__global__ __launch_bounds__(kThreads) void k_cg_dot(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                     int n_chunks, const float* __restrict__ p,
+                                                     float cg_alpha, double* __restrict__ partP) {
+  __shared__ double red[kWaves];
+  double acc = 0.0;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* hsrc = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float4 h[kVecPerThread], q[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      h[i] = ld4(hsrc, e, ck.len);
+      q[i] = ld4(p + ck.flat_off, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      acc += (double)mul_rn(cg_alpha, h[i].x) * q[i].x + (double)mul_rn(cg_alpha, h[i].y) * q[i].y +
+             (double)mul_rn(cg_alpha, h[i].z) * q[i].z + (double)mul_rn(cg_alpha, h[i].w) * q[i].w;
+    }
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partP[blockIdx.x] = s;
+}
+
+// K2: a = rr/den ; r' = r - a*Hp (cg.py:47,50) ; partial r'.r' (cg.py:51-52)
+// reads Hp, r; writes r: 12*N bytes.  x += a*p is deferred to K3, which reads p anyway.
+__global__ __launch_bounds__(kThreads) void k_cg_resid(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                       int n_chunks, float* __restrict__ r,
+                                                       const double* __restrict__ partP,
+                                                       const double* __restrict__ partR_old,
+                                                       double* __restrict__ partR_new, int n_part,
+                                                       int iter, double* __restrict__ scal) {
+  __shared__ double red[kWaves];
+  const double rr = sum_partials(partR_old, (int)scal[S_NPART0 + (iter & 1)], red);
+  const double den = sum_partials(partP, n_part, red);
+  const float alpha = (float)rr / (float)den;  // fp32 divide of fp32 dots, as torch does
+  double acc = 0.0;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* hsrc = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float* rrp = r + ck.flat_off;
+    float4 h[kVecPerThread], a[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      h[i] = ld4(hsrc, e, ck.len);
+      a[i] = ld4(rrp, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      float4 nr;
+      nr.x = sub_rn(a[i].x, mul_rn(alpha, h[i].x)); nr.y = sub_rn(a[i].y, mul_rn(alpha, h[i].y));
+      nr.z = sub_rn(a[i].z, mul_rn(alpha, h[i].z)); nr.w = sub_rn(a[i].w, mul_rn(alpha, h[i].w));
+      st4(rrp, e, ck.len, nr);
+      acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
+    }
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    partR_new[blockIdx.x] = s;
+    if (blockIdx.x == 0) {
+      scal[S_RR_OLD] = rr;
+      scal[S_PHP] = den;
+      scal[S_ALPHA] = (double)alpha;
+      scal[S_NPART0 + ((iter + 1) & 1)] = (double)gridDim.x;
+    }
+  }
+}
+
+// K3: b = r'.r'/rr ; x += a*p ; p = r' + b*p (cg.py:49,52,53) [x <- out_scale*x on the last step]
+// reads r', p, x; writes x, p: 20*N bytes.
+__global__ __launch_bounds__(kThreads) void k_cg_dir(const bhg_chunk* __restrict__ chunks, int n_chunks,
+                                                     float* __restrict__ x, const float* __restrict__ r,
+                                                     float* __restrict__ p,
+                                                     const double* __restrict__ partR_new, int n_part,
+                                                     float out_scale, double* __restrict__ scal) {
+  __shared__ double red[kWaves];
+  const double rr_new = sum_partials(partR_new, n_part, red);
+  const double rr_old = scal[S_RR_OLD];
+  const float alpha = (float)scal[S_ALPHA];
+  const float beta = (float)rr_new / (float)rr_old;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    float4 a[kVecPerThread], q[kVecPerThread], xx[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      a[i] = ld4(r + ck.flat_off, e, ck.len);
+      q[i] = ld4(p + ck.flat_off, e, ck.len);
+      xx[i] = ld4(x + ck.flat_off, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      float4 nx, np;
+      nx.x = add_rn(xx[i].x, mul_rn(alpha, q[i].x)); nx.y = add_rn(xx[i].y, mul_rn(alpha, q[i].y));
+      nx.z = add_rn(xx[i].z, mul_rn(alpha, q[i].z)); nx.w = add_rn(xx[i].w, mul_rn(alpha, q[i].w));
+      if (out_scale != 0.f) {
+        nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
+        nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
+      }
+      np.x = add_rn(a[i].x, mul_rn(beta, q[i].x)); np.y = add_rn(a[i].y, mul_rn(beta, q[i].y));
+      np.z = add_rn(a[i].z, mul_rn(beta, q[i].z)); np.w = add_rn(a[i].w, mul_rn(beta, q[i].w));
+      st4(x + ck.flat_off, e, ck.len, nx);
+      st4(p + ck.flat_off, e, ck.len, np);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[S_RR_NEW] = rr_new;
+    scal[S_BETA] = (double)beta;
+  }
+}
+
+// ---- CG: register-resident variant (1 persistent kernel per iteration, 28*N bytes) --------------
+// One 512-thread workgroup per CU (2 waves per SIMD => 256 VGPRs per lane); every thread keeps
+// its float4s of Hp (later r') and of p in VGPRs across two grid-wide barriers, so Hp, p, r, x
+// are each read exactly once and x, r, p written exactly once per iteration.
+// Holds N <= gridDim * kResMax * 4096 elements (11.5 M on a 256-CU MI355X).
+constexpr int kResThreads = 512;
+constexpr int kResWaves = kResThreads / 64;
+constexpr int kResV = kChunk / (kResThreads * 4);  // float4 per thread per chunk = 2
+constexpr int kResMax = 11;   // chunks per workgroup; 2 x 11 x 2 float4 = 176 VGPRs of state (252 total, no spill)
+
+__device__ __forceinline__ double block_sum_res(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < kResWaves; ++i) s += red[i];
+  return s;
+}
+
+using gu32 = __attribute__((address_space(1))) unsigned;
+using gf64 = __attribute__((address_space(1))) double;
+
+// Grid barrier + all-reduce of one double per workgroup.  Partials are exchanged with
+// 8-byte agent-scope atomics on both sides (write-through store, L1-bypassing load), the
+// arrival counter is monotonic (zeroed by k_cg_init, so targets depend only on `iter`).
+// Returns the fixed-order sum over all workgroups, identical in every workgroup.
+__device__ __forceinline__ double grid_allreduce(double block_value, double* part, unsigned* counter,
+                                                 unsigned target, double* red, unsigned* timeout_word) {
+  // block_value is valid in every thread (block_sum_res); thread 0 publishes it.
+  if (threadIdx.x == 0) {
+    __hip_atomic_store((gf64*)(part + blockIdx.x), block_value, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add((gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) {  // bounded spin: flag and fall through instead of hanging the GPU
+        __hip_atomic_store((gu32*)timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  double a = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kResThreads)
+    a += __hip_atomic_load((gf64*)(part + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return block_sum_res(a, red);
+}
+
+__global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
+    PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
+    float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale,
+    const double* __restrict__ partR_old, double* __restrict__ partR_new,
+    double* __restrict__ partP, unsigned* __restrict__ barrier_words, double* __restrict__ scal) {
+  __shared__ double red[kResWaves];
+  const int G = gridDim.x;
+
+  // numerator r.r from the previous producer (k_cg_init or the previous iteration).
+  double rr;
+  {
+    const int n_part_old = (int)scal[S_NPART0 + (iter & 1)];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n_part_old; i += kResThreads) a += partR_old[i];
+    rr = block_sum_res(a, red);
+  }
+
+  float4 h[kResMax][kResV], q[kResMax][kResV];
+  // ---- phase 1: load Hp, p once; den = (cg_alpha*Hp).p
+#pragma unroll
+  for (int i = 0; i < kResMax; ++i) {
+    const int c = blockIdx.x + i * G;
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) {
+      h[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      q[i][j] = h[i][j];
+    }
+    if (c < n_chunks) {
+      const bhg_chunk ck = chunks[c];
+      const float* hs = tab_ptr(tab, ck.tensor) + ck.src_off;
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        h[i][j] = ld4(hs, e, ck.len);
+        q[i][j] = ld4(p + ck.flat_off, e, ck.len);
+      }
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < kResMax; ++i) {
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) {
+      acc += (double)mul_rn(cg_alpha, h[i][j].x) * q[i][j].x + (double)mul_rn(cg_alpha, h[i][j].y) * q[i][j].y +
+             (double)mul_rn(cg_alpha, h[i][j].z) * q[i][j].z + (double)mul_rn(cg_alpha, h[i][j].w) * q[i][j].w;
+    }
+  }
+  const double blk_den = block_sum_res(acc, red);
+  const double den = grid_allreduce(blk_den, partP, barrier_words, (unsigned)G * (2u * iter + 1u), red,
+                                    barrier_words + 1);
+  const float alpha = (float)rr / (float)den;
+
+  // ---- phase 2: x += a*p ; r' = r - a*Hp (kept in h) ; partial r'.r'
+  // Software-pipelined: the x/r loads of chunk i+1 are issued before chunk i is stored (the
+  // compiler cannot hoist them across the stores to the same arrays itself).
+  acc = 0.0;
+  float4 xv[kResV], rv[kResV], xn[kResV], rn[kResV];
+#pragma unroll
+  for (int j = 0; j < kResV; ++j) xv[j] = rv[j] = xn[j] = rn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((int)blockIdx.x < n_chunks) {
+    const bhg_chunk ck = chunks[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) {
+      const int e = 4 * (threadIdx.x + kResThreads * j);
+      xv[j] = ld4(x + ck.flat_off, e, ck.len);
+      rv[j] = ld4(r + ck.flat_off, e, ck.len);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kResMax; ++i) {
+    const int c = blockIdx.x + i * G;
+    const int cn = c + G;
+    if (i + 1 < kResMax && cn < n_chunks) {
+      const bhg_chunk ckn = chunks[cn];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        xn[j] = ld4(x + ckn.flat_off, e, ckn.len);
+        rn[j] = ld4(r + ckn.flat_off, e, ckn.len);
+      }
+    }
+    if (c < n_chunks) {
+      const bhg_chunk ck = chunks[c];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        float4 nx, nr;
+        nx.x = add_rn(xv[j].x, mul_rn(alpha, q[i][j].x)); nx.y = add_rn(xv[j].y, mul_rn(alpha, q[i][j].y));
+        nx.z = add_rn(xv[j].z, mul_rn(alpha, q[i][j].z)); nx.w = add_rn(xv[j].w, mul_rn(alpha, q[i][j].w));
+        if (out_scale != 0.f) {
+          nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
+          nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
+        }
+        nr.x = sub_rn(rv[j].x, mul_rn(alpha, h[i][j].x)); nr.y = sub_rn(rv[j].y, mul_rn(alpha, h[i][j].y));
+        nr.z = sub_rn(rv[j].z, mul_rn(alpha, h[i][j].z)); nr.w = sub_rn(rv[j].w, mul_rn(alpha, h[i][j].w));
+        st4(x + ck.flat_off, e, ck.len, nx);
+        st4(r + ck.flat_off, e, ck.len, nr);
+        h[i][j] = nr;
+        acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) {
+      xv[j] = xn[j];
+      rv[j] = rn[j];
+    }
+  }
+  const double blk_rr = block_sum_res(acc, red);
+  const double rr_new = grid_allreduce(blk_rr, partR_new, barrier_words, (unsigned)G * (2u * iter + 2u),
+                                       red, barrier_words + 1);
+  const float beta = (float)rr_new / (float)rr;
+
+  // ---- phase 3: p = r' + b*p
+#pragma unroll
+  for (int i = 0; i < kResMax; ++i) {
+    const int c = blockIdx.x + i * G;
+    if (c < n_chunks) {
+      const bhg_chunk ck = chunks[c];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        float4 np;
+        np.x = add_rn(h[i][j].x, mul_rn(beta, q[i][j].x)); np.y = add_rn(h[i][j].y, mul_rn(beta, q[i][j].y));
+        np.z = add_rn(h[i][j].z, mul_rn(beta, q[i][j].z)); np.w = add_rn(h[i][j].w, mul_rn(beta, q[i][j].w));
+        st4(p + ck.flat_off, e, ck.len, np);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[S_RR_OLD] = rr;
+    scal[S_PHP] = den;
+    scal[S_ALPHA] = (double)alpha;
+    scal[S_RR_NEW] = rr_new;
+    scal[S_BETA] = (double)beta;
+    scal[S_NPART0 + ((iter + 1) & 1)] = (double)gridDim.x;
+  }
+}
+
+// ---- DARTS vector ops ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_sqnorm(PtrTab tab, const bhg_chunk* __restrict__ chunks,
+                                                     int n_chunks, double* __restrict__ part) {
+  __shared__ double red[kWaves];
+  double acc = 0.0;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* src = tab_ptr(tab, ck.tensor) + ck.src_off;
+    float4 t[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) t[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i)
+      acc += (double)t[i].x * t[i].x + (double)t[i].y * t[i].y + (double)t[i].z * t[i].z +
+             (double)t[i].w * t[i].w;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// darts.py:29-35: eps = R / (norm + 1e-15); the norm is an fp32 tensor in the reference and the
+// division happens in Python floats (double), then eps is used as an fp32 `alpha`.
+__global__ __launch_bounds__(kThreads) void k_darts_eps(const double* __restrict__ part, int n_part, double R,
+                                                        double* __restrict__ out, float* __restrict__ eps_f32) {
+  __shared__ double red[kWaves];
+  const double ss = sum_partials(part, n_part, red);
+  if (threadIdx.x == 0) {
+    float nf = (float)sqrt(ss);
+    nf = add_rn(nf, 1e-15f);
+    const double eps = R / (double)nf;
+    out[0] = ss;
+    out[1] = eps;
+    if (eps_f32) *eps_f32 = (float)eps;
+  }
+}
+
+// darts.py:37-38,49-50,62-63: w_t += (mul * coef) * v_t, in place on the live weights.
+__global__ __launch_bounds__(kThreads) void k_axpy_multi(PtrTab dst, PtrTab src,
+                                                         const bhg_chunk* __restrict__ chunks, int n_chunks,
+                                                         const float* __restrict__ coef_dev, float mul) {
+  const float a = coef_dev ? mul_rn(mul, *coef_dev) : mul;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    float* d = tab_ptr(dst, ck.tensor) + ck.src_off;
+    const float* s = tab_ptr(src, ck.tensor) + ck.src_off;
+    float4 dv[kVecPerThread], sv[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      dv[i] = ld4(d, e, ck.len);
+      sv[i] = ld4(s, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      float4 o;
+      o.x = add_rn(dv[i].x, mul_rn(a, sv[i].x)); o.y = add_rn(dv[i].y, mul_rn(a, sv[i].y));
+      o.z = add_rn(dv[i].z, mul_rn(a, sv[i].z)); o.w = add_rn(dv[i].w, mul_rn(a, sv[i].w));
+      st4(d, e, ck.len, o);
+    }
+  }
+}
+
+inline int grid_for(int n_chunks) { return n_chunks < kMaxBlocks ? (n_chunks > 0 ? n_chunks : 1) : kMaxBlocks; }
+
+int g_num_cus = -1;
+int num_cus() {
+  if (g_num_cus >= 0) return g_num_cus;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    g_num_cus = 0;
+  } else {
+    g_num_cus = prop.multiProcessorCount;
+  }
+  return g_num_cus;
+}
+
+}  // namespace
+
+int make_table(PtrTab* out, const void* const* host_ptrs, int T, void* ws, int slot, hipStream_t stream) {
+  memset(out, 0, sizeof(*out));
+  if (T <= kInlineT) {
+    for (int i = 0; i < T; ++i) out->inl[i] = host_ptrs[i];
+    out->dev = nullptr;
+    return BHG_OK;
+  }
+  if (!ws) {
+    set_error("make_table: workspace required for T=%d > %d", T, kInlineT);
+    return BHG_ERR_WS;
+  }
+  const void** dev = reinterpret_cast<const void**>(static_cast<char*>(ws) + kWsTables) + (size_t)slot * T;
+  for (int off = 0; off < T; off += kWriterT) {
+    WriterArgs a;
+    const int cnt = (T - off) < kWriterT ? (T - off) : kWriterT;
+    for (int i = 0; i < cnt; ++i) a.p[i] = host_ptrs[off + i];
+    for (int i = cnt; i < kWriterT; ++i) a.p[i] = nullptr;
+    hipLaunchKernelGGL(k_write_table, dim3(1), dim3(kWriterT), 0, stream, dev + off, a, cnt);
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  out->dev = dev;
+  return BHG_OK;
+}
+
+}  // namespace bhg
+
+using namespace bhg;
+
+#define BHG_COMMON_CHECKS(tabptr)                                          \
+  BHG_REQUIRE(tabptr != nullptr || T == 0, "tensor table is NULL");        \
+  BHG_REQUIRE(T >= 0 && n_chunks >= 0, "negative size");                   \
+  BHG_REQUIRE(chunks_dev != nullptr || n_chunks == 0, "chunk table is NULL")
+
+extern "C" {
+
+int bhg_flatten(const void* const* src, int T, const bhg_chunk* chunks_dev, int n_chunks, float* flat,
+                float scale, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(src);
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(flat, "flat is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tab;
+  if (int rc = make_table(&tab, src, T, ws, 0, st)) return rc;
+  hipLaunchKernelGGL(k_flatten, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks,
+                     flat, scale);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_scatter(const float* flat, void* const* dst, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                float scale, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(dst);
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(flat, "flat is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tab;
+  if (int rc = make_table(&tab, const_cast<const void* const*>(dst), T, ws, 0, st)) return rc;
+  hipLaunchKernelGGL(k_scatter, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, flat, tab, chunks_dev,
+                     n_chunks, scale);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_scale_flat(float* flat, int64_t n, float scale, void* stream) {
+  BHG_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return BHG_OK;
+  BHG_REQUIRE(flat, "flat is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + kThreads - 1) / kThreads;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_scale_flat, dim3((unsigned)blocks), dim3(kThreads), 0, st, flat, n4, n, scale);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_neumann_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, float* v,
+                     float* p, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(vec);
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(v && p, "state vector is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tab;
+  if (int rc = make_table(&tab, vec, T, ws, 0, st)) return rc;
+  hipLaunchKernelGGL(k_neumann_init, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev,
+                     n_chunks, v, p);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* v,
+                     float* p, float alpha, float out_scale, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(hvp);
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(v && p, "state vector is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tab;
+  if (int rc = make_table(&tab, hvp, T, ws, 0, st)) return rc;
+  hipLaunchKernelGGL(k_neumann_step, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev,
+                     n_chunks, v, p, alpha, out_scale);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
+                float* p, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(vec);
+  BHG_REQUIRE(ws, "workspace is NULL");
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(x && r && p, "state vector is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tab;
+  if (int rc = make_table(&tab, vec, T, ws, 0, st)) return rc;
+  char* w = static_cast<char*>(ws);
+  hipLaunchKernelGGL(k_cg_init, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, x,
+                     r, p, reinterpret_cast<double*>(w + kWsPartR),
+                     reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal));
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMax; }
+
+const double* bhg_cg_scalars_dev(const void* ws) {
+  return reinterpret_cast<const double*>(static_cast<const char*>(ws) + kWsScal);
+}
+
+int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
+                float* p, float cg_alpha, int iter, float out_scale, int variant, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(hvp);
+  BHG_REQUIRE(ws, "workspace is NULL");
+  BHG_REQUIRE(iter >= 0, "negative iteration index");
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(x && r && p, "state vector is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int cap = bhg_cg_resident_capacity_chunks();
+  if (variant == BHG_CG_AUTO) variant = (n_chunks <= cap && cap > 0) ? BHG_CG_RESIDENT : BHG_CG_STREAM;
+  if (variant == BHG_CG_RESIDENT && n_chunks > cap) {
+    set_error("bhg_cg_step: %d chunks exceed the resident capacity of %d", n_chunks, cap);
+    return BHG_ERR_CAPACITY;
+  }
+  BHG_REQUIRE(variant == BHG_CG_STREAM || variant == BHG_CG_RESIDENT, "unknown variant");
+  PtrTab tab;
+  if (int rc = make_table(&tab, hvp, T, ws, 0, st)) return rc;
+  char* w = static_cast<char*>(ws);
+  double* scal = reinterpret_cast<double*>(w + kWsScal);
+  double* partP = reinterpret_cast<double*>(w + kWsPartP);
+  double* partR = reinterpret_cast<double*>(w + kWsPartR);
+  // The producer of r.r for iteration `iter` wrote partR[iter & 1]; this iteration writes the other.
+  double* partR_old = partR + (size_t)(iter & 1) * kMaxBlocks;
+  double* partR_new = partR + (size_t)((iter + 1) & 1) * kMaxBlocks;
+  // How many partials the previous producer wrote travels in scal[S_NPART0 + parity], so the
+  // stream and resident variants may be mixed freely between iterations.
+  const int n_stream = grid_for(n_chunks);
+  if (variant == BHG_CG_STREAM) {
+    hipLaunchKernelGGL(k_cg_dot, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks,
+                       (const float*)p, cg_alpha, partP);
+    hipLaunchKernelGGL(k_cg_resid, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, r,
+                       (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
+    hipLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, chunks_dev, n_chunks, x,
+                       (const float*)r, p, (const double*)partR_new, n_stream, out_scale, scal);
+  } else {
+    const int G = num_cus();
+    hipLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, tab, chunks_dev, n_chunks, x, r, p,
+                       cg_alpha, iter, out_scale, (const double*)partR_old, partR_new, partP,
+                       reinterpret_cast<unsigned*>(w + kWsBarrier), scal);
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_darts_eps(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, double R,
+                  double* out_dev, float* eps_f32_dev, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(vec);
+  BHG_REQUIRE(ws && out_dev, "workspace/out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  double* part = reinterpret_cast<double*>(w + kWsPartP);
+  int n_part = 0;
+  if (n_chunks > 0) {
+    PtrTab tab;
+    if (int rc = make_table(&tab, vec, T, ws, 0, st)) return rc;
+    n_part = grid_for(n_chunks);
+    hipLaunchKernelGGL(k_sqnorm, dim3(n_part), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, part);
+  }
+  hipLaunchKernelGGL(k_darts_eps, dim3(1), dim3(kThreads), 0, st, (const double*)part, n_part, R, out_dev,
+                     eps_f32_dev);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                   const float* coef_dev, float mul, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(dst);
+  BHG_REQUIRE(src != nullptr || T == 0, "src table is NULL");
+  if (n_chunks == 0) return BHG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab td, ts;
+  if (int rc = make_table(&td, const_cast<const void* const*>(dst), T, ws, 0, st)) return rc;
+  if (int rc = make_table(&ts, src, T, ws, 1, st)) return rc;
+  hipLaunchKernelGGL(k_axpy_multi, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, td, ts, chunks_dev,
+                     n_chunks, coef_dev, mul);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+"""Conjugate-gradient best-response-Jacobian product (iMAML style) on fused gfx950 kernels.
+
+Behavioural twin of /root/reference betty/hypergradient/cg.py:8-70 — same signature, same
+iteration, including the reference's ``cg_alpha`` quirk (the step length is computed with
+``cg_alpha * Hp`` but the residual is updated with the un-scaled ``Hp``, cg.py:42-50) and the
+absence of any convergence test or breakdown guard.  What changes is where the arithmetic runs:
+``x, r, p`` are flat HBM vectors, the HVP tensors autograd returns are consumed in place through a
+pointer table, and each iteration's dots/AXPYs are one persistent kernel (28*N bytes) or three
+streaming kernels (40*N bytes) instead of ~10*T ATen launches moving ~140*N bytes.
+"""
+from __future__ import annotations
+
+from ..backend import get_backend
+from ._common import AutogradHVP, inner_gradient, mixed_vjp
+from .structured import structured_hvp_for
+
+
+def cg(vector, curr, prev, sync):
+    """``vector`` (list aligned with ``curr``'s parameters) -> best-response-Jacobian^T product
+    in ``prev``'s parameter space.  ``sync=True``: accumulate into ``prev`` ``.grad`` and return
+    None; ``sync=False``: return the list (cg.py:58-68)."""
+    assert len(curr.paths) == 0, "cg method is not supported for higher order MLO!"
+    config = curr.config
+    be = get_backend()
+    vector = list(vector)
+
+    provider = structured_hvp_for(curr, prev)
+    if provider is None:
+        in_grad = inner_gradient(curr)
+        hvp_fn = AutogradHVP(in_grad, curr.parameters())
+    else:
+        in_grad = None
+        hvp_fn = provider.prepare()
+
+    layout = be.layout(vector)
+    x, r, p = layout.state(3)
+    be.cg_init(layout, vector, x, r, p)  # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
+    p_views = layout.views(p, vector)
+
+    K = int(config.cg_iterations)
+    alpha = float(config.cg_alpha)
+    for k in range(K):
+        hvp = hvp_fn(p_views)  # H p   (cg.py:39-41)
+        # cg.py:42-55 in one launch group; the last one also applies cg.py:56 and the negation
+        be.cg_step(layout, hvp, x, r, p, alpha, k, out_scale=(-alpha if k == K - 1 else 0.0))
+    # K == 0: x is identically zero, -alpha * 0 needs no pass.
+
+    neg_x = layout.views(x, vector)
+    if provider is not None:
+        return provider.mixed_vjp(neg_x, sync)
+    return mixed_vjp(in_grad, prev, neg_x, sync)

@@ -1,0 +1,46 @@
+"""Neumann-series best-response-Jacobian product on fused gfx950 kernels.
+
+Behavioural twin of /root/reference betty/hypergradient/neumann.py:8-66: ``p = v``; K times
+``v <- v - alpha*Hv ; p <- p + v``; result ``alpha*p`` pushed through the mixed second derivative.
+Each iteration is ONE streaming kernel (20*N bytes: read Hv, v, p; write v, p) instead of 4*T
+ATen launches; the final ``alpha*p`` and the negation are folded into the last iteration.
+"""
+from __future__ import annotations
+
+from ..backend import get_backend
+from ._common import AutogradHVP, inner_gradient, mixed_vjp
+from .structured import structured_hvp_for
+
+
+def neumann(vector, curr, prev, sync):
+    assert len(curr.paths) == 0, "neumann method is not supported for higher order MLO!"
+    config = curr.config
+    be = get_backend()
+    vector = list(vector)
+
+    provider = structured_hvp_for(curr, prev)
+    if provider is None:
+        in_grad = inner_gradient(curr)
+        # neumann.py:39 differentiates w.r.t. trainable_parameters() (cg uses parameters())
+        hvp_fn = AutogradHVP(in_grad, curr.trainable_parameters())
+    else:
+        in_grad = None
+        hvp_fn = provider.prepare()
+
+    layout = be.layout(vector)
+    v, p = layout.state(2)
+    be.neumann_init(layout, vector, v, p)  # p = v   (neumann.py:60)
+    v_views = layout.views(v, vector)
+
+    K = int(config.neumann_iterations)
+    alpha = float(config.neumann_alpha)
+    for k in range(K):
+        hvp = hvp_fn(v_views)  # neumann.py:62
+        be.neumann_step(layout, hvp, v, p, alpha, out_scale=(-alpha if k == K - 1 else 0.0))  # 63-64 (+66)
+    if K == 0:
+        be.scale_flat(p, -alpha)  # alpha * p with p = v   (neumann.py:66)
+
+    neg_p = layout.views(p, vector)
+    if provider is not None:
+        return provider.mixed_vjp(neg_p, sync)
+    return mixed_vjp(in_grad, prev, neg_p, sync)

@@ -1,0 +1,148 @@
+/*
+ * bhg.h — C ABI of the MI355X-native hypergradient backend (libbhg.so).
+ *
+ * This is the drop-in boundary for the implicit-differentiation hot path of
+ * leopard-ai/betty (`betty/hypergradient/{cg,neumann,darts}.py`).  The reference
+ * has no FFI of its own (it is pure Python on torch); the entry points below are
+ * what a binding for this path has to call: each one replaces a run of per-tensor
+ * ATen launches in the reference and cites the lines it replaces.
+ *
+ * Conventions
+ *   - Every pointer named *_dev / x / r / p / v / ws is a DEVICE pointer owned by
+ *     the caller (a PyTorch-ROCm tensor).  The library never allocates or frees
+ *     caller memory; all scratch lives in the caller-provided workspace `ws`
+ *     (size from bhg_workspace_bytes()).
+ *   - "tensor tables" (`const void* const* ptrs`, `T` entries) are HOST arrays of
+ *     device pointers to T separately allocated, contiguous fp32 tensors (what
+ *     torch.autograd.grad hands back each iteration).  They are consumed before
+ *     the call returns (copied into kernel arguments / the workspace), so the
+ *     caller may reuse the host array immediately.
+ *   - A `bhg_layout` describes how those T tensors map onto one flat fp32 vector:
+ *     tensor t occupies flat[start_t, start_t + numel_t) with start_t a multiple of
+ *     64 elements (256 B).  Padding elements are zero and are never written.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream).  No call synchronises the host.
+ *   - Return value: 0 = ok, negative = error (message via bhg_last_error()).
+ *     No C++ exception crosses this boundary.
+ *   - All arithmetic is fp32 with fp64 accumulation of dot products.
+ */
+#ifndef BHG_H_
+#define BHG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHG_VERSION 1
+#define BHG_CHUNK_ELEMS 4096 /* elements of one tensor handled by one work item   */
+#define BHG_FLAT_ALIGN 64    /* flat start of every tensor is a multiple of this  */
+
+/* error codes */
+#define BHG_OK 0
+#define BHG_ERR_ARG (-1)     /* bad argument (NULL pointer, negative size, ...)   */
+#define BHG_ERR_HIP (-2)     /* a HIP runtime call failed                         */
+#define BHG_ERR_WS (-3)      /* workspace too small                               */
+#define BHG_ERR_CAPACITY (-4)/* requested kernel variant cannot hold this N       */
+
+/* One unit of multi-tensor work: `len` (<= BHG_CHUNK_ELEMS) elements of tensor
+ * `tensor`, starting `src_off` elements into that tensor and `flat_off` elements
+ * into the flat vector.  Built once per parameter list by bhg_layout_build(). */
+typedef struct bhg_chunk {
+  int64_t flat_off;
+  int64_t src_off;
+  int32_t tensor;
+  int32_t len;
+} bhg_chunk;
+
+int bhg_version(void);
+const char* bhg_last_error(void);
+
+/* ---- layout helpers (host only, no GPU needed) -------------------------------
+ * Replace the implicit layout of betty/utils.py:117-118 (`to_vec` = cat of
+ * reshaped tensors): same element order, plus 256-B alignment padding. */
+int64_t bhg_layout_flat_size(const int64_t* numel, int T);
+int64_t bhg_layout_num_chunks(const int64_t* numel, int T);
+/* Fills starts[T] (flat start of every tensor) and chunks[num_chunks] (host memory;
+ * the caller uploads `chunks` to the device once). */
+int bhg_layout_build(const int64_t* numel, int T, int64_t* starts, bhg_chunk* chunks);
+/* Bytes of device workspace any call below may need for a T-tensor layout. */
+size_t bhg_workspace_bytes(int T);
+
+/* ---- multi-tensor <-> flat ----------------------------------------------------
+ * bhg_flatten: flat[...] = scale * tensors   (betty/utils.py:117-118 to_vec)      */
+int bhg_flatten(const void* const* src, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                float* flat, float scale, void* ws, void* stream);
+/* bhg_scatter: tensors = scale * flat[...]   (inverse of to_vec; used to hand
+ * results back as a list aligned with the parameters)                             */
+int bhg_scatter(const float* flat, void* const* dst, int T, const bhg_chunk* chunks_dev,
+                int n_chunks, float scale, void* ws, void* stream);
+
+/* ---- Neumann series: betty/hypergradient/neumann.py:59-66 ---------------------
+ * init:  v = p = vector                                    (neumann.py:60)
+ * step:  v <- v - alpha*Hv ; p <- p + v                    (neumann.py:62-64)
+ *        on the LAST step pass out_scale = -alpha to fold `alpha * p` (66) and the
+ *        negation of neumann.py:45/54 into the same pass; otherwise out_scale = 0. */
+int bhg_neumann_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                     float* v, float* p, void* ws, void* stream);
+int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                     float* v, float* p, float alpha, float out_scale, void* ws, void* stream);
+
+/* ---- Conjugate gradient: betty/hypergradient/cg.py:34-56 ----------------------
+ * init:  x = 0 ; r = p = vector ; rr = r.r                 (cg.py:34-36,45)
+ * step (iteration `iter` = 0,1,..):                        (cg.py:39-55)
+ *        den = (cg_alpha*Hp).p ; a = rr/den ; x += a*p ; r -= a*Hp (UN-scaled Hp:
+ *        reference quirk) ; b = r'.r'/rr ; p = r' + b*p ; rr = r'.r'
+ *        on the LAST step pass out_scale = -cg_alpha to fold cg.py:56 and the
+ *        negation of cg.py:59/68 into x; otherwise out_scale = 0.
+ * variant: BHG_CG_AUTO picks the register-resident single-pass kernel when the
+ *        vector fits on chip and the 3-kernel streaming form otherwise.
+ * After the call ws holds the iteration's scalars (see bhg_cg_read_scalars).      */
+#define BHG_CG_AUTO 0
+#define BHG_CG_STREAM 1     /* 3 streaming kernels, 40*N bytes per iteration         */
+#define BHG_CG_RESIDENT 2   /* 1 persistent kernel, 28*N bytes, N <= on-chip capacity */
+int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                float* x, float* r, float* p, void* ws, void* stream);
+int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                float* x, float* r, float* p, float cg_alpha, int iter, float out_scale,
+                int variant, void* ws, void* stream);
+/* Largest number of chunks BHG_CG_RESIDENT can hold on the current device (0 when
+ * no device is visible). */
+int bhg_cg_resident_capacity_chunks(void);
+/* Device address (inside ws) of 8 doubles: {rr_old, pHp, alpha, rr_new, beta, 0,0,0}
+ * written by the most recent bhg_cg_step on that workspace. */
+const double* bhg_cg_scalars_dev(const void* ws);
+
+/* ---- flat helpers ------------------------------------------------------------- */
+/* flat <- scale * flat  (cg.py:56 / neumann.py:66 when iterations == 0)           */
+int bhg_scale_flat(float* flat, int64_t n, float scale, void* stream);
+
+/* ---- DARTS finite difference: betty/hypergradient/darts.py:29-38,49-50,62-63 --
+ * bhg_darts_eps: eps = R / (||vec||_2 + 1e-15) computed entirely on device
+ *        (darts.py:29-35 without the host .item()).  out_dev[0] = sum of squares,
+ *        out_dev[1] = eps (both double); eps_f32_dev receives (float)eps.
+ * bhg_axpy_multi: dst_t += (mul * *coef_dev) * src_t for all t (coef_dev may be
+ *        NULL => coefficient = mul): the three in-place weight perturbations.     */
+int bhg_darts_eps(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                  double R, double* out_dev, float* eps_f32_dev, void* ws, void* stream);
+int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_chunk* chunks_dev,
+                   int n_chunks, const float* coef_dev, float mul, void* ws, void* stream);
+
+/* ---- analytic Hessian-vector products (structured inner problems) --------------
+ * Logistic regression with per-weight L2 (the inner problem of
+ * examples/logistic_regression_hpo/logistic_regression_implicit.py:80-91):
+ *   Hp = X^T( s .* (X p) ) + lam .* p,  s_i = sigma_i (1 - sigma_i) / n.
+ * bhg_logreg_prepare computes s from (X, w) once per hypergradient step;
+ * bhg_logreg_hvp applies it.  X is row-major [n, d] fp32.                          */
+int bhg_logreg_prepare(const float* X, const float* w, float* s, int n, int d, void* stream);
+/* fp32 elements of device scratch bhg_logreg_hvp needs in `tmp` */
+size_t bhg_logreg_tmp_floats(int n, int d);
+int bhg_logreg_hvp(const float* X, const float* s, const float* lam, const float* p, float* out,
+                   float* tmp, int n, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHG_H_ */

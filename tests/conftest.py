@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+_GOLDEN_CACHE = {}
+
+
+def load_golden(family):
+    """tests/golden/<family>.npz -> (inputs dict, outputs dict keyed '<case>/<kind>/<i>')."""
+    if family not in _GOLDEN_CACHE:
+        blob = np.load(os.path.join(HERE, "golden", f"{family}.npz"))
+        inputs = {k[3:]: blob[k] for k in blob.files if k.startswith("in/")}
+        outputs = {k[4:]: blob[k] for k in blob.files if k.startswith("out/")}
+        _GOLDEN_CACHE[family] = (inputs, outputs)
+    return _GOLDEN_CACHE[family]
+
+
+def golden_list(outputs, case_name, kind):
+    out = []
+    i = 0
+    while f"{case_name}/{kind}/{i}" in outputs:
+        out.append(outputs[f"{case_name}/{kind}/{i}"])
+        i += 1
+    return out
+
+
+def rel_err(got, want):
+    """Relative L2 error over a list of arrays, and max-abs error relative to max |want|."""
+    g = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in got])
+    w = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in want])
+    if not np.all(np.isfinite(g)):
+        return float("inf"), float("inf")
+    nw = np.linalg.norm(w)
+    if nw == 0.0:
+        return float(np.linalg.norm(g)), float(np.abs(g).max(initial=0.0))
+    return float(np.linalg.norm(g - w) / nw), float(np.abs(g - w).max() / np.abs(w).max())

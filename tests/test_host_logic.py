@@ -1,0 +1,117 @@
+"""Host orchestration of betty_amd.hypergradient (flat state, autograd views, sync semantics,
+registry / get_grads) on CPU, with the kernels replaced by the C oracle through the test-only
+checker backend.  The GPU suite (test_gpu_parity.py) runs the same cases through the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+import zoo
+from _cpu_checker_backend import CpuCheckerBackend
+from conftest import golden_list, load_golden, rel_err
+
+import betty_amd
+from betty_amd import Config
+from betty_amd import hypergradient as hg
+from betty_amd.backend import use_backend
+
+
+@pytest.fixture()
+def checker():
+    with use_backend(CpuCheckerBackend()) as b:
+        yield b
+
+
+@pytest.mark.parametrize("case", zoo.CASES, ids=lambda c: c.name)
+def test_host_path_matches_reference(case, checker):
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config)
+    w_before = [p.data.clone() for p in curr.trainable_parameters()]
+    v_before = [v.clone() for v in vector]
+    out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, False)
+    want = golden_list(outputs, case.name, "fp32")
+    assert len(out) == len(want)
+    rel, mx = rel_err([o.detach().numpy() for o in out], want)
+    assert rel <= case.rtol and mx <= 10 * case.rtol, (rel, mx)
+    for v, vb in zip(vector, v_before):  # the direction vector is never mutated (cg.py:35 copies)
+        assert torch.equal(v, vb)
+    if case.algo == "darts":  # weights restored up to the reference's own drift
+        for p, w in zip(curr.trainable_parameters(), golden_list(outputs, case.name, "w32")):
+            np.testing.assert_allclose(p.data.numpy(), w, rtol=0, atol=1e-7)
+    else:
+        for p, w in zip(curr.trainable_parameters(), w_before):
+            assert torch.equal(p.data, w)
+
+
+@pytest.mark.parametrize("case", zoo.CASES, ids=lambda c: c.name)
+def test_sync_accumulates_and_returns_none(case, checker):
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config)
+    # pre-existing gradient must be accumulated into, not overwritten (problem.py:592-597)
+    for p in prev.trainable_parameters():
+        p.grad = torch.full_like(p, 0.25)
+    ret = hg.jvp_fn_mapping[case.algo](vector, curr, prev, True)
+    assert ret is None
+    got = [p.grad.detach().numpy() - 0.25 for p in prev.trainable_parameters()]
+    want = golden_list(outputs, case.name, "sync32")
+    rel, _ = rel_err(got, want)
+    scale = max(1.0, 0.25 / max(np.abs(np.concatenate([w.ravel() for w in want])).max(), 1e-30))
+    assert rel <= case.rtol * scale + 1e-6 * scale
+
+
+def test_registry_and_get_grads(checker):
+    assert set(hg.jvp_fn_mapping) == {"cg", "neumann", "darts"}
+    case = zoo.CASE_BY_NAME["logreg_cg5"]
+    inputs, _ = load_golden("logreg")
+    curr, prev, _ = zoo.build_case(case, inputs, Config)
+    # upper loss = validation BCE through the inner weights; path = [upper, inner, upper]
+    xv = torch.from_numpy(inputs["batch_x"][:64])
+    yv = torch.from_numpy(inputs["batch_y"][:64])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(xv @ curr.module.w, yv)
+    out = hg.get_grads(loss, [prev, curr, prev], retain_graph=False, do_sync=False)
+    assert len(out) == 1 and out[0].shape == (100,)
+    # against the oracle's get_grads on an identical fresh problem
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as orc
+
+    curr2, prev2, _ = zoo.build_case(case, inputs, Config)
+    loss2 = torch.nn.functional.binary_cross_entropy_with_logits(xv @ curr2.module.w, yv)
+    want = orc.get_grads(loss2, [prev2, curr2, prev2], False, False)
+    rel, _ = rel_err([out[0].detach().numpy()], [want[0].detach().numpy()])
+    assert rel < 1e-5
+    # do_sync=True: result lands in .grad, returns None
+    curr3, prev3, _ = zoo.build_case(case, inputs, Config)
+    loss3 = torch.nn.functional.binary_cross_entropy_with_logits(xv @ curr3.module.w, yv)
+    assert hg.get_grads(loss3, [prev3, curr3, prev3], False, True) is None
+    rel, _ = rel_err([prev3.module.w.grad.numpy()], [want[0].detach().numpy()])
+    assert rel < 1e-5
+
+
+def test_higher_order_paths_rejected(checker):
+    case = zoo.CASE_BY_NAME["logreg_cg5"]
+    inputs, _ = load_golden("logreg")
+    curr, prev, vector = zoo.build_case(case, inputs, Config)
+    curr.paths = [[curr, prev, curr]]
+    with pytest.raises(AssertionError, match="higher order"):
+        hg.cg(vector, curr, prev, False)
+    curr.config = Config(type="neumann")
+    with pytest.raises(AssertionError, match="higher order"):
+        hg.neumann(vector, curr, prev, False)
+
+
+def test_config_matches_reference_defaults():
+    c = Config()
+    assert (c.type, c.cg_iterations, c.cg_alpha, c.neumann_iterations, c.neumann_alpha) == ("darts", 1, 1.0, 1, 1.0)
+    assert (c.darts_alpha, c.darts_multitask, c.first_order, c.retain_graph, c.allow_unused) == (0.01, False, True, False, True)
+    assert (c.gradient_accumulation, c.precision, c.unroll_steps) == (1, "fp32", 1)
+
+
+def test_install_mutates_registry_in_place():
+    class FakeRef:
+        jvp_fn_mapping = {"cg": 1, "neumann": 2, "darts": 3, "sama": 4, "reinforce": 5}
+
+    mapping = FakeRef.jvp_fn_mapping
+    betty_amd.install(FakeRef)
+    assert FakeRef.jvp_fn_mapping is mapping
+    assert mapping["cg"] is hg.cg and mapping["neumann"] is hg.neumann and mapping["darts"] is hg.darts
+    assert mapping["sama"] == 4

@@ -1,0 +1,95 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/bhg.h declares;
+host-only entry points (layout builder, version, error string) behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from betty_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bhg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bhg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    declared = _declared_symbols()
+    assert declared, "no prototypes found in include/bhg.h"
+    assert sorted(_native.SYMBOLS) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.bhg_version() == 1
+    assert lib.bhg_last_error() is not None
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libbhg.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_product_backend_refuses_cpu():
+    import torch
+
+    from betty_amd.backend import HipBackend
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        HipBackend()
+
+
+@pytest.mark.parametrize(
+    "numels",
+    [[], [0], [1], [63, 64, 65], [4096], [4097, 3, 0, 8192], [10, 5000, 4096, 1], [3072 * 2048, 2048, 2048 * 1536, 1536, 1536 * 384, 384, 3840, 10]],
+)
+def test_layout_builder(numels):
+    lib = _native.load()
+    T = len(numels)
+    arr = (ctypes.c_int64 * max(T, 1))(*numels)
+    flat = lib.bhg_layout_flat_size(arr, T)
+    nch = lib.bhg_layout_num_chunks(arr, T)
+    assert nch == sum((n + 4095) // 4096 for n in numels)
+    starts = (ctypes.c_int64 * max(T, 1))()
+    chunks = (_native.Chunk * max(nch, 1))()
+    assert lib.bhg_layout_build(arr, T, starts, chunks) == 0
+    # every element of every tensor is covered exactly once, flat starts are 64-aligned, no overlap
+    cover = np.zeros(max(flat, 1), dtype=np.int32)
+    pos = 0
+    for t, n in enumerate(numels):
+        assert starts[t] % 64 == 0 and starts[t] >= pos
+        pos = starts[t] + n
+    assert flat % 64 == 0 and flat >= pos
+    per_tensor = [np.zeros(n, dtype=np.int32) for n in numels]
+    for c in range(nch):
+        ck = chunks[c]
+        assert 0 < ck.len <= 4096 and ck.src_off % 4096 == 0
+        assert ck.flat_off == starts[ck.tensor] + ck.src_off
+        per_tensor[ck.tensor][ck.src_off : ck.src_off + ck.len] += 1
+        cover[ck.flat_off : ck.flat_off + ck.len] += 1
+    for a in per_tensor:
+        assert (a == 1).all()
+    assert cover.max(initial=0) <= 1
+    assert lib.bhg_workspace_bytes(T) >= 24576 + 16 * T
+
+
+def test_layout_builder_rejects_bad_sizes():
+    lib = _native.load()
+    arr = (ctypes.c_int64 * 2)(5, -1)
+    assert lib.bhg_layout_flat_size(arr, 2) == -1
+    assert lib.bhg_layout_num_chunks(arr, 2) == -1
+    starts = (ctypes.c_int64 * 2)()
+    chunks = (_native.Chunk * 4)()
+    assert lib.bhg_layout_build(arr, 2, starts, chunks) == -1
+    assert b"negative" in lib.bhg_last_error()

@@ -1,0 +1,270 @@
+"""Seeded synthetic bilevel problems shared by the golden generator, the oracle tests and the
+GPU parity tests.
+
+Every case is a pair of duck-typed problems exposing exactly the surface the reference's
+``cg`` / ``neumann`` / ``darts`` touch (SURVEY.md §8b "Object surface"): ``paths``, ``config``,
+``cur_batch``, ``training_step_exec``, ``trainable_parameters``, ``parameters``,
+``meta_trainable_parameters``, ``_strategy``, ``set_grads``.  The same objects run through
+  * the real reference (tests/golden/make_golden.py, in the build container only),
+  * the CPU oracle (oracle/hypergrad_oracle.py),
+  * the HIP path (betty_amd.hypergradient) on the GPU box.
+Inputs (weights, data, direction vector) are stored in the golden files so all three see
+bit-identical numbers.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, Dict, List
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class StubProblem:
+    """Minimal stand-in for betty's ``ImplicitProblem`` (implicit_problem.py:80-84,
+    problem.py:327-332,583-597,850-854)."""
+
+    def __init__(self, name, module, config=None, loss_fn=None, batch=None):
+        self.name = name
+        self.module = module
+        self.config = config
+        self._loss_fn = loss_fn
+        self.cur_batch = batch
+        self.paths = []
+        self._strategy = "default"
+
+    def training_step_exec(self, batch):
+        return self._loss_fn(self, batch)
+
+    def parameters(self):
+        return list(self.module.parameters())
+
+    def trainable_parameters(self):
+        return list(self.module.parameters())
+
+    def meta_trainable_parameters(self):
+        return self.trainable_parameters()
+
+    def set_grads(self, params, grads):
+        for param, grad in zip(params, grads):
+            if grad is not None:
+                if getattr(param, "grad", None) is not None:
+                    param.grad = param.grad + grad
+                else:
+                    param.grad = grad
+
+
+# ---------------------------------------------------------------------------------------------
+# modules
+# ---------------------------------------------------------------------------------------------
+class Vec(nn.Module):
+    """A bare parameter vector; forward returns a NON-leaf (``w * 1``) so the module also works
+    under DistributedDataParallel (SURVEY.md §8e caveat)."""
+
+    def __init__(self, n, fill=0.0):
+        super().__init__()
+        self.w = nn.Parameter(torch.full((n,), float(fill)))
+
+    def forward(self):
+        return self.w * 1.0
+
+
+class MLP(nn.Module):
+    def __init__(self, sizes):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:])])
+
+    def forward(self, x):
+        for i, lin in enumerate(self.layers):
+            x = lin(x)
+            if i + 1 < len(self.layers):
+                x = F.relu(x)
+        return x
+
+
+class MWN(nn.Module):
+    """Meta-weight-net 1 -> h -> 1 with sigmoid output (examples/learning_to_reweight/model.py:98-111)."""
+
+    def __init__(self, hidden):
+        super().__init__()
+        self.l1 = nn.Linear(1, hidden)
+        self.l2 = nn.Linear(hidden, 1)
+
+    def forward(self, x):
+        return torch.sigmoid(self.l2(F.relu(self.l1(x))))
+
+
+class SmallConv(nn.Module):
+    def __init__(self, ways=5):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 8, 3, padding=1)
+        self.c2 = nn.Conv2d(8, 8, 3, padding=1)
+        self.fc = nn.Linear(8 * 4 * 4, ways)
+
+    def forward(self, x):
+        x = F.max_pool2d(torch.tanh(self.c1(x)), 2)
+        x = F.max_pool2d(torch.tanh(self.c2(x)), 2)
+        return self.fc(x.flatten(1))
+
+
+# ---------------------------------------------------------------------------------------------
+# inner losses (what the user writes in ``training_step``)
+# ---------------------------------------------------------------------------------------------
+def make_logreg_loss(upper):
+    # examples/logistic_regression_hpo/logistic_regression_implicit.py:80-91
+    def loss(self, batch):
+        x, y = batch
+        w = self.module.w
+        lam = upper.module()
+        return F.binary_cross_entropy_with_logits(x @ w, y) + 0.5 * (lam * w * w).sum()
+
+    return loss
+
+
+def make_reweight_loss(upper, ridge):
+    # examples/learning_to_reweight/main.py:117-127 (+ ridge keeps H positive definite for CG)
+    def loss(self, batch):
+        x, y = batch
+        logits = self.module(x)
+        ce = F.cross_entropy(logits, y, reduction="none")
+        weight = upper.module(ce.detach().reshape(-1, 1))
+        out = torch.mean(weight.reshape(-1) * ce)
+        if ridge:
+            out = out + ridge * sum((p * p).sum() for p in self.module.parameters())
+        return out
+
+    return loss
+
+
+def make_imaml_loss(upper, reg):
+    # examples/implicit_maml/main.py:87-92,122-129: CE + reg * ||w - theta||^2
+    def loss(self, batch):
+        x, y = batch
+        out = F.cross_entropy(self.module(x), y)
+        prox = sum(((p - q) ** 2).sum() for p, q in zip(self.module.parameters(), upper.module.parameters()))
+        return out + reg * prox
+
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------
+# case registry
+# ---------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class Case:
+    name: str
+    family: str  # logreg | reweight | imaml | deep
+    algo: str  # cg | neumann | darts
+    cfg: Dict  # Config kwargs
+    rtol: float = 1e-4  # parity tolerance of the HIP path against the fp32 reference golden
+
+
+CASES: List[Case] = [
+    # cfg 1 of BASELINE.json (plumbing case) and its variants
+    Case("logreg_cg5", "logreg", "cg", dict(type="cg", cg_iterations=5, cg_alpha=1.0)),
+    Case("logreg_cg3_a01", "logreg", "cg", dict(type="cg", cg_iterations=3, cg_alpha=0.1)),
+    Case("logreg_cg0", "logreg", "cg", dict(type="cg", cg_iterations=0, cg_alpha=1.0)),
+    Case("logreg_neumann5", "logreg", "neumann", dict(type="neumann", neumann_iterations=5, neumann_alpha=0.5)),
+    Case("logreg_neumann0", "logreg", "neumann", dict(type="neumann", neumann_iterations=0, neumann_alpha=0.5)),
+    Case("logreg_darts", "logreg", "darts", dict(type="darts", darts_alpha=0.01), rtol=2e-3),
+    # cfg 2 shape (reduced): ReLU-MLP inner with MWN-weighted CE
+    Case("reweight_neumann10", "reweight", "neumann", dict(type="neumann", neumann_iterations=10, neumann_alpha=0.1)),
+    Case("reweight_cg20", "reweight", "cg", dict(type="cg", cg_iterations=20, cg_alpha=1.0)),
+    Case("reweight_darts", "reweight", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
+    # cfg 3 shape (reduced): conv net inner, prox-regularised to the upper copy (M = N)
+    Case("imaml_cg10", "imaml", "cg", dict(type="cg", cg_iterations=10, cg_alpha=1.0)),
+    # many small tensors (T = 48 > 32): exercises the device pointer-table path (cfg 5 shape)
+    Case("deep_neumann6", "deep", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.2)),
+    Case("deep_cg6", "deep", "cg", dict(type="cg", cg_iterations=6, cg_alpha=1.0)),
+    Case("deep_darts", "deep", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
+]
+CASE_BY_NAME = {c.name: c for c in CASES}
+
+
+def _family_modules(family):
+    """Fresh (randomly initialised) inner/upper modules of a family; weights are overwritten
+    from the golden file afterwards."""
+    if family == "logreg":
+        return Vec(100, 0.0), Vec(100, 1.0)
+    if family == "reweight":
+        return MLP([48, 64, 32, 10]), MWN(16)
+    if family == "imaml":
+        return SmallConv(5), SmallConv(5)
+    if family == "deep":
+        return MLP([12] + [12] * 23 + [4]), MWN(8)  # 24 Linear layers = 48 tensors
+    raise KeyError(family)
+
+
+def seed_family_inputs(family, seed=0):
+    """Create the seeded inputs of a family (run ONCE by make_golden.py; everyone else loads
+    the stored arrays)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    torch.manual_seed(2000 + seed)
+    inner, upper = _family_modules(family)
+    arrays = {}
+    if family == "logreg":
+        # BASELINE.md cfg 1: w_gt~N(0,1)^100, X~N(0,1)^{1000x100}, y=(X w_gt + 0.1 eps > 0), 500 train
+        w_gt = torch.randn(100, generator=g)
+        X = torch.randn(1000, 100, generator=g)
+        y = ((X @ w_gt + 0.1 * torch.randn(1000, generator=g)) > 0).float()
+        xtr, ytr = X[:500].clone(), y[:500].clone()
+        w = torch.zeros(100)
+        for _ in range(100):  # 100 SGD steps, lr 0.1, lambda = 1
+            z = xtr @ w
+            gw = xtr.t() @ (torch.sigmoid(z) - ytr) / 500 + w
+            w = w - 0.1 * gw
+        inner.w.data.copy_(w)
+        arrays["batch_x"], arrays["batch_y"] = xtr, ytr
+    elif family in ("reweight", "deep"):
+        d_in = 48 if family == "reweight" else 12
+        n_cls = 10 if family == "reweight" else 4
+        B = 40
+        arrays["batch_x"] = torch.randn(B, d_in, generator=g)
+        yy = torch.randint(0, n_cls, (B,), generator=g)
+        flip = torch.rand(B, generator=g) < 0.4
+        yy = torch.where(flip, torch.randint(0, n_cls, (B,), generator=g), yy)
+        arrays["batch_y"] = yy
+    elif family == "imaml":
+        arrays["batch_x"] = torch.randn(25, 3, 16, 16, generator=g)
+        arrays["batch_y"] = torch.arange(5).repeat_interleave(5)
+        # outer copy = inner + small perturbation, like a few adaptation steps apart
+        for p, q in zip(inner.parameters(), upper.parameters()):
+            q.data.copy_(p.data + 0.05 * torch.randn(p.shape, generator=g))
+    for i, p in enumerate(inner.parameters()):
+        arrays[f"inner_{i}"] = p.data.clone()
+        arrays[f"vec_{i}"] = 0.01 * torch.randn(p.shape, generator=g)
+    for i, p in enumerate(upper.parameters()):
+        arrays[f"upper_{i}"] = p.data.clone()
+    return {k: v.numpy() for k, v in arrays.items()}
+
+
+FAMILY_LOSS: Dict[str, Callable] = {
+    "logreg": lambda upper: make_logreg_loss(upper),
+    "reweight": lambda upper: make_reweight_loss(upper, 0.5),
+    "imaml": lambda upper: make_imaml_loss(upper, 0.5),
+    "deep": lambda upper: make_reweight_loss(upper, 0.5),
+}
+
+
+def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cpu", dtype=torch.float32):
+    """Instantiate (curr, prev, vector) of a case from stored inputs."""
+    inner, upper = _family_modules(case.family)
+
+    def T(a):
+        t = torch.from_numpy(np.asarray(a))
+        if t.is_floating_point():
+            t = t.to(dtype)
+        return t.to(device)
+
+    inner, upper = inner.to(device=device, dtype=dtype), upper.to(device=device, dtype=dtype)
+    for i, p in enumerate(inner.parameters()):
+        p.data.copy_(T(inputs[f"inner_{i}"]))
+    for i, p in enumerate(upper.parameters()):
+        p.data.copy_(T(inputs[f"upper_{i}"]))
+    vector = [T(inputs[f"vec_{i}"]) for i in range(len(list(inner.parameters())))]
+    batch = (T(inputs["batch_x"]), T(inputs["batch_y"]))
+    prev = StubProblem("upper", upper, config=config_cls())
+    curr = StubProblem("inner", inner, config=config_cls(**case.cfg), loss_fn=FAMILY_LOSS[case.family](prev), batch=batch)
+    return curr, prev, vector
