@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""bench.py — hypergradient-steps/sec (CG K=20, 10 M inner params) on N MI355X.
+
+One "step" = one call of the hot path ``cg(vector, curr, prev, sync=True)``: inner-loss
+re-evaluation + gradient with graph, K=20 x (Hessian-vector product + fused CG recurrence), and
+the final mixed-derivative VJP accumulated into the upper parameters' ``.grad`` (the path
+``Problem.backward -> get_grads -> cg`` of the reference, betty/hypergradient/cg.py:8-70).
+
+Workload = BASELINE.json configs[1]'s inner problem at the size the metric is quoted on
+(BASELINE.md cfg 2 / metric): ReLU-MLP 3072-2048-1536-384-10 (N = 10,034,826 in 8 tensors) with
+meta-weight-net-weighted cross-entropy (+1e-2 ||w||^2 so H is positive definite), upper problem
+MWN 1-100-1 (M = 301), batch 100 x 3072, synthetic seeded data already resident in HBM.
+
+Multi-GPU (``--gpus N`` under torch.distributed.run): the path shards by replica exactly as the
+reference's DDP mode does — every rank solves on its local batch with no collective inside the CG
+loop; the M-sized hypergradient is all-reduced (mean) by the DDP reducer over RCCL when the
+``sync=True`` backward fires.  Weak scaling: value = N * steps / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from betty_amd import Config  # noqa: E402
+from betty_amd import hypergradient as hg  # noqa: E402
+
+SIZES = [3072, 2048, 1536, 384, 10]
+BATCH = 100
+RIDGE = 1e-2
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s float4 copy)
+
+
+class InnerMLP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(SIZES[:-1], SIZES[1:])])
+
+    def forward(self, x):
+        for i, lin in enumerate(self.layers):
+            x = lin(x)
+            if i + 1 < len(self.layers):
+                x = F.relu(x)
+        return x
+
+
+class MWN(nn.Module):
+    def __init__(self, hidden=100):
+        super().__init__()
+        self.l1 = nn.Linear(1, hidden)
+        self.l2 = nn.Linear(hidden, 1)
+
+    def forward(self, x):
+        return torch.sigmoid(self.l2(F.relu(self.l1(x))))
+
+
+class Problem:
+    """The slice of betty's ImplicitProblem the hot path touches."""
+
+    def __init__(self, name, module, config, loss_fn=None, batch=None, forward_module=None):
+        self.name, self.module, self.config = name, module, config
+        self._loss_fn, self.cur_batch = loss_fn, batch
+        self.paths, self._strategy = [], "default"
+        self.fwd = forward_module if forward_module is not None else module
+
+    def training_step_exec(self, batch):
+        return self._loss_fn(self, batch)
+
+    def parameters(self):
+        return list(self.module.parameters())
+
+    trainable_parameters = parameters
+    meta_trainable_parameters = parameters
+
+    def set_grads(self, params, grads):
+        for p, g in zip(params, grads):
+            if g is not None:
+                p.grad = g if p.grad is None else p.grad + g
+
+
+def make_loss(upper):
+    def loss(self, batch):
+        x, y = batch
+        ce = F.cross_entropy(self.fwd(x), y, reduction="none")
+        w = upper.fwd(ce.detach().reshape(-1, 1)).reshape(-1)
+        out = torch.mean(w * ce)
+        return out + RIDGE * sum((p * p).sum() for p in self.module.parameters())
+
+    return loss
+
+
+def build(device, seed, dtype=torch.float32, ddp=False, K=20):
+    torch.manual_seed(seed)
+    inner = InnerMLP().to(device=device, dtype=dtype)
+    mwn = MWN(100).to(device=device, dtype=dtype)
+    g = torch.Generator().manual_seed(1234 + seed)
+    x = torch.randn(BATCH, SIZES[0], generator=g).to(device=device, dtype=dtype)
+    y = torch.randint(0, 10, (BATCH,), generator=g)
+    flip = torch.rand(BATCH, generator=g) < 0.4
+    y = torch.where(flip, torch.randint(0, 10, (BATCH,), generator=g), y).to(device)
+    vector = [(0.01 * torch.randn(p.shape, generator=g)).to(device=device, dtype=dtype) for p in inner.parameters()]
+    fwd = mwn
+    if ddp:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        # the wrapper the reference uses, problem.py:220-224
+        fwd = DDP(mwn, device_ids=[device.index], gradient_as_bucket_view=True, find_unused_parameters=True)
+    prev = Problem("upper", mwn, Config(), forward_module=fwd)
+    curr = Problem("inner", inner, Config(type="cg", cg_iterations=K, cg_alpha=1.0), loss_fn=make_loss(prev), batch=(x, y))
+    return curr, prev, vector
+
+
+def cpu_baseline(steps, K):
+    """The oracle (line-for-line restatement of the reference's CPU autograd path, pinned
+    bit-for-bit against it in tests/test_oracle.py) timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hypergrad_oracle as orc
+
+    # torch's CPU kernels stop scaling (and oversubscribe badly) far below the 256 hardware
+    # threads of the GPU box's host: use at most 32 and say so.
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    curr, prev, vector = build(torch.device("cpu"), seed=0, K=K)
+    orc.cg(vector, curr, prev, False)  # warm-up
+    times = []
+    budget_t0 = time.perf_counter()
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        orc.cg(vector, curr, prev, False)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - budget_t0 > 25.0:  # bounded sample
+            break
+    steps = len(times)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": 1.0 / med,
+        "unit": "hypergradient-steps/sec",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{steps} steps of the same workload (cg K={K}, N=10,034,826, batch {BATCH}), median; "
+        f"oracle/hypergrad_oracle.py on torch CPU fp32, min {times[0]:.3f}s max {times[-1]:.3f}s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cg-iters", type=int, default=20)
+    ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; betty_amd has no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from betty_amd import _native
+    from betty_amd.backend import get_backend
+
+    be = get_backend()
+    be.cg_variant = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}[args.variant]
+    K = args.cg_iters
+    curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K)
+    N = sum(p.numel() for p in curr.parameters())
+    M = sum(p.numel() for p in prev.parameters())
+    layout = be.layout(vector)
+    resident = args.variant == "resident" or (args.variant == "auto" and layout.n_chunks <= be.lib.bhg_cg_resident_capacity_chunks())
+
+    # per-launch timing of the CG recurrence with HIP events on the stream the kernels run on
+    events = []
+    timing_on = not args.no_kernel_timing
+    orig_step = be.cg_step
+
+    def timed_step(*a, **kw):
+        if not timing_on or not recording[0]:
+            return orig_step(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_step(*a, **kw)
+        e1.record()
+        events.append((e0, e1))
+
+    recording = [False]
+    be.cg_step = timed_step
+
+    def step():
+        for p in prev.parameters():
+            p.grad = None
+        out = hg.cg(vector, curr, prev, True)
+        assert out is None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    recording[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    recording[0] = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    out = None
+    if rank == 0:
+        value = world * args.steps / elapsed
+        roof = None
+        if kern_ms:
+            avg_us = 1e3 * sum(kern_ms) / len(kern_ms)
+            alg_bytes = 28.0 * N  # read Hp,p,r,x; write x,r,p (fp32) per CG iteration
+            achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+            roof = {
+                "bound": "hbm",
+                "kernel": "k_cg_resident (1 launch/iter)" if resident else "k_cg_dot+k_cg_resid+k_cg_dir (3 launches/iter)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": avg_us,
+                "launches_timed": len(kern_ms),
+            }
+        out = {
+            "metric": "hypergradient-steps/sec (CG K=20, 10M inner params)",
+            "value": value,
+            "unit": "hypergradient-steps/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE cfg2/metric: MLP 3072-2048-1536-384-10 inner (N=%d, 8 tensors), MWN 1-100-1 upper (M=%d), "
+                "batch %d, cg K=%d alpha=1, sync=True" % (N, M, BATCH, K),
+                "hvp": "pytorch-rocm autograd double backward",
+                "cg_variant": "resident" if resident else "stream",
+                "parallelism": "replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU",
+                "finite": finite,
+            },
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps, K)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,304 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against
+  * the goldens produced by the real reference (fp32, tolerance per case, 1e-4 for cg/neumann),
+  * the C oracle, kernel by kernel, on ragged multi-tensor inputs,
+  * closed forms at BASELINE.json's full size (N = 10,034,826) where the oracle would be slow.
+Tolerances are written next to each assertion.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import zoo
+from conftest import golden_list, load_golden, rel_err
+
+from betty_amd import Config, _native
+from betty_amd import hypergradient as hg
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def be():
+    from betty_amd.backend import get_backend
+
+    b = get_backend()
+    assert b.name == "hip"
+    return b
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from _cpu_checker_backend import load_oracle_lib
+
+    return load_oracle_lib()
+
+
+def _np(ts):
+    return [t.detach().cpu().numpy() for t in ts]
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end against the reference goldens
+# ------------------------------------------------------------------------------------------------
+VARIANTS = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}
+
+
+@pytest.mark.parametrize("variant", ["stream", "resident"])
+@pytest.mark.parametrize("case", zoo.CASES, ids=lambda c: c.name)
+def test_hip_path_matches_reference(case, variant, be):
+    if case.algo != "cg" and variant == "resident":
+        pytest.skip("variant only affects cg")
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    v_before = [v.clone() for v in vector]
+    w_before = [p.data.clone() for p in curr.trainable_parameters()]
+    be.cg_variant = VARIANTS[variant]
+    try:
+        out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, False)
+    finally:
+        be.cg_variant = _native.BHG_CG_AUTO
+    want = golden_list(outputs, case.name, "fp32")
+    assert len(out) == len(want)
+    rel, mx = rel_err(_np(out), want)
+    # rtol: 1e-4 (north_star) for cg/neumann; finite differences carry the fp32 noise the reference
+    # itself shows between its fp32 and fp64 runs (Case.rtol)
+    assert rel <= case.rtol and mx <= 10 * case.rtol, (case.name, variant, rel, mx)
+    for v, vb in zip(vector, v_before):
+        assert torch.equal(v, vb), "direction vector must not be mutated"
+    if case.algo == "darts":
+        for p, w in zip(curr.trainable_parameters(), golden_list(outputs, case.name, "w32")):
+            np.testing.assert_allclose(p.data.cpu().numpy(), w, rtol=0, atol=2e-7)
+    else:
+        for p, w in zip(curr.trainable_parameters(), w_before):
+            assert torch.equal(p.data, w)
+
+
+@pytest.mark.parametrize("case", zoo.CASES, ids=lambda c: c.name)
+def test_hip_sync_accumulates_and_returns_none(case, be):
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    for p in prev.trainable_parameters():
+        p.grad = torch.full_like(p, 0.25)
+    assert hg.jvp_fn_mapping[case.algo](vector, curr, prev, True) is None
+    got = [p.grad.detach().cpu().numpy().astype(np.float64) - 0.25 for p in prev.trainable_parameters()]
+    want = golden_list(outputs, case.name, "sync32")
+    rel, _ = rel_err(got, want)
+    wmax = max(np.abs(np.concatenate([w.ravel() for w in want])).max(), 1e-30)
+    scale = max(1.0, 0.25 / wmax)  # the 0.25 offset costs fp32 digits when the result is tiny
+    assert rel <= case.rtol * scale + 2e-7 * scale, (case.name, rel)
+
+
+def test_cg_is_bitwise_deterministic(be):
+    # (MLP case: MIOpen's conv weight-gradient kernels use float atomics, so a conv inner model is
+    # not run-to-run reproducible in PyTorch itself; our kernels use fixed-order reductions.)
+    case = zoo.CASE_BY_NAME["reweight_cg20"]
+    inputs, _ = load_golden(case.family)
+    outs = []
+    for _ in range(3):
+        curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+        outs.append(_np(hg.cg(vector, curr, prev, False)))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel level against the C oracle on ragged multi-tensor inputs
+# ------------------------------------------------------------------------------------------------
+RAGGED = [
+    [1],
+    [3, 5, 7],
+    [4095, 4096, 4097],
+    [10000, 1, 64, 63, 8193],
+    [17] * 50,  # T = 50 > 32: device pointer table
+    [4096 * 3 + 5, 2, 4096],
+    [250000, 130001, 77],
+]
+
+
+def _rand_list(sizes, gen, scale=1.0):
+    return [(scale * torch.randn(n, generator=gen)).to(DEV) for n in sizes]
+
+
+def _flat_concat(layout, flat):
+    return torch.cat([flat[s : s + n] for s, n in zip(layout.starts, layout.numels)]).cpu().numpy()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("sizes", RAGGED, ids=lambda s: f"T{len(s)}_N{sum(s)}")
+def test_flatten_scatter_axpy_bitwise(sizes, be):
+    gen = torch.Generator().manual_seed(sum(sizes))
+    src = _rand_list(sizes, gen)
+    lay = be.layout(src)
+    flat = lay.new_flat()
+    be.flatten(lay, src, flat, 0.37)
+    want = np.concatenate([(np.float32(0.37) * t.cpu().numpy()) for t in src])
+    np.testing.assert_array_equal(_flat_concat(lay, flat), want)
+    # padding untouched
+    mask = torch.ones(lay.flat_size, dtype=torch.bool)
+    for s, n in zip(lay.starts, lay.numels):
+        mask[s : s + n] = False
+    assert float(flat.cpu()[mask].abs().sum()) == 0.0
+    dst = [torch.empty_like(t) for t in src]
+    be.scatter(lay, flat, dst, -2.0)
+    for d, t in zip(dst, src):
+        np.testing.assert_array_equal(d.cpu().numpy(), np.float32(-2.0) * (np.float32(0.37) * t.cpu().numpy()))
+    # axpy with a device coefficient
+    w = _rand_list(sizes, gen)
+    w0 = [t.clone() for t in w]
+    coef = torch.tensor([0.123], device=DEV)
+    be.axpy_multi(lay, w, src, coef[0], -2.0)
+    a = np.float32(-2.0) * np.float32(0.123)
+    for wi, w0i, si in zip(w, w0, src):
+        np.testing.assert_array_equal(wi.cpu().numpy(), w0i.cpu().numpy() + a * si.cpu().numpy())
+
+
+@pytest.mark.parametrize("sizes", RAGGED, ids=lambda s: f"T{len(s)}_N{sum(s)}")
+def test_neumann_kernels_bitwise_vs_oracle(sizes, be, orc):
+    gen = torch.Generator().manual_seed(7 + sum(sizes))
+    vec = _rand_list(sizes, gen)
+    lay = be.layout(vec)
+    v, p = lay.new_flat(), lay.new_flat()
+    be.neumann_init(lay, vec, v, p)
+    v_ref = np.concatenate([t.cpu().numpy() for t in vec])
+    p_ref = v_ref.copy()
+    for k in range(3):
+        hv = _rand_list(sizes, gen)
+        out_scale = -0.3 if k == 2 else 0.0
+        be.neumann_step(lay, hv, v, p, 0.3, out_scale)
+        h = np.concatenate([t.cpu().numpy() for t in hv])
+        orc.orc_neumann_step(_ptr(h), _ptr(v_ref), _ptr(p_ref), len(h), 0.3, out_scale)
+    np.testing.assert_array_equal(_flat_concat(lay, v), v_ref)  # element-wise, no reductions: exact
+    np.testing.assert_array_equal(_flat_concat(lay, p), p_ref)
+
+
+def _oracle_cg(orc, vec_np, hvps, cg_alpha):
+    n = len(vec_np)
+    x, r, p = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    orc.orc_cg_init(_ptr(vec_np), _ptr(x), _ptr(r), _ptr(p), n)
+    rr = orc.orc_sqnorm(_ptr(vec_np), n)
+    scal = []
+    K = len(hvps)
+    for k, h in enumerate(hvps):
+        den = orc.orc_dot_scaled(_ptr(h), _ptr(p), n, cg_alpha)
+        a = np.float32(np.float32(rr) / np.float32(den))
+        rr_new = orc.orc_cg_resid(_ptr(h), _ptr(r), n, float(a))
+        b = np.float32(np.float32(rr_new) / np.float32(rr))
+        orc.orc_cg_dir(_ptr(x), _ptr(r), _ptr(p), n, float(a), float(b), -cg_alpha if k == K - 1 else 0.0)
+        scal.append((rr, den, float(a), rr_new, float(b)))
+        rr = rr_new
+    return x, r, p, scal
+
+
+@pytest.mark.parametrize("variant", ["stream", "resident"])
+@pytest.mark.parametrize("sizes", RAGGED, ids=lambda s: f"T{len(s)}_N{sum(s)}")
+def test_cg_kernels_vs_oracle(sizes, variant, be, orc):
+    gen = torch.Generator().manual_seed(11 + sum(sizes))
+    vec = _rand_list(sizes, gen)
+    lay = be.layout(vec)
+    x, r, p = lay.new_flat(), lay.new_flat(), lay.new_flat()
+    be.cg_init(lay, vec, x, r, p)
+    K = 4
+    hv_lists = []
+    for k in range(K):
+        # H p with a fixed SPD diagonal so the recurrence stays well scaled
+        pv = lay.views(p, vec)
+        hv = [(1.0 + 0.5 * torch.sin(torch.arange(t.numel(), device=DEV, dtype=torch.float32))) * t for t in pv]
+        hv_lists.append(np.concatenate([t.cpu().numpy() for t in hv]))
+        be.cg_step(lay, hv, x, r, p, 0.7, k, out_scale=(-0.7 if k == K - 1 else 0.0), variant=VARIANTS[variant])
+        got_scal = be.cg_scalars(lay).cpu().numpy()
+        assert np.all(np.isfinite(got_scal))
+    # the oracle consumes the very HVP vectors the GPU run produced, so the two recurrences can
+    # only drift through the dot products' summation order (fp64 on both sides)
+    xo, ro, po, scal = _oracle_cg(orc, np.concatenate([t.cpu().numpy() for t in vec]), hv_lists, 0.7)
+    np.testing.assert_allclose(got_scal, np.array(scal[-1]), rtol=1e-6)
+    for got, want in ((x, xo), (r, ro), (p, po)):
+        g = _flat_concat(lay, got)
+        scale = np.abs(want).max() + 1e-30
+        # 4 iterations of fp32 recurrences whose alpha/beta may differ in the last ulp
+        assert np.abs(g - want).max() <= 4e-6 * scale
+
+
+def test_darts_eps_matches_oracle(be, orc):
+    gen = torch.Generator().manual_seed(3)
+    vec = _rand_list([1000, 33, 5000], gen, scale=0.01)
+    lay = be.layout(vec)
+    e32, e64 = be.darts_eps(lay, vec, 0.01)
+    flat = np.concatenate([t.cpu().numpy() for t in vec])
+    want = orc.orc_darts_eps(orc.orc_sqnorm(_ptr(flat), len(flat)), 0.01)
+    assert abs(float(e64) - want) <= 1e-12 * want
+    assert float(e32) == np.float32(float(e64))
+    # against torch's own norm, as darts.py:30-35 computes it
+    ref = 0.01 / (float(torch.cat([t.reshape(-1) for t in vec]).norm()) + 1e-15)
+    assert abs(float(e64) - ref) <= 1e-6 * ref
+    # all-zero vector: eps = R / 1e-15, finite
+    z = [torch.zeros(10, device=DEV)]
+    e32, e64 = be.darts_eps(be.layout(z), z, 0.01)
+    assert np.isfinite(float(e64)) and float(e64) > 1e12
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE size (N = 10,034,826 in the 8 tensors of the cfg-2 MLP): closed forms
+# ------------------------------------------------------------------------------------------------
+CFG2_SIZES = [3072 * 2048, 2048, 2048 * 1536, 1536, 1536 * 384, 384, 384 * 10, 10]
+
+
+@pytest.mark.parametrize("variant", ["stream", "resident"])
+def test_cg_full_size_diagonal_hessian_converges_exactly(variant, be):
+    """H = diag(d) with 4 distinct eigenvalues: CG solves H x = v exactly in 4 iterations
+    (Krylov argument), independent of N.  Checks x = -cg_alpha * v / d at N = 10 M."""
+    assert sum(CFG2_SIZES) == 10_034_826
+    gen = torch.Generator().manual_seed(5)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in CFG2_SIZES]
+    dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
+    diag = [dvals[torch.arange(n, device=DEV) % 4] for n in CFG2_SIZES]
+    lay = be.layout(vec)
+    if variant == "resident" and lay.n_chunks > be.lib.bhg_cg_resident_capacity_chunks():
+        pytest.skip("vector does not fit the resident kernel on this device")
+    x, r, p = lay.state(3)
+    be.cg_init(lay, vec, x, r, p)
+    K = 4
+    for k in range(K):
+        hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
+        be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == K - 1 else 0.0), variant=VARIANTS[variant])
+    for xv, v, d in zip(lay.views(x, vec), vec, diag):
+        want = -(v / d)
+        err = (xv - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), err  # fp32 CG, 4 steps, kappa = 8
+    ws_timeout = lay.workspace[24704 + 4 : 24704 + 8].view(torch.int32)  # barrier_words[1]
+    assert int(ws_timeout.item()) == 0, "grid barrier timed out"
+
+
+def test_neumann_full_size_closed_form(be):
+    """H = diag(d): p_K = sum_{j<=K} (1 - alpha d)^j v, result = -alpha p_K (fp32 geometric sum)."""
+    gen = torch.Generator().manual_seed(6)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in CFG2_SIZES]
+    diag = [0.5 + (torch.arange(n, device=DEV) % 7).float() * 0.25 for n in CFG2_SIZES]
+    lay = be.layout(vec)
+    v, p = lay.state(2)
+    be.neumann_init(lay, vec, v, p)
+    K, alpha = 10, 0.1
+    for k in range(K):
+        hv = [d * t for d, t in zip(diag, lay.views(v, vec))]
+        be.neumann_step(lay, hv, v, p, alpha, out_scale=(-alpha if k == K - 1 else 0.0))
+    for pv, vv, d in zip(lay.views(p, vec), vec, diag):
+        q = (1.0 - alpha * d.double())
+        geo = sum(q**j for j in range(K + 1))
+        want = (-alpha * geo * vv.double()).float()
+        assert (pv - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+def test_product_refuses_cpu_tensors(be):
+    t = [torch.randn(10)]
+    lay = be.layout([torch.randn(10, device=DEV)])
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        be.neumann_init(lay, t, lay.new_flat(), lay.new_flat())
