@@ -9,6 +9,10 @@
 // Arithmetic follows the reference's rounding sequence (a*b rounded, then +/-; never
 // contracted into an fma) so that the only differences to the CPU autograd reference are
 // the reduction order of the dot products (we accumulate in fp64) and the HVP itself.
+#include <hip/hip_ext.h>
+
+#include <vector>
+
 #include "bhg_common.hpp"
 
 namespace bhg {
@@ -321,22 +325,27 @@ __device__ __forceinline__ double block_sum_res(double v, double* red) {
 using gu32 = __attribute__((address_space(1))) unsigned;
 using gf64 = __attribute__((address_space(1))) double;
 
-// Grid barrier + all-reduce of one double per workgroup.  Partials are exchanged with
-// 8-byte agent-scope atomics on both sides (write-through store, L1-bypassing load), the
-// arrival counter is monotonic (zeroed by k_cg_init, so targets depend only on `iter`).
-// Returns the fixed-order sum over all workgroups, identical in every workgroup.
-__device__ __forceinline__ double grid_allreduce(double block_value, double* part, unsigned* counter,
-                                                 unsigned target, double* red, unsigned* timeout_word) {
-  // block_value is valid in every thread (block_sum_res); thread 0 publishes it.
+// Split grid barrier + all-reduce of one double per workgroup: `grid_arrive` publishes this
+// workgroup's partial and bumps the arrival counter, `grid_wait_sum` (later, after independent
+// work has been issued) waits for all arrivals and returns the fixed-order sum, identical in
+// every workgroup.  Partials travel as 8-byte agent-scope atomics on both sides (write-through
+// store, L1-bypassing load: MI355X_MICROARCH.md "8-B agent atomics both sides"); the counter is
+// monotonic and zeroed by k_cg_init, so targets depend only on `iter`.
+__device__ __forceinline__ void grid_arrive(double block_value, double* part, unsigned* counter) {
   if (threadIdx.x == 0) {
     __hip_atomic_store((gf64*)(part + blockIdx.x), block_value, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add((gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ double grid_wait_sum(const double* part, unsigned* counter, unsigned target,
+                                                double* red, unsigned* timeout_word) {
+  if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 24)) {  // bounded spin: flag and fall through instead of hanging the GPU
+      if (++spins > (1u << 22)) {  // bounded spin: flag and fall through instead of hanging the GPU
         __hip_atomic_store((gu32*)timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -349,6 +358,50 @@ __device__ __forceinline__ double grid_allreduce(double block_value, double* par
   return block_sum_res(a, red);
 }
 
+// Streams one flat vector through the resident chunks with a kDepth-deep software prefetch:
+// f(i, j, loaded_float4) -> float4 to store back.  The compiler cannot hoist the loads of chunk
+// i+1 above the stores of chunk i to the same array itself, so the pipeline is explicit.
+constexpr int kResDepth = 3;
+template <typename F>
+__device__ __forceinline__ void resident_stream(float* __restrict__ vec, const bhg_chunk* __restrict__ chunks,
+                                                int n_chunks, F f) {
+  const int G = gridDim.x;
+  float4 buf[kResDepth][kResV];
+#pragma unroll
+  for (int d = 0; d < kResDepth; ++d) {
+    const int c = blockIdx.x + d * G;
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) buf[d][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d < kResMax && c < n_chunks) {
+      const bhg_chunk ck = chunks[c];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) buf[d][j] = ld4(vec + ck.flat_off, 4 * (threadIdx.x + kResThreads * j), ck.len);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kResMax; ++i) {
+    const int c = blockIdx.x + i * G;
+    float4 cur[kResV];
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) cur[j] = buf[i % kResDepth][j];
+    const int cn = c + kResDepth * G;
+    if (i + kResDepth < kResMax && cn < n_chunks) {
+      const bhg_chunk ckn = chunks[cn];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j)
+        buf[i % kResDepth][j] = ld4(vec + ckn.flat_off, 4 * (threadIdx.x + kResThreads * j), ckn.len);
+    }
+    if (c < n_chunks) {
+      const bhg_chunk ck = chunks[c];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        st4(vec + ck.flat_off, e, ck.len, f(i, j, cur[j]));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
     float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale,
@@ -357,17 +410,8 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
   __shared__ double red[kResWaves];
   const int G = gridDim.x;
 
-  // numerator r.r from the previous producer (k_cg_init or the previous iteration).
-  double rr;
-  {
-    const int n_part_old = (int)scal[S_NPART0 + (iter & 1)];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n_part_old; i += kResThreads) a += partR_old[i];
-    rr = block_sum_res(a, red);
-  }
-
   float4 h[kResMax][kResV], q[kResMax][kResV];
-  // ---- phase 1: load Hp, p once; den = (cg_alpha*Hp).p
+  // ---- phase 1: load Hp, p once (all loads in flight together); den = (cg_alpha*Hp).p
 #pragma unroll
   for (int i = 0; i < kResMax; ++i) {
     const int c = blockIdx.x + i * G;
@@ -387,6 +431,15 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
       }
     }
   }
+  // numerator r.r from the previous producer (k_cg_init or the previous iteration); these
+  // loads overlap the big ones above.
+  double rr;
+  {
+    const int n_part_old = (int)scal[S_NPART0 + (iter & 1)];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n_part_old; i += kResThreads) a += partR_old[i];
+    rr = block_sum_res(a, red);
+  }
   double acc = 0.0;
 #pragma unroll
   for (int i = 0; i < kResMax; ++i) {
@@ -396,72 +449,38 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
              (double)mul_rn(cg_alpha, h[i][j].z) * q[i][j].z + (double)mul_rn(cg_alpha, h[i][j].w) * q[i][j].w;
     }
   }
-  const double blk_den = block_sum_res(acc, red);
-  const double den = grid_allreduce(blk_den, partP, barrier_words, (unsigned)G * (2u * iter + 1u), red,
-                                    barrier_words + 1);
+  grid_arrive(block_sum_res(acc, red), partP, barrier_words);
+  const double den = grid_wait_sum(partP, barrier_words, (unsigned)G * (2u * iter + 1u), red, barrier_words + 1);
   const float alpha = (float)rr / (float)den;
 
-  // ---- phase 2: x += a*p ; r' = r - a*Hp (kept in h) ; partial r'.r'
-  // Software-pipelined: the x/r loads of chunk i+1 are issued before chunk i is stored (the
-  // compiler cannot hoist them across the stores to the same arrays itself).
+  // ---- phase 2a: r' = r - a*Hp (kept in h, stored once) ; partial r'.r' ; ARRIVE
   acc = 0.0;
-  float4 xv[kResV], rv[kResV], xn[kResV], rn[kResV];
-#pragma unroll
-  for (int j = 0; j < kResV; ++j) xv[j] = rv[j] = xn[j] = rn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((int)blockIdx.x < n_chunks) {
-    const bhg_chunk ck = chunks[blockIdx.x];
-#pragma unroll
-    for (int j = 0; j < kResV; ++j) {
-      const int e = 4 * (threadIdx.x + kResThreads * j);
-      xv[j] = ld4(x + ck.flat_off, e, ck.len);
-      rv[j] = ld4(r + ck.flat_off, e, ck.len);
+  resident_stream(r, chunks, n_chunks, [&](int i, int j, float4 rv) {
+    float4 nr;
+    nr.x = sub_rn(rv.x, mul_rn(alpha, h[i][j].x)); nr.y = sub_rn(rv.y, mul_rn(alpha, h[i][j].y));
+    nr.z = sub_rn(rv.z, mul_rn(alpha, h[i][j].z)); nr.w = sub_rn(rv.w, mul_rn(alpha, h[i][j].w));
+    h[i][j] = nr;
+    acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
+    return nr;
+  });
+  grid_arrive(block_sum_res(acc, red), partR_new, barrier_words);
+
+  // ---- phase 2b (hides the second barrier): x += a*p [x <- out_scale*x on the last step]
+  resident_stream(x, chunks, n_chunks, [&](int i, int j, float4 xv) {
+    float4 nx;
+    nx.x = add_rn(xv.x, mul_rn(alpha, q[i][j].x)); nx.y = add_rn(xv.y, mul_rn(alpha, q[i][j].y));
+    nx.z = add_rn(xv.z, mul_rn(alpha, q[i][j].z)); nx.w = add_rn(xv.w, mul_rn(alpha, q[i][j].w));
+    if (out_scale != 0.f) {
+      nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
+      nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
     }
-  }
-#pragma unroll
-  for (int i = 0; i < kResMax; ++i) {
-    const int c = blockIdx.x + i * G;
-    const int cn = c + G;
-    if (i + 1 < kResMax && cn < n_chunks) {
-      const bhg_chunk ckn = chunks[cn];
-#pragma unroll
-      for (int j = 0; j < kResV; ++j) {
-        const int e = 4 * (threadIdx.x + kResThreads * j);
-        xn[j] = ld4(x + ckn.flat_off, e, ckn.len);
-        rn[j] = ld4(r + ckn.flat_off, e, ckn.len);
-      }
-    }
-    if (c < n_chunks) {
-      const bhg_chunk ck = chunks[c];
-#pragma unroll
-      for (int j = 0; j < kResV; ++j) {
-        const int e = 4 * (threadIdx.x + kResThreads * j);
-        float4 nx, nr;
-        nx.x = add_rn(xv[j].x, mul_rn(alpha, q[i][j].x)); nx.y = add_rn(xv[j].y, mul_rn(alpha, q[i][j].y));
-        nx.z = add_rn(xv[j].z, mul_rn(alpha, q[i][j].z)); nx.w = add_rn(xv[j].w, mul_rn(alpha, q[i][j].w));
-        if (out_scale != 0.f) {
-          nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
-          nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
-        }
-        nr.x = sub_rn(rv[j].x, mul_rn(alpha, h[i][j].x)); nr.y = sub_rn(rv[j].y, mul_rn(alpha, h[i][j].y));
-        nr.z = sub_rn(rv[j].z, mul_rn(alpha, h[i][j].z)); nr.w = sub_rn(rv[j].w, mul_rn(alpha, h[i][j].w));
-        st4(x + ck.flat_off, e, ck.len, nx);
-        st4(r + ck.flat_off, e, ck.len, nr);
-        h[i][j] = nr;
-        acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kResV; ++j) {
-      xv[j] = xn[j];
-      rv[j] = rn[j];
-    }
-  }
-  const double blk_rr = block_sum_res(acc, red);
-  const double rr_new = grid_allreduce(blk_rr, partR_new, barrier_words, (unsigned)G * (2u * iter + 2u),
-                                       red, barrier_words + 1);
+    return nx;
+  });
+  const double rr_new = grid_wait_sum(partR_new, barrier_words, (unsigned)G * (2u * iter + 2u), red,
+                                      barrier_words + 1);
   const float beta = (float)rr_new / (float)rr;
 
-  // ---- phase 3: p = r' + b*p
+  // ---- phase 3: p = r' + b*p (registers only -> store)
 #pragma unroll
   for (int i = 0; i < kResMax; ++i) {
     const int c = blockIdx.x + i * G;
@@ -548,6 +567,31 @@ __global__ __launch_bounds__(kThreads) void k_axpy_multi(PtrTab dst, PtrTab src,
       st4(d, e, ck.len, o);
     }
   }
+}
+
+// ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
+// When enabled, the recurrence launches carry start/stop events attached to the kernels themselves
+// (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end on the launch stream, the same interval
+// rocprofv3 --kernel-trace reports.  Off by default: no events, no overhead.
+struct TimedSpan { hipEvent_t a, b; int kind; };
+bool g_timing = false;
+std::vector<TimedSpan> g_spans;
+std::vector<hipEvent_t> g_free_events;
+constexpr size_t kMaxSpans = 8192;
+hipEvent_t take_event() {
+  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+// Returns true (and fills a/b) when this launch group should be timed.
+bool span_begin(int kind, hipEvent_t* a, hipEvent_t* b) {
+  *a = *b = nullptr;
+  if (!g_timing || g_spans.size() >= kMaxSpans) return false;
+  *a = take_event(); *b = take_event();
+  if (!*a || !*b) return false;
+  g_spans.push_back({*a, *b, kind});
+  return true;
 }
 
 inline int grid_for(int n_chunks) { return n_chunks < kMaxBlocks ? (n_chunks > 0 ? n_chunks : 1) : kMaxBlocks; }
@@ -667,8 +711,10 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
   hipStream_t st = static_cast<hipStream_t>(stream);
   PtrTab tab;
   if (int rc = make_table(&tab, hvp, T, ws, 0, st)) return rc;
-  hipLaunchKernelGGL(k_neumann_step, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev,
-                     n_chunks, v, p, alpha, out_scale);
+  hipEvent_t ea, eb;
+  const bool timed = span_begin(BHG_TIMING_NEUMANN_STEP, &ea, &eb);
+  hipExtLaunchKernelGGL(k_neumann_step, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, timed ? ea : nullptr,
+                        timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, v, p, alpha, out_scale);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
@@ -723,18 +769,24 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   // How many partials the previous producer wrote travels in scal[S_NPART0 + parity], so the
   // stream and resident variants may be mixed freely between iterations.
   const int n_stream = grid_for(n_chunks);
+  hipEvent_t ea, eb;
+  const bool timed = span_begin(BHG_TIMING_CG_STEP, &ea, &eb);
   if (variant == BHG_CG_STREAM) {
-    hipLaunchKernelGGL(k_cg_dot, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks,
-                       (const float*)p, cg_alpha, partP);
+    // start event rides on the first kernel, stop event on the last: the span is the whole
+    // iteration's recurrence including the two inter-kernel boundaries.
+    hipExtLaunchKernelGGL(k_cg_dot, dim3(n_stream), dim3(kThreads), 0, st, timed ? ea : nullptr, nullptr, 0, tab,
+                          chunks_dev, n_chunks, (const float*)p, cg_alpha, partP);
     hipLaunchKernelGGL(k_cg_resid, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, r,
                        (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
-    hipLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, chunks_dev, n_chunks, x,
-                       (const float*)r, p, (const double*)partR_new, n_stream, out_scale, scal);
+    hipExtLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, nullptr, timed ? eb : nullptr, 0,
+                          chunks_dev, n_chunks, x, (const float*)r, p, (const double*)partR_new, n_stream,
+                          out_scale, scal);
   } else {
     const int G = num_cus();
-    hipLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, tab, chunks_dev, n_chunks, x, r, p,
-                       cg_alpha, iter, out_scale, (const double*)partR_old, partR_new, partP,
-                       reinterpret_cast<unsigned*>(w + kWsBarrier), scal);
+    hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
+                          timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
+                          (const double*)partR_old, partR_new, partP,
+                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal);
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
@@ -772,6 +824,31 @@ int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_ch
   hipLaunchKernelGGL(k_axpy_multi, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, td, ts, chunks_dev,
                      n_chunks, coef_dev, mul);
   BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_timing_enable(int on) {
+  // (re)start or stop collecting; starting drops any spans not yet read
+  for (auto& sp : g_spans) { g_free_events.push_back(sp.a); g_free_events.push_back(sp.b); }
+  g_spans.clear();
+  g_timing = on != 0;
+  return BHG_OK;
+}
+
+int bhg_timing_read(int kind, double* total_ms, int* launches) {
+  BHG_REQUIRE(total_ms && launches, "NULL output");
+  double tot = 0.0;
+  int n = 0;
+  for (auto& sp : g_spans) {
+    if (sp.kind != kind) continue;
+    BHG_HIP_CHECK(hipEventSynchronize(sp.b));
+    float ms = 0.f;
+    BHG_HIP_CHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+    tot += (double)ms;
+    ++n;
+  }
+  *total_ms = tot;
+  *launches = n;
   return BHG_OK;
 }
 

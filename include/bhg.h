@@ -130,6 +130,16 @@ int bhg_darts_eps(const void* const* vec, int T, const bhg_chunk* chunks_dev, in
 int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_chunk* chunks_dev,
                    int n_chunks, const float* coef_dev, float mul, void* ws, void* stream);
 
+/* ---- optional kernel timing (measurement only) ----------------------------------
+ * When enabled, every bhg_cg_step / bhg_neumann_step launch group carries start/stop
+ * HIP events attached to its first/last kernel on the launch stream (kernel begin ->
+ * kernel end, the interval rocprofv3 --kernel-trace reports).  bhg_timing_read waits for
+ * the recorded spans of `kind` and returns their summed duration and count.           */
+#define BHG_TIMING_CG_STEP 0
+#define BHG_TIMING_NEUMANN_STEP 1
+int bhg_timing_enable(int on);
+int bhg_timing_read(int kind, double* total_ms, int* launches);
+
 /* ---- analytic Hessian-vector products (structured inner problems) --------------
  * Logistic regression with per-weight L2 (the inner problem of
  * examples/logistic_regression_hpo/logistic_regression_implicit.py:80-91):
