@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: world size 2, gloo.  The path shards by replica: each rank
+solves on its own batch with no collective inside the loop; the `sync=True` hop ends in
+`torch.autograd.backward`, so DistributedDataParallel's reducer all-reduces (mean) the upper-level
+hypergradient.  Checked: after the synced call `prev.grad` equals the mean over ranks of the
+un-synced local results, and the call returns None — for cg, neumann and darts.
+
+Kernels are replaced by the C oracle through the test-only checker backend (no GPU here); the
+GPU suite covers the kernels themselves."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case_name, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zoo
+        from _cpu_checker_backend import CpuCheckerBackend
+        from conftest import load_golden
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        from betty_amd import Config
+        from betty_amd import hypergradient as hg
+        from betty_amd.backend import use_backend
+
+        case = zoo.CASE_BY_NAME[case_name]
+        inputs, _ = load_golden(case.family)
+        inputs = dict(inputs)
+        # different data per rank: each rank keeps its half of the batch
+        half = inputs["batch_x"].shape[0] // world
+        inputs["batch_x"] = inputs["batch_x"][rank * half : (rank + 1) * half]
+        inputs["batch_y"] = inputs["batch_y"][rank * half : (rank + 1) * half]
+
+        with use_backend(CpuCheckerBackend()):
+            # local, un-synced result
+            curr, prev, vector = zoo.build_case(case, inputs, Config)
+            local = hg.jvp_fn_mapping[case.algo](vector, curr, prev, False)
+            local = torch.cat([t.reshape(-1) for t in local]).detach()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            want = torch.stack(gathered).mean(0)
+
+            # synced call through DDP (the wrapper the reference uses, problem.py:220-224)
+            curr, prev, vector = zoo.build_case(case, inputs, Config)
+            prev.fwd = DDP(prev.module, gradient_as_bucket_view=True, find_unused_parameters=True)
+            ret = hg.jvp_fn_mapping[case.algo](vector, curr, prev, True)
+            got = torch.cat([p.grad.reshape(-1) for p in prev.trainable_parameters()]).detach()
+        err = float((got - want).abs().max() / want.abs().max())
+        differs = float((local - want).abs().max() / want.abs().max())
+        q.put((rank, ret is None, err, differs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name", ["reweight_cg20", "reweight_neumann10", "reweight_darts"])
+def test_sync_hop_averages_over_ranks(case_name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    results = sorted(q.get(timeout=5) for _ in range(world))
+    for rank, returned_none, err, differs in results:
+        assert returned_none
+        # DDP's mean of per-rank results; 1e-6 = fp32 all-reduce rounding (darts: finite differences)
+        assert err < (2e-4 if "darts" in case_name else 2e-6), (rank, err)
+        assert differs > 1e-3, "ranks must see different data for the test to mean anything"

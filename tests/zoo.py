@@ -34,6 +34,7 @@ class StubProblem:
         self.cur_batch = batch
         self.paths = []
         self._strategy = "default"
+        self.fwd = module  # what `training_step` calls; a DDP wrapper in the distributed tests
 
     def training_step_exec(self, batch):
         return self._loss_fn(self, batch)
@@ -117,7 +118,7 @@ def make_logreg_loss(upper):
     def loss(self, batch):
         x, y = batch
         w = self.module.w
-        lam = upper.module()
+        lam = upper.fwd()
         return F.binary_cross_entropy_with_logits(x @ w, y) + 0.5 * (lam * w * w).sum()
 
     return loss
@@ -129,7 +130,7 @@ def make_reweight_loss(upper, ridge):
         x, y = batch
         logits = self.module(x)
         ce = F.cross_entropy(logits, y, reduction="none")
-        weight = upper.module(ce.detach().reshape(-1, 1))
+        weight = upper.fwd(ce.detach().reshape(-1, 1))
         out = torch.mean(weight.reshape(-1) * ce)
         if ridge:
             out = out + ridge * sum((p * p).sum() for p in self.module.parameters())
