@@ -34,6 +34,31 @@ class Chunk(ctypes.Structure):
     ]
 
 
+BHG_MLP_MAX_LAYERS = 32
+
+
+class Mlp(ctypes.Structure):
+    """Mirror of ``bhg_mlp`` (include/bhg.h)."""
+
+    _fields_ = [
+        ("L", c_int32),
+        ("B", c_int32),
+        ("Bp", c_int32),
+        ("dims", c_int32 * (BHG_MLP_MAX_LAYERS + 1)),
+        ("W", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("h", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("mask", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("delta", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("prob", c_void_p),
+        ("sd", c_void_p),
+        ("Rh", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("Rd", c_void_p * BHG_MLP_MAX_LAYERS),
+        ("partial", c_void_p),
+        ("partial_floats", c_size_t),
+        ("ridge2", c_float),
+    ]
+
+
 _PP = POINTER(c_void_p)  # const void* const*
 _CH = c_void_p  # const bhg_chunk* (device)
 
@@ -70,6 +95,8 @@ SYMBOLS = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    "bhg_mlp_partial_floats": (c_size_t, [POINTER(Mlp)]),
+    "bhg_mlp_hvp": (c_int, [POINTER(Mlp), _PP, _PP, c_void_p]),
 }
 
 _lib = None

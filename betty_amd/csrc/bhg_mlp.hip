@@ -1,0 +1,659 @@
+// bhg_mlp.hip — analytic Hessian-vector product of a ReLU-MLP with per-sample-weighted
+// cross-entropy (+ ridge) on the gfx950 matrix cores.
+//
+// Replaces the double backward `torch.autograd.grad(in_grad, params, grad_outputs=p)` of
+// betty/hypergradient/cg.py:39-41 / neumann.py:62 for the inner problem of
+// examples/learning_to_reweight/main.py:117-127.  Everything that does
+// not depend on the direction (activations h_l, ReLU masks m_l, softmax p, back-propagated
+// delta_l) is computed once per hypergradient step by the caller and cached; one HVP is then
+//   R-forward   Ra_l = Rh_{l-1} W_l^T + h_{l-1} V_l^T + c_l ,  Rh_l = m_l * Ra_l       (NT GEMMs)
+//   top         Rd_L = sd * (p*Rz - p (p.Rz))
+//   R-backward  Rd_{l-1} = m_{l-1} * (delta_l V_l + Rd_l W_l)                           (NN GEMMs)
+//   outputs     H(W_l) = Rd_l^T h_{l-1} + delta_l^T Rh_{l-1} + 2 rho V_l                (TN GEMMs)
+//               H(b_l) = colsum(Rd_l) + 2 rho c_l
+// All GEMMs have one skinny dimension (the batch, padded to 128 rows) and stream a large weight
+// or produce a large weight-shaped output, so they are tiled 128 x 64 per workgroup (4 waves of
+// 64 x 32 on v_mfma_f32_32x32x2_f32, exact fp32), staged through LDS with coalesced 16-B global
+// loads, split along K across workgroups to fill the 256 CUs (deterministic: partial slabs are
+// summed in fixed order by the epilogue, no atomics).
+#include "bhg_common.hpp"
+
+namespace bhg {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTM = 128;  // workgroup tile rows
+constexpr int kTN = 64;   // workgroup tile cols
+constexpr int kTK = 32;   // K step
+constexpr int kPadK = kTK + 1;  // LDS row stride of K-contiguous tiles (conflict-free fragment reads)
+
+// Operand layouts in global memory.
+enum : int { LAYOUT_KC = 0 /* [rows][K], K contiguous */, LAYOUT_RC = 1 /* [K][rows], rows contiguous */ };
+
+struct GemmPair {
+  const float* A;  // "M side" operand
+  const float* B;  // "N side" operand
+  int lda, ldb;    // leading dimensions (elements)
+};
+struct GemmArgs {
+  GemmPair pr[2];
+  int pairs;
+  int M, N, K;     // logical sizes (K per pair)
+  int splits;      // split-K factor (gridDim.z); each split handles a contiguous K range of every pair
+  float* out;      // splits == 1 && !partial: C [M][ldo]; else partial slabs [split][Mpad][ldo]
+  int ldo;
+  int out_rows;    // rows per partial slab
+  const float* addend;  // optional: out = acc + addend_scale * addend[m][n] (same ld as out)
+  float addend_scale;
+};
+
+// LDS tile loaders -----------------------------------------------------------------------------------
+// Every loader has two forms selected by a WORKGROUP-UNIFORM flag: `fast` (tile fully inside the
+// operand, leading dimension a multiple of 4 -> unconditional 16-B loads, no control flow, so all
+// loads of a step are in flight together) and a branch-free edge form (clamped addresses + selects,
+// scalar loads) for ragged tiles and odd leading dimensions.
+__device__ __forceinline__ float ld_guard(const float* __restrict__ g, int64_t idx, bool ok) {
+  const float v = g[ok ? idx : 0];
+  return ok ? v : 0.f;
+}
+// K-contiguous operand ([rows][K]): tile ROWS x 32, stored [row][kPadK].
+template <int ROWS>
+__device__ __forceinline__ void load_kc(const float* __restrict__ g, int ld, int row0, int nrows, int k0, int kend,
+                                        bool fast, float4 (&regs)[ROWS / 32]) {
+  const int t = threadIdx.x;
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i)
+      regs[i] = *reinterpret_cast<const float4*>(g + (int64_t)(row0 + (t >> 3) + 32 * i) * ld + k0 + 4 * (t & 7));
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int r = row0 + (t >> 3) + 32 * i;
+      const int k = k0 + 4 * (t & 7);
+      const int64_t base = (int64_t)r * ld + k;
+      const bool rok = r < nrows;
+      regs[i].x = ld_guard(g, base, rok && k < kend);
+      regs[i].y = ld_guard(g, base + 1, rok && k + 1 < kend);
+      regs[i].z = ld_guard(g, base + 2, rok && k + 2 < kend);
+      regs[i].w = ld_guard(g, base + 3, rok && k + 3 < kend);
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_kc(float* __restrict__ lds, const float4 (&regs)[ROWS / 32]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    float* d = lds + ((t >> 3) + 32 * i) * kPadK + 4 * (t & 7);
+    d[0] = regs[i].x; d[1] = regs[i].y; d[2] = regs[i].z; d[3] = regs[i].w;
+  }
+}
+// rows-contiguous operand ([K][rows]): tile 32 x ROWS, stored [k][ROWS].
+template <int ROWS>
+__device__ __forceinline__ void load_rc(const float* __restrict__ g, int ld, int row0, int nrows, int k0, int kend,
+                                        bool fast, float4 (&regs)[ROWS / 32]) {
+  const int t = threadIdx.x;
+  constexpr int F4_PER_K = ROWS / 4;           // float4 per k-row of the tile
+  constexpr int K_PER_PASS = 256 / F4_PER_K;   // k-rows covered by the 256 threads per pass
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i)
+      regs[i] = *reinterpret_cast<const float4*>(g + (int64_t)(k0 + (t / F4_PER_K) + K_PER_PASS * i) * ld + row0 +
+                                                 4 * (t % F4_PER_K));
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int k = k0 + (t / F4_PER_K) + K_PER_PASS * i;
+      const int r = row0 + 4 * (t % F4_PER_K);
+      const int64_t base = (int64_t)k * ld + r;
+      const bool kok = k < kend;
+      regs[i].x = ld_guard(g, base, kok && r < nrows);
+      regs[i].y = ld_guard(g, base + 1, kok && r + 1 < nrows);
+      regs[i].z = ld_guard(g, base + 2, kok && r + 2 < nrows);
+      regs[i].w = ld_guard(g, base + 3, kok && r + 3 < nrows);
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_rc(float* __restrict__ lds, const float4 (&regs)[ROWS / 32]) {
+  const int t = threadIdx.x;
+  constexpr int F4_PER_K = ROWS / 4;
+  constexpr int K_PER_PASS = 256 / F4_PER_K;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    float* d = lds + ((t / F4_PER_K) + K_PER_PASS * i) * ROWS + 4 * (t % F4_PER_K);
+    *reinterpret_cast<float4*>(d) = regs[i];
+  }
+}
+
+template <int LA, int ROWS>
+__device__ __forceinline__ float frag(const float* __restrict__ lds, int row, int k) {
+  if (LA == LAYOUT_KC) return lds[row * kPadK + k];
+  return lds[k * ROWS + row];
+}
+
+// C[M][N] (+)= sum over pairs  A_pair (M x K) * B_pair (K x N), operands in layouts LA / LB.
+// grid = (ceil(N/64), ceil(M/128), splits), block = 256 (4 waves: 2 along M x 2 along N).
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
+  constexpr int B_ELEMS = (LB == LAYOUT_KC) ? kTN * kPadK : kTK * kTN;
+  __shared__ __attribute__((aligned(16))) float sA[2][A_ELEMS];
+  __shared__ __attribute__((aligned(16))) float sB[2][B_ELEMS];
+
+  const int n0 = blockIdx.x * kTN;
+  const int m0 = blockIdx.y * kTM;
+  const int split = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64;  // wave's row offset inside the tile
+  const int wn = (wave & 1) * 32;   // wave's col offset
+  const int li = lane & 31, lk = lane >> 5;
+
+  // K range of this split (multiples of kTK except possibly the end)
+  const int ksteps_total = (a.K + kTK - 1) / kTK;
+  const int per = (ksteps_total + a.splits - 1) / a.splits;
+  const int kbeg = split * per * kTK;
+  const int kend = min(a.K, (split + 1) * per * kTK);
+  const int nsteps_pair = kbeg < kend ? (kend - kbeg + kTK - 1) / kTK : 0;
+  const int nsteps = nsteps_pair * a.pairs;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  // Two register stages: the global loads of step s+2 are issued before the MFMAs of step s, so every
+  // load has two compute phases (plus the other resident workgroups) to land.
+  float4 ra0[kTM / 32], rb0[kTN / 32], ra1[kTM / 32], rb1[kTN / 32];
+  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[kTN / 32]) {
+    const int pi = step / nsteps_pair;
+    const int k0 = kbeg + (step - pi * nsteps_pair) * kTK;
+    const GemmPair& pr = a.pr[pi];
+    const bool kfull = k0 + kTK <= kend;  // workgroup-uniform
+    const bool fa = kfull && m0 + kTM <= a.M && (pr.lda & 3) == 0;
+    const bool fb = kfull && n0 + kTN <= a.N && (pr.ldb & 3) == 0;
+    if (LA == LAYOUT_KC) load_kc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
+    else load_rc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
+    if (LB == LAYOUT_KC) load_kc<kTN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
+    else load_rc<kTN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
+  };
+  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], const float4 (&rb)[kTN / 32]) {
+    if (LA == LAYOUT_KC) store_kc<kTM>(sA[buf], ra); else store_rc<kTM>(sA[buf], ra);
+    if (LB == LAYOUT_KC) store_kc<kTN>(sB[buf], rb); else store_rc<kTN>(sB[buf], rb);
+  };
+  auto compute = [&](int step) {
+    const float* A = sA[step & 1];
+    const float* B = sB[step & 1];
+    // valid k in this tile (the tail of a K range is zero-filled in LDS; skip its MFMAs)
+    const int klen = min(kTK, kend - (kbeg + (step % nsteps_pair) * kTK));
+    if (klen == kTK) {
+#pragma unroll
+      for (int kp = 0; kp < kTK / 2; ++kp) {
+        const int k = 2 * kp + lk;
+        const float b = frag<LB, kTN>(B, wn + li, k);
+        const float a0 = frag<LA, kTM>(A, wm + li, k);
+        const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+      }
+    } else {
+      for (int kp = 0; kp < (klen + 1) / 2; ++kp) {
+        const int k = 2 * kp + lk;
+        const float b = frag<LB, kTN>(B, wn + li, k);
+        const float a0 = frag<LA, kTM>(A, wm + li, k);
+        const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+      }
+    }
+  };
+  // body for one step whose NEXT step's data sits in (ran, rbn) and whose step+2 loads go to (raf, rbf)
+  auto body = [&](int step, float4 (&raf)[kTM / 32], float4 (&rbf)[kTN / 32], const float4 (&ran)[kTM / 32],
+                  const float4 (&rbn)[kTN / 32]) {
+    if (step + 2 < nsteps) gload(step + 2, raf, rbf);
+    compute(step);
+    if (step + 1 < nsteps) lstore((step + 1) & 1, ran, rbn);
+    __syncthreads();
+  };
+
+  if (nsteps > 0) {
+    gload(0, ra0, rb0);
+    if (nsteps > 1) gload(1, ra1, rb1);
+    lstore(0, ra0, rb0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; step += 2) {
+    body(step, ra0, rb0, ra1, rb1);      // step even: next (odd) data in stage 1, step+2 loads into stage 0
+    if (step + 1 < nsteps) body(step + 1, ra1, rb1, ra0, rb0);
+  }
+
+  // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)split * a.out_rows * a.ldo : 0);
+  const int col = n0 + wn + li;
+  if (col < a.N) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int row = m0 + wm + 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+        if (row < a.M) {
+          float v = acc[t][rg];
+          if (a.addend) v += a.addend_scale * a.addend[(int64_t)row * a.ldo + col];
+          out[(int64_t)row * a.ldo + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- weight-shaped outputs: C[M][N] = sum_pairs A_pair^T B_pair (+ addend), K = batch (<= 128) -----------
+// The whole K extent of a pair is ONE LDS tile ([K][128] + [K][64], <= 96 KiB): a single round of
+// global loads per pair (all in flight together) instead of a 4-step latency chain; the second
+// pair's loads are issued before the first pair's MFMAs and parked in registers.  The accumulators
+// are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
+constexpr int kOK = 128;                      // max K of the outer-product kernel
+constexpr int kOA = kOK * kTM / (256 * 4);    // float4 per thread for a full [128][128] A tile = 16
+constexpr int kOB = kOK * kTN / (256 * 4);    // = 8
+constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging tile (16-B aligned rows)
+
+__global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = a.K;                      // <= kOK
+  const int Kp = (K + 1) & ~1;
+  float* sA = smem;                       // [Kp][128]
+  float* sB = smem + Kp * kTM;            // [Kp][64]
+  const int n0 = blockIdx.x * kTN;
+  const int m0 = blockIdx.y * kTM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+  const int li = lane & 31, lk = lane >> 5;
+  const int t = threadIdx.x;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  float4 ra[kOA], rb[kOB];
+  auto gload = [&](const GemmPair& pr) {
+    const bool fa = m0 + kTM <= a.M && (pr.lda & 3) == 0;  // workgroup-uniform
+    const bool fb = n0 + kTN <= a.N && (pr.ldb & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < kOA; ++i) {   // A tile: 32 float4 per k-row, 8 k-rows per pass
+      const int k = (t >> 5) + 8 * i;
+      const int r = m0 + 4 * (t & 31);
+      const bool kok = k < K;
+      const int64_t base = (int64_t)(kok ? k : 0) * pr.lda + r;
+      if (fa) {
+        const float4 v = *reinterpret_cast<const float4*>(pr.A + base);
+        ra[i] = kok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        ra[i].x = ld_guard(pr.A, base, kok && r < a.M);
+        ra[i].y = ld_guard(pr.A, base + 1, kok && r + 1 < a.M);
+        ra[i].z = ld_guard(pr.A, base + 2, kok && r + 2 < a.M);
+        ra[i].w = ld_guard(pr.A, base + 3, kok && r + 3 < a.M);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kOB; ++i) {   // B tile: 16 float4 per k-row, 16 k-rows per pass
+      const int k = (t >> 4) + 16 * i;
+      const int r = n0 + 4 * (t & 15);
+      const bool kok = k < K;
+      const int64_t base = (int64_t)(kok ? k : 0) * pr.ldb + r;
+      if (fb) {
+        const float4 v = *reinterpret_cast<const float4*>(pr.B + base);
+        rb[i] = kok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        rb[i].x = ld_guard(pr.B, base, kok && r < a.N);
+        rb[i].y = ld_guard(pr.B, base + 1, kok && r + 1 < a.N);
+        rb[i].z = ld_guard(pr.B, base + 2, kok && r + 2 < a.N);
+        rb[i].w = ld_guard(pr.B, base + 3, kok && r + 3 < a.N);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < kOA; ++i) {
+      const int k = (t >> 5) + 8 * i;
+      if (k < Kp) *reinterpret_cast<float4*>(sA + k * kTM + 4 * (t & 31)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kOB; ++i) {
+      const int k = (t >> 4) + 16 * i;
+      if (k < Kp) *reinterpret_cast<float4*>(sB + k * kTN + 4 * (t & 15)) = rb[i];
+    }
+  };
+  auto compute = [&]() {
+    const int nkp = Kp / 2;
+    int kp = 0;
+    for (; kp + 4 <= nkp; kp += 4) {  // 12 LDS reads in flight, then 8 MFMAs
+      float b[4], a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 2 * (kp + u) + lk;
+        b[u] = sB[k * kTN + wn + li];
+        a0[u] = sA[k * kTM + wm + li];
+        a1[u] = sA[k * kTM + wm + 32 + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], acc[1], 0, 0, 0);
+      }
+    }
+    for (; kp < nkp; ++kp) {
+      const int k = 2 * kp + lk;
+      const float b = sB[k * kTN + wn + li];
+      const float a0 = sA[k * kTM + wm + li];
+      const float a1 = sA[k * kTM + wm + 32 + li];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+    }
+  };
+
+  gload(a.pr[0]);
+  lstore();
+  if (a.pairs > 1) gload(a.pr[1]);  // in flight during the first pair's MFMAs
+  __syncthreads();
+  compute();
+  if (a.pairs > 1) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    compute();
+  }
+  __syncthreads();  // LDS is reused as the C staging tile below
+
+  // ---- epilogue: acc -> LDS [128][kCPad] -> coalesced float4 rows (+ addend) -> global
+  float* sC = smem;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = wm + 32 * tt + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+      sC[row * kCPad + wn + li] = acc[tt][rg];
+    }
+  __syncthreads();
+  const bool vec_ok = ((a.ldo & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < kTM * kTN / (256 * 4); ++i) {  // 8 float4 per thread
+    const int row = (t >> 4) + 16 * i;
+    const int c4 = 4 * (t & 15);
+    const int grow = m0 + row, gcol = n0 + c4;
+    if (grow >= a.M || gcol >= a.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
+    float* dst = a.out + (int64_t)grow * a.ldo + gcol;
+    if (vec_ok && gcol + 4 <= a.N) {
+      if (a.addend) {
+        const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)grow * a.ldo + gcol);
+        v.x += a.addend_scale * ad.x; v.y += a.addend_scale * ad.y;
+        v.z += a.addend_scale * ad.z; v.w += a.addend_scale * ad.w;
+      }
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
+        float o = vv[j];
+        if (a.addend) o += a.addend_scale * a.addend[(int64_t)grow * a.ldo + gcol + j];
+        dst[j] = o;
+      }
+    }
+  }
+}
+
+// ---- split-K epilogues ---------------------------------------------------------------------------------
+// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + bias[n]);  rows >= B are written as zero.
+// One float4 per thread when N % 4 == 0 (all split loads independent => in flight together);
+// fixed summation order over splits => deterministic.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ part, int splits, int slab,
+                                                     const float* __restrict__ bias, const float* __restrict__ mask,
+                                                     float* __restrict__ out, int rows, int N, int B) {
+  const int64_t total = (int64_t)rows * N / VEC;
+  const int nv = N / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / nv), n = (int)(i - (int64_t)m * nv) * VEC;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    if (m < B) {
+      for (int s = 0; s < splits; ++s) {
+        const float* p = part + (int64_t)s * slab + i * VEC;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(p);
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+          v[0] += p[0];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (bias) v[j] += bias[n + j];
+        if (mask) v[j] *= mask[i * VEC + j];
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
+    else out[i] = v[0];
+  }
+}
+
+// Top of the network: Rz = sum_s part + c ; Rd_L = sd * (p*Rz - p (p.Rz)).
+// 16 lanes per sample row (C <= 16 handled by one lane each; larger C strides), 16 rows per block.
+__global__ __launch_bounds__(256) void k_reduce_softmax_jvp(const float* __restrict__ part, int splits, int slab,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ prob,
+                                                            const float* __restrict__ sd, float* __restrict__ rd,
+                                                            int rows, int C, int B) {
+  const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  const bool live = m < rows && m < B;
+  float dot = 0.f;
+  for (int c = sub; c < C; c += 16) {
+    float rz = 0.f;
+    if (live) {
+      for (int s = 0; s < splits; ++s) rz += part[(int64_t)s * slab + (int64_t)m * C + c];
+      if (bias) rz += bias[c];
+      dot += prob[(int64_t)m * C + c] * rz;
+    }
+  }
+  // sum `dot` over the 16 lanes of this row (xor butterfly stays inside the 16-lane group)
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+  if (m < rows) {
+    const float w = live ? sd[m] : 0.f;
+    for (int c = sub; c < C; c += 16) {
+      float v = 0.f;
+      if (live) {
+        float rz = 0.f;
+        for (int s = 0; s < splits; ++s) rz += part[(int64_t)s * slab + (int64_t)m * C + c];
+        if (bias) rz += bias[c];
+        const float p = prob[(int64_t)m * C + c];
+        v = w * (p * rz - p * dot);
+      }
+      rd[(int64_t)m * C + c] = v;
+    }
+  }
+}
+
+// H(b_l) = colsum_b Rd_l[b][:] + 2 rho c_l for ALL layers in one launch.
+// Block = 64 columns x 4 row groups; each thread sums rows rg, rg+4, ... in order, the 4 groups are
+// combined in fixed order through LDS => deterministic.
+struct BiasArgs {
+  const float* rd[BHG_MLP_MAX_LAYERS];
+  const float* c[BHG_MLP_MAX_LAYERS];
+  float* out[BHG_MLP_MAX_LAYERS];
+  int n[BHG_MLP_MAX_LAYERS];
+  int blk0[BHG_MLP_MAX_LAYERS + 1];  // first block of each layer
+  int L, B;
+  float rho2;
+};
+__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
+  __shared__ float red[4][64];
+  int l = 0;
+  while (l + 1 < a.L && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
+  const int N = a.n[l];
+  const int col = ((int)blockIdx.x - a.blk0[l]) * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  const float* __restrict__ rd = a.rd[l];
+  float s0 = 0.f, s1 = 0.f;
+  if (col < N) {
+    int b = rg;
+    for (; b + 4 < a.B; b += 8) {  // two independent accumulators for load ILP
+      s0 += rd[(int64_t)b * N + col];
+      s1 += rd[(int64_t)(b + 4) * N + col];
+    }
+    if (b < a.B) s0 += rd[(int64_t)b * N + col];
+  }
+  red[rg][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && col < N) {
+    const int t = threadIdx.x;
+    a.out[l][col] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.rho2 * a.c[l][col];
+  }
+}
+
+template <int LA, int LB>
+void launch_gemm(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, a.splits);
+  hipLaunchKernelGGL((k_gemm<LA, LB>), grid, dim3(256), 0, st, a);
+}
+
+void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
+                        const float* mask, float* out, int rows, int N, int B) {
+  if ((N & 3) == 0) {
+    int blocks = (slab / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B);
+  } else {
+    int blocks = (slab + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B);
+  }
+}
+
+int pick_splits(int tiles, int K, int pairs) {
+  // fill ~2 workgroups per CU; never split below one K step
+  const int ksteps = (K + kTK - 1) / kTK;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > ksteps) s = ksteps;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return s;
+}
+
+}  // namespace
+}  // namespace bhg
+
+using namespace bhg;
+
+extern "C" {
+
+size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
+  if (!m || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS) return 0;
+  size_t mx = 0;
+  for (int l = 0; l < m->L; ++l) {
+    // R-forward of layer l (N = dims[l+1], K = dims[l]) and R-backward into layer l (N = dims[l], K = dims[l+1])
+    const int Nf = m->dims[l + 1], Kf = m->dims[l];
+    const int sf = pick_splits((Nf + kTN - 1) / kTN, Kf, 2);
+    mx = mx > (size_t)sf * m->Bp * Nf ? mx : (size_t)sf * m->Bp * Nf;
+    const int sb = pick_splits((Kf + kTN - 1) / kTN, Nf, 2);
+    mx = mx > (size_t)sb * m->Bp * Kf ? mx : (size_t)sb * m->Bp * Kf;
+  }
+  return mx;
+}
+
+int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream) {
+  BHG_REQUIRE(m && dir && out, "NULL argument");
+  BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
+  BHG_REQUIRE(m->Bp == kTM && m->B >= 1 && m->B <= m->Bp, "batch must fit one 128-row tile");
+  BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  const float rho2 = m->ridge2;
+
+  // ---- R-forward ------------------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    const float* c = static_cast<const float*>(dir[2 * l + 1]);
+    GemmArgs a{};
+    a.pr[0] = {m->h[l], V, K, K};                       // h_{l-1} V_l^T
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
+    a.M = Bp; a.N = N; a.K = K;
+    a.splits = pick_splits((N + kTN - 1) / kTN, K, a.pairs);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, st);
+    const int slab = Bp * N;
+    if (l + 1 < L) {
+      launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
+    } else {
+      hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
+                         a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
+    }
+  }
+  // ---- R-backward -----------------------------------------------------------------------------------
+  for (int l = L - 1; l >= 1; --l) {
+    const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    GemmArgs a{};
+    a.pr[0] = {m->delta[l], V, K, N};
+    a.pr[1] = {m->Rd[l], m->W[l], K, N};
+    a.pairs = 2;
+    a.M = Bp; a.N = N; a.K = K;
+    a.splits = pick_splits((N + kTN - 1) / kTN, K, 2);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, st);
+    const int slab = Bp * N;
+    launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
+  }
+  // ---- outputs ----------------------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const int Mo = m->dims[l + 1], No = m->dims[l];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    GemmArgs a{};
+    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
+    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
+    a.splits = 1;
+    a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
+    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
+    {
+      const int Kp = (B + 1) & ~1;
+      size_t lds = (size_t)Kp * (kTM + kTN) * sizeof(float);
+      const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
+      if (lds < lds_c) lds = lds_c;
+      static bool attr_set = false;
+      if (!attr_set) {  // > 64 KiB of dynamic LDS needs an explicit opt-in
+        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
+      hipLaunchKernelGGL(k_outer, grid, dim3(256), lds, st, a);
+    }
+  }
+  {
+    BiasArgs ba{};
+    ba.L = L; ba.B = B; ba.rho2 = rho2;
+    int blk = 0;
+    for (int l = 0; l < L; ++l) {
+      ba.rd[l] = m->Rd[l];
+      ba.c[l] = static_cast<const float*>(dir[2 * l + 1]);
+      ba.out[l] = static_cast<float*>(out[2 * l + 1]);
+      ba.n[l] = m->dims[l + 1];
+      ba.blk0[l] = blk;
+      blk += (m->dims[l + 1] + 63) / 64;
+    }
+    ba.blk0[L] = blk;
+    hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+}  // extern "C"

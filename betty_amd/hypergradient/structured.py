@@ -1,12 +1,28 @@
-"""Opt-in analytic HVP providers for structured inner problems.
+"""Opt-in analytic Hessian-vector products for structured inner problems.
 
-The reference always differentiates twice through the user's opaque ``training_step``.  When the
-inner problem *declares* a structure the backend knows (logistic regression; ReLU-MLP with
-weighted cross-entropy), the HVP and the mixed second derivative are computed by dedicated HIP
-kernels instead.  A problem opts in by exposing ``hypergradient_structure(prev)`` returning a
-provider; problems that do not are handled by autograd exactly as in the reference.
+The reference always differentiates twice through the user's opaque ``training_step``
+(cg.py:39-41, neumann.py:62).  When the inner problem *declares* a structure this backend knows,
+the HVP and the mixed second derivative are computed in closed form instead (SURVEY.md
+Appendix A), with everything that does not depend on the direction vector cached across the K
+iterations of one hypergradient step.  A problem opts in by exposing::
+
+    def hypergradient_structure(self, prev):     # on the INNER problem
+        return WeightedCEMLP(self, prev, layers=[...], weight_fn=..., ridge=...)
+
+Problems that do not are handled by autograd exactly as in the reference.
+
+Protocol (what cg/neumann call)::
+
+    hvp_fn = provider.prepare()        # once per hypergradient step
+    hvp    = hvp_fn(direction_views)   # K times; list aligned with curr.parameters()
+    out    = provider.mixed_vjp(neg_x_views, sync)   # final hop to prev's parameters
 """
 from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
 
 
 def structured_hvp_for(curr, prev):
@@ -14,3 +30,132 @@ def structured_hvp_for(curr, prev):
     if hook is None:
         return None
     return hook(prev)
+
+
+class WeightedCEMLP:
+    """ReLU-MLP with per-sample-weighted cross-entropy (+ optional ridge):
+
+        L_in(w, lam) = (1/B) sum_i s_i(lam) * CE(f_w(x_i), y_i) + ridge * ||w||^2,
+        s_i = weight_fn(CE_i.detach())          (e.g. a meta-weight-net of ``prev``)
+
+    — the inner problem of examples/learning_to_reweight/main.py:117-127 (BASELINE cfg 2 / the
+    metric's 10 M-parameter problem).  ``layers`` are the ``nn.Linear`` modules in forward order;
+    ``curr.parameters()`` must enumerate them as [W1, b1, W2, b2, ...].
+
+    Full Hessian (not Gauss-Newton), SURVEY.md Appendix A.3:
+      cached per step:  h_l, masks m_l, softmax p, delta_l
+      per direction (V_l, c_l):
+        R-forward   Ra_l = Rh_{l-1} W_l^T + h_{l-1} V_l^T + c_l,  Rh_l = m_l * Ra_l
+        top         Rdelta_L = (s/B) * (p*Rz - p (p.Rz))
+        R-backward  Rdelta_{l-1} = m_{l-1} * (delta_l V_l + Rdelta_l W_l)
+        outputs     H(W_l) = Rdelta_l^T h_{l-1} + delta_l^T Rh_{l-1} + 2 ridge V_l,
+                    H(b_l) = sum_batch Rdelta_l + 2 ridge c_l
+      mixed VJP to lam: c_i = (p_i - onehot_i).Rz_i(x) / B, then backward of sum_i c_i s_i(lam).
+
+    ``impl="hip"`` (default on a GPU) runs the GEMM chain on the MFMA kernels of libbhg;
+    ``impl="torch"`` evaluates the same formulas with ATen ops (used by the tests to validate the
+    math against autograd and to cross-check the kernels).
+    """
+
+    def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
+                 batch=None, impl: Optional[str] = None):
+        self.curr, self.prev = curr, prev
+        self.layers = list(layers)
+        self.weight_fn = weight_fn
+        self.ridge = float(ridge)
+        self.batch = batch
+        self.impl = impl
+        params = list(curr.parameters())
+        expect = []
+        for lin in self.layers:
+            expect += [lin.weight, lin.bias]
+        if len(params) != len(expect) or any(a is not b for a, b in zip(params, expect)):
+            raise ValueError("WeightedCEMLP: curr.parameters() must be [W1, b1, W2, b2, ...] of `layers`")
+
+    # ---------------------------------------------------------------------------------------------
+    def prepare(self):
+        x, y = self.batch if self.batch is not None else self.curr.cur_batch
+        impl = self.impl or ("hip" if x.is_cuda else "torch")
+        if impl == "hip":
+            from ._mlp_hip import HipMLPState  # noqa: PLC0415
+
+            self._state = HipMLPState(self, x, y)
+        elif impl == "torch":
+            self._state = _TorchMLPState(self, x, y)
+        else:
+            raise ValueError(f"unknown impl {impl!r}")
+        return self._state.hvp
+
+    def mixed_vjp(self, neg_x_views, sync: bool):
+        st = self._state
+        coeff = st.mixed_coeff(neg_x_views)  # [B]: d(g.(-x))/d s_i
+        upper = self.prev.trainable_parameters()
+        if sync:
+            torch.autograd.backward(st.sample_weight, grad_tensors=coeff.reshape(st.sample_weight.shape), inputs=upper)
+            return None
+        return list(torch.autograd.grad(st.sample_weight, upper, grad_outputs=coeff.reshape(st.sample_weight.shape)))
+
+
+class _TorchMLPState:
+    """ATen evaluation of the closed form (device agnostic; the math reference for the kernels)."""
+
+    def __init__(self, spec: WeightedCEMLP, x, y):
+        self.spec = spec
+        Ws = [lin.weight.detach() for lin in spec.layers]
+        bs = [lin.bias.detach() for lin in spec.layers]
+        B = x.shape[0]
+        hs, masks = [x.detach()], []
+        h = hs[0]
+        for l, (W, b) in enumerate(zip(Ws, bs)):
+            a = torch.addmm(b, h, W.t())
+            if l + 1 < len(Ws):
+                m = (a > 0).to(a.dtype)
+                h = a * m
+                masks.append(m)
+                hs.append(h)
+            else:
+                z = a
+        logp = F.log_softmax(z, dim=1)
+        p = logp.exp()
+        ce = -logp.gather(1, y.reshape(-1, 1)).reshape(-1)
+        self.sample_weight = spec.weight_fn(ce.detach())  # keeps the graph to prev's parameters
+        sd = self.sample_weight.detach().reshape(-1) / B
+        onehot = F.one_hot(y, z.shape[1]).to(z.dtype)
+        self.err = p - onehot  # [B, C]
+        deltas = [None] * len(Ws)
+        deltas[-1] = sd[:, None] * self.err
+        for l in range(len(Ws) - 1, 0, -1):
+            deltas[l - 1] = masks[l - 1] * (deltas[l] @ Ws[l])
+        self.Ws, self.hs, self.masks, self.p, self.sd, self.deltas, self.B = Ws, hs, masks, p, sd, deltas, B
+
+    def _r_forward(self, Vs, cs):
+        Rh, Rhs = None, [None]
+        for l, (W, V, c) in enumerate(zip(self.Ws, Vs, cs)):
+            Ra = torch.addmm(c, self.hs[l], V.t())
+            if Rh is not None:
+                Ra = Ra + Rh @ W.t()
+            if l + 1 < len(self.Ws):
+                Rh = self.masks[l] * Ra
+                Rhs.append(Rh)
+        return Ra, Rhs  # Rz, [None, Rh_1, ..]
+
+    def hvp(self, direction_views):
+        Vs, cs = direction_views[0::2], direction_views[1::2]
+        rho2 = 2.0 * self.spec.ridge
+        Rz, Rhs = self._r_forward(Vs, cs)
+        Rd = self.sd[:, None] * (self.p * Rz - self.p * (self.p * Rz).sum(1, keepdim=True))
+        out = [None] * (2 * len(self.Ws))
+        for l in range(len(self.Ws) - 1, -1, -1):
+            HW = Rd.t() @ self.hs[l]
+            if Rhs[l] is not None:
+                HW = HW + self.deltas[l].t() @ Rhs[l]
+            out[2 * l] = HW + rho2 * Vs[l] if rho2 else HW
+            Hb = Rd.sum(0)
+            out[2 * l + 1] = Hb + rho2 * cs[l] if rho2 else Hb
+            if l > 0:
+                Rd = self.masks[l - 1] * (self.deltas[l] @ Vs[l] + Rd @ self.Ws[l])
+        return out
+
+    def mixed_coeff(self, dir_views):
+        Rz, _ = self._r_forward(dir_views[0::2], dir_views[1::2])
+        return (self.err * Rz).sum(1) / self.B

@@ -152,6 +152,34 @@ size_t bhg_logreg_tmp_floats(int n, int d);
 int bhg_logreg_hvp(const float* X, const float* s, const float* lam, const float* p, float* out,
                    float* tmp, int n, int d, void* stream);
 
+/* ReLU-MLP with per-sample-weighted cross-entropy (+ ridge) — SURVEY Appendix A.3; the inner
+ * problem of examples/learning_to_reweight/main.py:117-127 (BASELINE cfg 2 / the metric's 10 M
+ * parameter problem).  The caller computes the direction-independent quantities once per
+ * hypergradient step and describes them here; bhg_mlp_hvp then evaluates
+ *   H(W_l) = Rd_l^T h_{l-1} + delta_l^T Rh_{l-1} + ridge2 * V_l ,  H(b_l) = colsum(Rd_l) + ridge2 * c_l
+ * on the fp32 matrix cores.  Layer l (0-based) maps dims[l] -> dims[l+1]; all [Bp, d] buffers are
+ * row-major with Bp = 128 rows, rows >= B zero.                                                   */
+#define BHG_MLP_MAX_LAYERS 32
+typedef struct bhg_mlp {
+  int32_t L, B, Bp;
+  int32_t dims[BHG_MLP_MAX_LAYERS + 1];
+  const float* W[BHG_MLP_MAX_LAYERS];     /* [dims[l+1], dims[l]] (torch nn.Linear.weight)          */
+  const float* h[BHG_MLP_MAX_LAYERS];     /* input of layer l:      [Bp, dims[l]]   (h[0] = x)      */
+  const float* mask[BHG_MLP_MAX_LAYERS];  /* ReLU mask of layer l:  [Bp, dims[l+1]], l < L-1 (1/0)  */
+  const float* delta[BHG_MLP_MAX_LAYERS]; /* dL/d(pre-activation l): [Bp, dims[l+1]]                */
+  const float* prob;                      /* softmax output [Bp, dims[L]]                           */
+  const float* sd;                        /* per-sample weight / B  [Bp]                            */
+  float* Rh[BHG_MLP_MAX_LAYERS];          /* scratch [Bp, dims[l+1]], l < L-1                       */
+  float* Rd[BHG_MLP_MAX_LAYERS];          /* scratch [Bp, dims[l+1]]                                */
+  float* partial;                         /* split-K scratch, >= bhg_mlp_partial_floats() floats    */
+  size_t partial_floats;
+  float ridge2;                           /* 2 * ridge                                              */
+} bhg_mlp;
+size_t bhg_mlp_partial_floats(const bhg_mlp* m);
+/* dir / out: host arrays of 2L device pointers [V_0, c_0, V_1, c_1, ...] / [H(W_0), H(b_0), ...]
+ * (contiguous fp32, 16-byte aligned; out tensors are fully overwritten).                         */
+int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

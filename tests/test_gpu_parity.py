@@ -302,3 +302,89 @@ def test_product_refuses_cpu_tensors(be):
     lay = be.layout([torch.randn(10, device=DEV)])
     with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
         be.neumann_init(lay, t, lay.new_flat(), lay.new_flat())
+
+
+# ------------------------------------------------------------------------------------------------
+# analytic MLP HVP on the matrix cores (csrc/bhg_mlp.hip)
+# ------------------------------------------------------------------------------------------------
+def _mlp_problem(dims, B, ridge, seed):
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    g = torch.Generator().manual_seed(seed)
+    inner = zoo.MLP(dims)
+    upper = zoo.MWN(16)
+    with torch.no_grad():
+        for p in list(inner.parameters()) + list(upper.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (1.0 / max(p.shape[-1], 4) ** 0.5))
+    inner, upper = inner.to(DEV), upper.to(DEV)
+    x = torch.randn(B, dims[0], generator=g).to(DEV)
+    y = torch.randint(0, dims[-1], (B,), generator=g).to(DEV)
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    curr = zoo.StubProblem("inner", inner, config=Config(type="cg"), loss_fn=zoo.make_reweight_loss(prev, ridge), batch=(x, y))
+    direction = [torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+
+    def provider(impl):
+        return WeightedCEMLP(curr, prev, layers=list(inner.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)),
+                             ridge=ridge, impl=impl)
+
+    return curr, prev, direction, provider
+
+
+@pytest.mark.parametrize(
+    "dims,B",
+    [([48, 64, 32, 10], 40), ([70, 130, 33, 10], 100), ([256, 192, 10], 128), ([33, 7], 5), ([12] + [12] * 5 + [4], 17)],
+    ids=lambda v: str(v),
+)
+def test_mlp_hvp_kernels_vs_aten_and_autograd(dims, B):
+    curr, prev, direction, provider = _mlp_problem(dims, B, ridge=0.05, seed=sum(dims) + B)
+    hip = provider("hip")
+    got = [t.clone() for t in hip.prepare()(direction)]
+    ref = provider("torch").prepare()(direction)
+    # same closed form, fp32 on both sides: only the GEMM summation order differs
+    for a, b in zip(got, ref):
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-5 * scale
+    # and against double backward through the user's training_step
+    loss = curr.training_step_exec(curr.cur_batch)
+    g = torch.autograd.grad(loss, curr.parameters(), create_graph=True)
+    want = torch.autograd.grad(g, curr.parameters(), grad_outputs=direction, retain_graph=True)
+    rel, _ = rel_err(_np(got), _np(want))
+    assert rel <= 2e-5, rel
+    # mixed VJP
+    mv = hip.mixed_vjp(direction, False)
+    want_m = torch.autograd.grad(g, prev.trainable_parameters(), grad_outputs=direction)
+    rel, _ = rel_err(_np(mv), _np(want_m))
+    assert rel <= 2e-5, rel
+
+
+@pytest.mark.parametrize("name", ["reweight_cg20", "reweight_neumann10", "deep_cg6", "deep_neumann6"])
+@pytest.mark.parametrize("sync", [False, True])
+def test_structured_hip_path_matches_reference(name, sync, be):
+    case = zoo.CASE_BY_NAME[name]
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    zoo.attach_mlp_structure(curr, case.family, impl="hip")
+    out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, sync)
+    if sync:
+        assert out is None
+        out = [p.grad for p in prev.trainable_parameters()]
+    rel, mx = rel_err(_np(out), golden_list(outputs, case.name, "fp32"))
+    assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)  # north_star tolerance
+
+
+def test_mlp_hvp_full_size_cfg2():
+    """BASELINE cfg-2 shapes (N = 10,034,826, batch 100): MFMA HVP vs the ATen closed form, and
+    linearity H(a u + b v) = a H u + b H v as a size-independent property."""
+    dims, B = [3072, 2048, 1536, 384, 10], 100
+    curr, prev, direction, provider = _mlp_problem(dims, B, ridge=1e-2, seed=1)
+    hvp = provider("hip").prepare()
+    got = [t.clone() for t in hvp(direction)]
+    ref = provider("torch").prepare()(direction)
+    rel, mx = rel_err(_np(got), _np(ref))
+    assert rel <= 1e-5 and mx <= 1e-4, (rel, mx)
+    g = torch.Generator().manual_seed(9)
+    other = [torch.randn(d.shape, generator=g).to(DEV) for d in direction]
+    h2 = [t.clone() for t in hvp(other)]
+    comb = [t.clone() for t in hvp([0.5 * u - 2.0 * v for u, v in zip(direction, other)])]
+    rel, _ = rel_err(_np(comb), _np([0.5 * a - 2.0 * b for a, b in zip(got, h2)]))
+    assert rel <= 1e-5, rel

@@ -243,7 +243,7 @@ def seed_family_inputs(family, seed=0):
 
 FAMILY_LOSS: Dict[str, Callable] = {
     "logreg": lambda upper: make_logreg_loss(upper),
-    "reweight": lambda upper: make_reweight_loss(upper, 0.5),
+    "reweight": lambda upper: make_reweight_loss(upper, 0.5),  # keep in sync with RIDGE below
     "imaml": lambda upper: make_imaml_loss(upper, 0.5),
     "deep": lambda upper: make_reweight_loss(upper, 0.5),
 }
@@ -269,3 +269,21 @@ def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cp
     prev = StubProblem("upper", upper, config=config_cls())
     curr = StubProblem("inner", inner, config=config_cls(**case.cfg), loss_fn=FAMILY_LOSS[case.family](prev), batch=batch)
     return curr, prev, vector
+
+
+RIDGE = {"reweight": 0.5, "deep": 0.5}
+
+
+def attach_mlp_structure(curr, family, impl=None):
+    """Opt the inner problem into the analytic HVP (betty_amd.hypergradient.structured)."""
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    def structure(prev):
+        return WeightedCEMLP(
+            curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)),
+            ridge=RIDGE[family], impl=impl,
+        )
+
+    curr.hypergradient_structure = structure
+    return curr
+
