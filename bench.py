@@ -128,6 +128,21 @@ def build(device, seed, dtype=torch.float32, ddp=False, K=20):
     return curr, prev, vector
 
 
+def pmc_traffic(resident, N):
+    """HBM bytes per launch of the recurrence kernel from the committed PMC passes
+    (profiles/pmc_k_cg_resident.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this
+    very command, corrected per MI355X_MICROARCH.md §HBM).  PMC collection needs rocprofv3 around the
+    process, so bench.py reports the committed measurement for the matching kernel + size, else null."""
+    path = os.path.join(ROOT, "profiles", "pmc_k_cg_resident.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    if not resident or d.get("workload_N") != N:
+        return None
+    return d["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(steps, K):
     """The oracle (line-for-line restatement of the reference's CPU autograd path, pinned
     bit-for-bit against it in tests/test_oracle.py) timed on this box's host cores."""
@@ -256,7 +271,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic(resident, N),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": avg_us,
                 "launches_timed": kern_launches,
