@@ -159,3 +159,64 @@ class _TorchMLPState:
     def mixed_coeff(self, dir_views):
         Rz, _ = self._r_forward(dir_views[0::2], dir_views[1::2])
         return (self.err * Rz).sum(1) / self.B
+
+
+class LogisticRegressionL2:
+    """Logistic regression with a per-weight L2 penalty (the inner problem
+    of examples/logistic_regression_hpo/logistic_regression_implicit.py:80-91 and
+    test/test_regression.py:47-59):
+
+        L_in(w, lam) = mean_i BCE(x_i.w, y_i) + 1/2 sum_j lam_j w_j^2
+
+    H p = X^T( s * (X p) ) + lam * p with s_i = sigma_i (1 - sigma_i) / n  — two GEMV passes over X
+    (csrc/bhg_logreg.hip); the mixed derivative of g.x w.r.t. the lam TENSOR is w * x, pushed into
+    ``prev``'s parameters through ``lam``'s own graph.  ``lam_fn()`` must return lam (shape [d]) as
+    a function of ``prev``'s parameters.
+    """
+
+    def __init__(self, curr, prev, weight: torch.nn.Parameter, lam_fn: Callable, batch=None):
+        self.curr, self.prev, self.weight, self.lam_fn, self.batch = curr, prev, weight, lam_fn, batch
+        params = list(curr.parameters())
+        if len(params) != 1 or params[0] is not weight:
+            raise ValueError("LogisticRegressionL2: curr.parameters() must be [weight]")
+
+    def prepare(self):
+        from .. import _native  # noqa: PLC0415
+
+        x, _y = self.batch if self.batch is not None else self.curr.cur_batch
+        if not x.is_cuda:
+            raise _native.NativeLibraryError("LogisticRegressionL2 needs CUDA/HIP tensors; there is no CPU fallback")
+        self.lib = _native.load()
+        self.X = x.detach().to(torch.float32).contiguous()
+        n, d = self.X.shape
+        self.n, self.d = n, d
+        self.lam = self.lam_fn()  # keeps the graph to prev's parameters
+        self.lam_d = self.lam.detach().to(torch.float32).contiguous()
+        self.w = self.weight.detach().to(torch.float32).contiguous()
+        self.s = torch.empty(n, device=x.device)
+        self.tmp = torch.empty(int(self.lib.bhg_logreg_tmp_floats(n, d)), device=x.device)
+        self.out = torch.empty(d, device=x.device)
+        self._stream = lambda: int(torch.cuda.current_stream().cuda_stream)
+        _native.check(self.lib.bhg_logreg_prepare(self.X.data_ptr(), self.w.data_ptr(), self.s.data_ptr(), n, d, self._stream()),
+                      "bhg_logreg_prepare")
+        self._native = _native
+        return self.hvp
+
+    def hvp(self, direction_views):
+        (p,) = direction_views
+        p = p.detach().to(torch.float32).contiguous()
+        self._native.check(
+            self.lib.bhg_logreg_hvp(self.X.data_ptr(), self.s.data_ptr(), self.lam_d.data_ptr(), p.data_ptr(),
+                                    self.out.data_ptr(), self.tmp.data_ptr(), self.n, self.d, self._stream()),
+            "bhg_logreg_hvp",
+        )
+        return [self.out.view(self.weight.shape)]
+
+    def mixed_vjp(self, neg_x_views, sync: bool):
+        coeff = (self.w * neg_x_views[0].reshape(-1)).reshape(self.lam.shape)  # d(g.(-x))/d lam
+        upper = self.prev.trainable_parameters()
+        if sync:
+            torch.autograd.backward(self.lam, grad_tensors=coeff, inputs=upper)
+            return None
+        return list(torch.autograd.grad(self.lam, upper, grad_outputs=coeff))
+

@@ -388,3 +388,43 @@ def test_mlp_hvp_full_size_cfg2():
     comb = [t.clone() for t in hvp([0.5 * u - 2.0 * v for u, v in zip(direction, other)])]
     rel, _ = rel_err(_np(comb), _np([0.5 * a - 2.0 * b for a, b in zip(got, h2)]))
     assert rel <= 1e-5, rel
+
+
+# ------------------------------------------------------------------------------------------------
+# analytic logistic-regression HVP (csrc/bhg_logreg.hip), BASELINE cfg 1
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(500, 100), (37, 5), (4096, 257), (1, 1)])
+def test_logreg_hvp_kernels_vs_autograd(n, d):
+    lib = _native.load()
+    g = torch.Generator().manual_seed(n + d)
+    X = torch.randn(n, d, generator=g).to(DEV)
+    w = (0.3 * torch.randn(d, generator=g)).to(DEV).requires_grad_(True)
+    y = (torch.rand(n, generator=g) < 0.5).float().to(DEV)
+    lam = (0.5 + torch.rand(d, generator=g)).to(DEV)
+    p = torch.randn(d, generator=g).to(DEV)
+    s = torch.empty(n, device=DEV)
+    tmp = torch.empty(int(lib.bhg_logreg_tmp_floats(n, d)), device=DEV)
+    out = torch.empty(d, device=DEV)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    _native.check(lib.bhg_logreg_prepare(X.data_ptr(), w.data_ptr(), s.data_ptr(), n, d, st), "prepare")
+    _native.check(lib.bhg_logreg_hvp(X.data_ptr(), s.data_ptr(), lam.data_ptr(), p.data_ptr(), out.data_ptr(), tmp.data_ptr(), n, d, st), "hvp")
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(X @ w, y) + 0.5 * (lam * w * w).sum()
+    (gr,) = torch.autograd.grad(loss, w, create_graph=True)
+    (want,) = torch.autograd.grad(gr, w, grad_outputs=p)
+    # fp32 GEMV pair vs autograd's fp32 mm chain; rtol 2e-5 of the largest entry
+    assert (out - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["logreg_cg5", "logreg_cg3_a01", "logreg_neumann5", "logreg_cg0"])
+@pytest.mark.parametrize("sync", [False, True])
+def test_structured_logreg_path_matches_reference(name, sync, be):
+    case = zoo.CASE_BY_NAME[name]
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    zoo.attach_logreg_structure(curr)
+    out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, sync)
+    if sync:
+        assert out is None
+        out = [p.grad for p in prev.trainable_parameters()]
+    rel, mx = rel_err(_np(out), golden_list(outputs, case.name, "fp32"))
+    assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)

@@ -287,3 +287,10 @@ def attach_mlp_structure(curr, family, impl=None):
     curr.hypergradient_structure = structure
     return curr
 
+
+def attach_logreg_structure(curr):
+    from betty_amd.hypergradient.structured import LogisticRegressionL2
+
+    curr.hypergradient_structure = lambda prev: LogisticRegressionL2(curr, prev, curr.module.w, lam_fn=lambda: prev.fwd())
+    return curr
+
