@@ -186,12 +186,15 @@ def main():
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; betty_amd has no CPU path"
+    if os.environ.get("BHG_ALL_RANKS_ON_GPU0") == "1":  # debug: exercise the N>1 code path on a 1-GPU box (gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -199,7 +202,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from betty_amd import _native

@@ -1,0 +1,261 @@
+"""The caller slice of the hot path: a compact ``ImplicitProblem`` with the reference's surface.
+
+Only what sits directly around the hypergradient call is restated here:
+``backward`` (direct gradient, then one ``get_grads`` per path with the reference's ``do_sync`` /
+``retain_graph`` rules — betty/problems/problem.py:521-581), ``set_grads`` (583-597),
+``training_step_exec`` (327-332), ``one_step_descent`` (334-369), the unroll/gradient-accumulation
+step schedule (371-415) and ``ImplicitProblem``'s parameter accessors and optimizer step
+(betty/problems/implicit_problem.py:40-65,80-84).  Logging, validation, roll-back, LR schedulers'
+warm-up, FSDP/accelerate and the iterative-differentiation problems stay in the reference: a Betty
+user keeps using ``betty.Engine`` + ``betty_amd.install()``; this module exists so the package
+(tests, examples, benchmarks) also runs where the reference is not installed.
+"""
+from __future__ import annotations
+
+import torch
+
+from .configs import Config
+from .hypergradient import get_grads
+
+
+def _to_device(obj, device):
+    if torch.is_tensor(obj):
+        return obj.to(device)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_device(o, device) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _to_device(v, device) for k, v in obj.items()}
+    return obj
+
+
+class Problem:
+    """One level of a multilevel optimisation problem.  Subclasses define ``training_step(batch)``
+    (and optionally ``on_inner_loop_start``, ``param_callback``, ``grad_callback``)."""
+
+    def __init__(self, name, config=None, module=None, optimizer=None, scheduler=None, train_data_loader=None,
+                 device=None):
+        self._name = name
+        self._config = config if config is not None else Config()
+        self.module, self.optimizer, self.scheduler = module, optimizer, scheduler
+        self.train_data_loader = train_data_loader
+        self._iter = None
+        self.device = device
+        self.cur_batch = None
+        self._parents, self._children, self._paths = [], [], []
+        self.ready = []
+        self._count = 0
+        self._inner_loop_start = True
+        self._training = True
+        self._strategy = "default"
+        self.leaf = False
+        # forward module seen by other problems (a DDP wrapper under strategy "distributed")
+        self.fwd = module
+
+    # ---- identity / wiring (engine.py:232-291, problem.py:808-870) ------------------------------------
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def config(self):
+        return self._config
+
+    @property
+    def paths(self):
+        return self._paths
+
+    @property
+    def children(self):
+        return self._children
+
+    @property
+    def parents(self):
+        return self._parents
+
+    @property
+    def count(self):
+        return self._count
+
+    def add_child(self, problem):
+        assert problem not in self._children
+        self._children.append(problem)
+        self.ready = [False] * len(self._children)
+
+    def add_parent(self, problem):
+        assert problem not in self._parents
+        self._parents.append(problem)
+
+    def add_paths(self, paths):
+        self._paths.extend(paths)
+
+    def clear_dependencies(self):
+        self._parents, self._children, self._paths, self.ready = [], [], [], []
+
+    def set_problem_attr(self, problem):
+        """Other problems are reachable as attributes by name (``self.inner(x)``), problem.py:792-806."""
+        if problem.name in self.__dict__ or hasattr(type(self), problem.name):
+            raise ValueError(f"problem name {problem.name!r} clashes with an attribute")
+        setattr(self, problem.name, problem)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        return self.fwd(*args, **kwargs)
+
+    # ---- parameters (implicit_problem.py:80-84, problem.py:850-854) --------------------------------------
+    def parameters(self):
+        raise NotImplementedError
+
+    def trainable_parameters(self):
+        raise NotImplementedError
+
+    def meta_trainable_parameters(self):
+        return self.trainable_parameters()
+
+    # ---- data (problem.py:456-487) --------------------------------------------------------------------------
+    def get_batch(self):
+        loader = self.train_data_loader
+        if loader is None:
+            return None
+        if self._iter is None:
+            self._iter = iter(loader)
+        try:
+            batch = next(self._iter)
+        except StopIteration:
+            self._iter = iter(loader)
+            batch = next(self._iter)
+        return _to_device(batch, self.device) if self.device is not None else batch
+
+    # ---- loss / step (problem.py:327-369, 489-519) ----------------------------------------------------------
+    def training_step(self, batch):
+        raise NotImplementedError
+
+    def training_step_exec(self, batch):
+        precision = self._config.precision
+        if precision in ("fp16", "bf16"):
+            dtype = torch.float16 if precision == "fp16" else torch.bfloat16
+            with torch.autocast(device_type="cuda", dtype=dtype):
+                return self.training_step(batch)
+        return self.training_step(batch)
+
+    @property
+    def gas(self):
+        return self._config.gradient_accumulation
+
+    def gradient_accumulation_boundary(self):
+        return bool(self._count % self.gas == 0)
+
+    def get_loss(self, batch):
+        out = self.training_step_exec(batch)
+        loss = out["loss"] if isinstance(out, dict) else out
+        return loss / self.gas
+
+    def one_step_descent(self, batch=None):
+        if batch is None:
+            self.cur_batch = self.get_batch()
+            batch = self.cur_batch
+        loss = self.get_loss(batch)
+        self.backward(
+            loss=loss,
+            params=self.trainable_parameters(),
+            paths=self._paths,
+            create_graph=not self._config.first_order,
+            retain_graph=self._config.retain_graph,
+            allow_unused=self._config.allow_unused,
+        )
+        if hasattr(self, "grad_callback"):
+            self.grad_callback()
+        if self.gradient_accumulation_boundary():
+            self.optimizer_step()
+            if hasattr(self, "param_callback"):
+                self.param_callback()
+            self.zero_grad()
+        return loss
+
+    def backward(self, loss, params, paths, create_graph=False, retain_graph=True, allow_unused=True):
+        """problem.py:521-581."""
+        # direct gradient: through autograd.grad + set_grads while a hypergradient (or another
+        # accumulation step) is still to come, through backward() (DDP-syncing) otherwise
+        if len(paths) > 0 or not self.gradient_accumulation_boundary():
+            grads = torch.autograd.grad(loss, params, create_graph=create_graph, retain_graph=retain_graph,
+                                        allow_unused=allow_unused)
+            self.set_grads(params, grads)
+        else:
+            torch.autograd.backward(loss, inputs=params, create_graph=create_graph, retain_graph=retain_graph)
+        # indirect gradient through the lower levels' best responses
+        if self._config.first_order:
+            last = len(paths) - 1
+            for idx, path in enumerate(paths):
+                do_sync = bool(idx == last and self.gradient_accumulation_boundary())
+                grads = get_grads(loss, path, retain_graph=(idx != last), do_sync=do_sync)
+                if not do_sync:
+                    self.set_grads(params, grads)
+
+    def set_grads(self, params, grads):
+        """problem.py:583-597: out-of-place accumulate, skip None."""
+        for param, grad in zip(params, grads):
+            if grad is None:
+                continue
+            param.grad = grad if getattr(param, "grad", None) is None else param.grad + grad
+
+    def optimizer_step(self):
+        raise NotImplementedError
+
+    def zero_grad(self):
+        for p in self.trainable_parameters():
+            p.grad = None
+
+    # ---- schedule (problem.py:371-454) ---------------------------------------------------------------------
+    def check_ready(self):
+        return all(self.ready) if self._children else True
+
+    def step_normal(self, global_step=None):
+        if not self.check_ready():
+            return
+        if self._inner_loop_start:
+            if hasattr(self, "on_inner_loop_start"):
+                self.on_inner_loop_start()
+            self._inner_loop_start = False
+        if self._training:
+            self._count += 1
+        self.one_step_descent()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        period = self._config.unroll_steps * self.gas
+        if self._training and self._count % period == 0 and self._count > self._config.warmup_steps:
+            for parent in self._parents:
+                parent.ready[parent.children.index(self)] = True
+                parent.step_normal(global_step=global_step)
+            self._inner_loop_start = True
+        self.ready = [False] * len(self._children)
+
+    def step(self, global_step=None):
+        self.step_normal(global_step=global_step)
+
+    def train(self):
+        self._training = True
+        if self.module is not None:
+            self.module.train()
+
+    def eval(self):
+        self._training = False
+        if self.module is not None:
+            self.module.eval()
+
+
+class ImplicitProblem(Problem):
+    """Problem differentiated by implicit differentiation (cg / neumann / darts), the class every
+    BASELINE config uses (betty/problems/implicit_problem.py:13-92)."""
+
+    def parameters(self):
+        return list(self.module.parameters())
+
+    def trainable_parameters(self):
+        return list(self.module.parameters())
+
+    def optimizer_step(self):
+        clip = self._config.gradient_clipping
+        if clip > 0.0:
+            torch.nn.utils.clip_grad_norm_(self.trainable_parameters(), max_norm=clip)
+        self.optimizer.step()
