@@ -16,6 +16,8 @@
 // 64 x 32 on v_mfma_f32_32x32x2_f32, exact fp32), staged through LDS with coalesced 16-B global
 // loads, split along K across workgroups to fill the 256 CUs (deterministic: partial slabs are
 // summed in fixed order by the epilogue, no atomics).
+#include <stdlib.h>
+
 #include "bhg_common.hpp"
 
 namespace bhg {
@@ -515,6 +517,130 @@ __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
   }
 }
 
+// ---- narrow output layer (C = dims[L] <= 32 classes): dedicated latency-optimised kernels ----------------
+// A 128x64-tile MFMA kernel is the wrong tool for the classifier head (10 x 384 at the benchmark): three
+// small kernels replace two split-K GEMM+reduce pairs and one outer-product launch.
+constexpr int kSmallC = 32;
+
+// Rz[b][c] = Rh[b].W[c] + h[b].V[c] + cb[c], then Rd_L[b] = sd[b] * (p*Rz - p (p.Rz)).
+// One workgroup per sample row; wave w handles classes w, w+4, ...; lanes stride K (coalesced rows).
+__global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ Rh, const float* __restrict__ h,
+                                                      const float* __restrict__ W, const float* __restrict__ V,
+                                                      const float* __restrict__ cb, const float* __restrict__ prob,
+                                                      const float* __restrict__ sd, float* __restrict__ rd, int K,
+                                                      int C, int B) {
+  __shared__ float rz[kSmallC];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (b >= B) {
+    if (threadIdx.x < C) rd[(int64_t)b * C + threadIdx.x] = 0.f;
+    return;
+  }
+  const float* rhb = Rh ? Rh + (int64_t)b * K : nullptr;
+  const float* hb = h + (int64_t)b * K;
+  // every wave owns up to 8 classes (w, w+4, ...); all their partial dots advance together so that
+  // 2 + 2*8 independent loads are in flight per k (the kernel is pure latency otherwise)
+  float acc[kSmallC / 4];
+#pragma unroll
+  for (int j = 0; j < kSmallC / 4; ++j) acc[j] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float hv = hb[k];
+    const float rv = rhb ? rhb[k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < kSmallC / 4; ++j) {
+      const int c = wave + 4 * j;
+      if (c < C) {
+        acc[j] = fmaf(hv, V[(int64_t)c * K + k], acc[j]);
+        if (rhb) acc[j] = fmaf(rv, W[(int64_t)c * K + k], acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSmallC / 4; ++j) {
+    const int c = wave + 4 * j;
+    float a = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0 && c < C) rz[c] = a + cb[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += prob[(int64_t)b * C + c] * rz[c];
+    const float p = prob[(int64_t)b * C + threadIdx.x];
+    rd[(int64_t)b * C + threadIdx.x] = sd[b] * (p * rz[threadIdx.x] - p * dot);
+  }
+}
+
+// Rd_prev[b][n] = mask[b][n] * sum_c (delta[b][c] V[c][n] + Rd[b][c] W[c][n]);  thread per (b, 4 n).
+__global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__ delta, const float* __restrict__ rd,
+                                                       const float* __restrict__ W, const float* __restrict__ V,
+                                                       const float* __restrict__ mask, float* __restrict__ out,
+                                                       int N, int C, int B, int rows) {
+  const int nv = N / 4;
+  const int64_t total = (int64_t)rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / nv), n = (int)(i - (int64_t)b * nv) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < B) {
+      for (int c = 0; c < C; ++c) {
+        const float d = delta[(int64_t)b * C + c], r = rd[(int64_t)b * C + c];
+        const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * N + n);
+        const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)c * N + n);
+        acc.x += d * v.x + r * w.x; acc.y += d * v.y + r * w.y;
+        acc.z += d * v.z + r * w.z; acc.w += d * v.w + r * w.w;
+      }
+      const float4 m = *reinterpret_cast<const float4*>(mask + (int64_t)b * N + n);
+      acc.x *= m.x; acc.y *= m.y; acc.z *= m.z; acc.w *= m.w;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)b * N + n) = acc;
+  }
+}
+
+// G[c][n] = sum_b (Rd[b][c] h[b][n] + delta[b][c] Rh[b][n]) + rho2 V[c][n];  block = 64 n x 4 batch groups,
+// fixed-order combine through LDS (deterministic).
+__global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd, const float* __restrict__ h,
+                                                    const float* __restrict__ delta, const float* __restrict__ Rh,
+                                                    const float* __restrict__ V, float rho2, float* __restrict__ out,
+                                                    int N, int C, int B) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.y;
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (n < N) {
+    int b = g;
+    for (; b + 28 < B; b += 32) {  // 8 batch rows per trip: 32 independent loads before the fma chain
+      float r[8], hh[8], d[8], rr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b + 4 * u;
+        r[u] = rd[(int64_t)bb * C + c];
+        hh[u] = h[(int64_t)bb * N + n];
+        d[u] = Rh ? delta[(int64_t)bb * C + c] : 0.f;
+        rr[u] = Rh ? Rh[(int64_t)bb * N + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = fmaf(r[u], hh[u], acc);
+        acc = fmaf(d[u], rr[u], acc);
+      }
+    }
+    for (; b < B; b += 4) {
+      acc = fmaf(rd[(int64_t)b * C + c], h[(int64_t)b * N + n], acc);
+      if (Rh) acc = fmaf(delta[(int64_t)b * C + c], Rh[(int64_t)b * N + n], acc);
+    }
+  }
+  red[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    const int t = threadIdx.x;
+    float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (rho2 != 0.f) v += rho2 * V[(int64_t)c * N + n];
+    out[(int64_t)c * N + n] = v;
+  }
+}
+
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, a.splits);
@@ -574,11 +700,20 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   const int L = m->L, Bp = m->Bp, B = m->B;
   const float rho2 = m->ridge2;
 
+  // a narrow classifier head (<= 32 classes, feature width a multiple of 4) takes the dedicated kernels
+  static const bool no_head = getenv("BHG_MLP_NO_HEAD") != nullptr;    // A/B switches (debug)
+  static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;
+  const bool head = !no_head && L >= 1 && m->dims[L] <= kSmallC && (m->dims[L - 1] & 3) == 0;
   // ---- R-forward ------------------------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
+    if (head && l == L - 1) {
+      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
+                         m->h[l], m->W[l], V, c, m->prob, m->sd, m->Rd[l], K, N, B);
+      continue;
+    }
     GemmArgs a{};
     a.pr[0] = {m->h[l], V, K, K};                       // h_{l-1} V_l^T
     a.pairs = 1;
@@ -595,10 +730,60 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
                          a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
     }
   }
-  // ---- R-backward -----------------------------------------------------------------------------------
+  // ---- R-backward (main stream) overlapped with the weight-shaped outputs (side stream) ----------------
+  // H(W_l) only needs Rd_l and Rh_{l-1}; the R-backward chain that produces Rd_{l-1} is independent of
+  // it.  The many-workgroup outer products therefore run on a library-owned side stream and fill the
+  // CUs the short, latency-bound split-K kernels of the backward chain leave idle.
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS], ev_join = nullptr;
+  if (!side) {
+    BHG_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // > 64 KiB dynamic LDS
+  }
+  auto launch_outer = [&](int l, hipStream_t s) {
+    const int Mo = m->dims[l + 1], No = m->dims[l];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    if (head && l == L - 1) {
+      hipLaunchKernelGGL(k_head_outer, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l], m->h[l],
+                         m->delta[l], l > 0 ? (const float*)m->Rh[l - 1] : nullptr, V, rho2,
+                         static_cast<float*>(out[2 * l]), No, Mo, B);
+      return;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
+    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
+    a.splits = 1;
+    a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
+    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
+    const int Kp = (B + 1) & ~1;
+    size_t lds = (size_t)Kp * (kTM + kTN) * sizeof(float);
+    const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
+    if (lds < lds_c) lds = lds_c;
+    dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
+    hipLaunchKernelGGL(k_outer, grid, dim3(256), lds, s, a);
+  };
   for (int l = L - 1; l >= 1; --l) {
+    // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
+    if (no_side) {
+      launch_outer(l, st);
+    } else {
+      BHG_HIP_CHECK(hipEventRecord(ev_rd[l], st));
+      BHG_HIP_CHECK(hipStreamWaitEvent(side, ev_rd[l], 0));
+      launch_outer(l, side);
+    }
     const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
     const float* V = static_cast<const float*>(dir[2 * l]);
+    if (head && l == L - 1) {
+      int blocks = (Bp * (N / 4) + 255) / 256;
+      hipLaunchKernelGGL(k_head_backward, dim3(blocks), dim3(256), 0, st, m->delta[l], (const float*)m->Rd[l], m->W[l],
+                         V, m->mask[l - 1], m->Rd[l - 1], N, K, B, Bp);
+      continue;
+    }
     GemmArgs a{};
     a.pr[0] = {m->delta[l], V, K, N};
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
@@ -610,32 +795,10 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     const int slab = Bp * N;
     launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
   }
-  // ---- outputs ----------------------------------------------------------------------------------------
-  for (int l = 0; l < L; ++l) {
-    const int Mo = m->dims[l + 1], No = m->dims[l];
-    const float* V = static_cast<const float*>(dir[2 * l]);
-    GemmArgs a{};
-    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
-    a.pairs = 1;
-    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
-    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
-    a.splits = 1;
-    a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
-    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
-    {
-      const int Kp = (B + 1) & ~1;
-      size_t lds = (size_t)Kp * (kTM + kTN) * sizeof(float);
-      const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
-      if (lds < lds_c) lds = lds_c;
-      static bool attr_set = false;
-      if (!attr_set) {  // > 64 KiB of dynamic LDS needs an explicit opt-in
-        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-      }
-      dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
-      hipLaunchKernelGGL(k_outer, grid, dim3(256), lds, st, a);
-    }
+  launch_outer(0, st);  // needs Rd_0, the end of the chain
+  if (L > 1 && !no_side) {
+    BHG_HIP_CHECK(hipEventRecord(ev_join, side));
+    BHG_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
   }
   {
     BiasArgs ba{};
