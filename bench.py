@@ -249,13 +249,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_total_ms, kern_launches = 0.0, 0
+    hvp_total_ms, hvp_calls = 0.0, 0
     if timing_on:
         import ctypes
 
         tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
         _native.check(be.lib.bhg_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
-        be.lib.bhg_timing_enable(0)
         kern_total_ms, kern_launches = tot.value, cnt.value
+        _native.check(be.lib.bhg_timing_read(2, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
+        hvp_total_ms, hvp_calls = tot.value, cnt.value
+        be.lib.bhg_timing_enable(0)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -282,6 +285,26 @@ def main():
                 "avg_launch_us": avg_us,
                 "launches_timed": kern_launches,
             }
+        hvp_roof = None
+        if hvp_calls:
+            # useful flops of one analytic HVP (B valid rows, no padding): R-forward + R-backward + weight-shaped outputs
+            d = SIZES
+            fwd = sum(2.0 * BATCH * d[l] * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 1))
+            bwd = sum(2.0 * BATCH * d[l] * d[l + 1] * 2 for l in range(1, len(d) - 1))
+            outer = sum(2.0 * BATCH * d[l] * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 1))
+            flops = fwd + bwd + outer
+            us = 1e3 * hvp_total_ms / hvp_calls
+            hvp_roof = {
+                "bound": "mfma",
+                "kernel": "bhg_mlp_hvp (k_gemm<NT>, k_gemm<NN>, k_outer, head kernels, split-K reduces)",
+                "achieved": flops / (us * 1e-6) / 1e12,
+                "peak": 157.3,
+                "unit": "TFLOP/s",
+                "frac": flops / (us * 1e-6) / 1e12 / 157.3,
+                "flops_per_call": flops,
+                "avg_call_us": us,
+                "calls_timed": hvp_calls,
+            }
         out = {
             "metric": "hypergradient-steps/sec (CG K=20, 10M inner params)",
             "value": value,
@@ -304,6 +327,7 @@ def main():
                 "finite": finite,
             },
             "roofline": roof,
+            "hvp_roofline": hvp_roof,
             "cpu_baseline": None,
         }
         if world == 1 and args.cpu_steps > 0:

@@ -62,6 +62,9 @@ struct PtrTab {
 int make_table(PtrTab* out, const void* const* host_ptrs, int T, void* ws, int slot,
                hipStream_t stream);
 
+// measurement hook (bhg_timing_enable): true + two fresh events when this launch group is to be timed
+bool span_begin(int kind, hipEvent_t* a, hipEvent_t* b);
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float* tab_ptr(const PtrTab& t, int i) {
   const void* p = t.dev ? t.dev[i] : t.inl[i];

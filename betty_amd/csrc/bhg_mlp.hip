@@ -663,7 +663,8 @@ void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab,
 int pick_splits(int tiles, int K, int pairs) {
   // fill ~2 workgroups per CU; never split below one K step
   const int ksteps = (K + kTK - 1) / kTK;
-  int s = (512 + tiles - 1) / tiles;
+  static const int target = getenv("BHG_SPLIT_TARGET") ? atoi(getenv("BHG_SPLIT_TARGET")) : 512;
+  int s = (target + tiles - 1) / tiles;
   if (s > ksteps) s = ksteps;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
@@ -700,6 +701,9 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   const int L = m->L, Bp = m->Bp, B = m->B;
   const float rho2 = m->ridge2;
 
+  hipEvent_t t_a, t_b;
+  const bool timed = span_begin(BHG_TIMING_MLP_HVP, &t_a, &t_b);
+  if (timed) BHG_HIP_CHECK(hipEventRecord(t_a, st));
   // a narrow classifier head (<= 32 classes, feature width a multiple of 4) takes the dedicated kernels
   static const bool no_head = getenv("BHG_MLP_NO_HEAD") != nullptr;    // A/B switches (debug)
   static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;
@@ -815,6 +819,7 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     ba.blk0[L] = blk;
     hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
   }
+  if (timed) BHG_HIP_CHECK(hipEventRecord(t_b, st));
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

@@ -569,31 +569,6 @@ __global__ __launch_bounds__(kThreads) void k_axpy_multi(PtrTab dst, PtrTab src,
   }
 }
 
-// ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
-// When enabled, the recurrence launches carry start/stop events attached to the kernels themselves
-// (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end on the launch stream, the same interval
-// rocprofv3 --kernel-trace reports.  Off by default: no events, no overhead.
-struct TimedSpan { hipEvent_t a, b; int kind; };
-bool g_timing = false;
-std::vector<TimedSpan> g_spans;
-std::vector<hipEvent_t> g_free_events;
-constexpr size_t kMaxSpans = 8192;
-hipEvent_t take_event() {
-  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
-  hipEvent_t e = nullptr;
-  if (hipEventCreate(&e) != hipSuccess) return nullptr;
-  return e;
-}
-// Returns true (and fills a/b) when this launch group should be timed.
-bool span_begin(int kind, hipEvent_t* a, hipEvent_t* b) {
-  *a = *b = nullptr;
-  if (!g_timing || g_spans.size() >= kMaxSpans) return false;
-  *a = take_event(); *b = take_event();
-  if (!*a || !*b) return false;
-  g_spans.push_back({*a, *b, kind});
-  return true;
-}
-
 inline int grid_for(int n_chunks) { return n_chunks < kMaxBlocks ? (n_chunks > 0 ? n_chunks : 1) : kMaxBlocks; }
 
 int g_num_cus = -1;
@@ -611,6 +586,34 @@ int num_cus() {
 }
 
 }  // namespace
+
+// ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
+// When enabled, the recurrence launches carry start/stop events attached to the kernels themselves
+// (hipExtLaunchKernelGGL), i.e. kernel begin -> kernel end on the launch stream, the same interval
+// rocprofv3 --kernel-trace reports.  Off by default: no events, no overhead.
+namespace {
+struct TimedSpan { hipEvent_t a, b; int kind; };
+bool g_timing = false;
+std::vector<TimedSpan> g_spans;
+std::vector<hipEvent_t> g_free_events;
+constexpr size_t kMaxSpans = 8192;
+hipEvent_t take_event() {
+  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+// Returns true (and fills a/b) when this launch group should be timed.
+bool span_begin(int kind, hipEvent_t* a, hipEvent_t* b) {  // declared in bhg_common.hpp
+  *a = *b = nullptr;
+  if (!g_timing || g_spans.size() >= kMaxSpans) return false;
+  *a = take_event(); *b = take_event();
+  if (!*a || !*b) return false;
+  g_spans.push_back({*a, *b, kind});
+  return true;
+}
+
 
 int make_table(PtrTab* out, const void* const* host_ptrs, int T, void* ws, int slot, hipStream_t stream) {
   memset(out, 0, sizeof(*out));

@@ -137,6 +137,7 @@ int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_ch
  * the recorded spans of `kind` and returns their summed duration and count.           */
 #define BHG_TIMING_CG_STEP 0
 #define BHG_TIMING_NEUMANN_STEP 1
+#define BHG_TIMING_MLP_HVP 2      /* whole bhg_mlp_hvp call: event before the first / after the last launch */
 int bhg_timing_enable(int on);
 int bhg_timing_read(int kind, double* total_ms, int* launches);
 

@@ -1,7 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "mlp or structured" 2>&1 | tail -3
 for i in 1 2; do
-for V in "" "BHG_MLP_NO_SIDE=1" "BHG_MLP_NO_HEAD=1" "BHG_MLP_NO_SIDE=1 BHG_MLP_NO_HEAD=1"; do
+for V in "BHG_SPLIT_TARGET=256" "BHG_SPLIT_TARGET=384" "BHG_SPLIT_TARGET=512" "BHG_SPLIT_TARGET=768" "BHG_SPLIT_TARGET=1024"; do
   echo "== [$V]"; env $V timeout 300 python bench.py --cpu-steps 0 --steps 30 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
 done; done
