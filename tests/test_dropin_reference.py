@@ -1,0 +1,112 @@
+"""Drop-in under the REAL reference: `betty_amd.install()` replaces the registry entries of a live
+`betty.hypergradient` and the reference's own Engine/Problem (unmodified, imported from /root/reference)
+drives our cg/neumann/darts through `Problem.backward -> get_grads`.  Only runs where the reference
+checkout exists (the build container); kernels are the C oracle via the test-only checker backend
+because that container has no GPU.  The same scenario runs on the GPU through the HIP kernels with
+betty_amd's own caller slice in tests/test_engine_shim.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "betty")), reason="reference checkout not present")
+
+
+@pytest.fixture()
+def ref():
+    sys.path.insert(0, REF)
+    try:
+        import betty  # noqa: F401
+        import betty.hypergradient as bh
+        from betty.configs import Config, EngineConfig
+        from betty.engine import Engine
+        from betty.problems import ImplicitProblem
+    finally:
+        sys.path.remove(REF)
+    saved = dict(bh.jvp_fn_mapping)
+    yield dict(bh=bh, Config=Config, EngineConfig=EngineConfig, Engine=Engine, ImplicitProblem=ImplicitProblem)
+    bh.jvp_fn_mapping.clear()
+    bh.jvp_fn_mapping.update(saved)
+
+
+@pytest.mark.parametrize("algo", ["cg", "neumann", "darts"])
+def test_reference_engine_runs_on_our_functions(ref, algo):
+    import betty_amd
+    from _cpu_checker_backend import CpuCheckerBackend
+    from betty_amd import hypergradient as hg
+    from betty_amd.backend import use_backend
+
+    Config, EngineConfig, Engine, ImplicitProblem = ref["Config"], ref["EngineConfig"], ref["Engine"], ref["ImplicitProblem"]
+    mapping = betty_amd.install(ref["bh"])
+    assert mapping is ref["bh"].jvp_fn_mapping and mapping[algo] is hg.jvp_fn_mapping[algo]
+    calls = []
+    orig = mapping[algo]
+
+    def spy(vector, curr, prev, sync):
+        calls.append((curr.name, prev.name, sync, len(vector)))
+        return orig(vector, curr, prev, sync)
+
+    mapping[algo] = spy
+
+    class Child(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(20))
+
+        def forward(self, x):
+            return x @ self.w, self.w
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(20))
+
+        def forward(self):
+            return self.w
+
+    class Outer(ImplicitProblem):
+        def training_step(self, batch):
+            x, y = batch
+            return F.binary_cross_entropy_with_logits(self.inner(x)[0], y)
+
+        def param_callback(self):
+            for p in self.trainable_parameters():
+                p.data.clamp_(min=1e-8)
+
+    class Inner(ImplicitProblem):
+        def training_step(self, batch):
+            x, y = batch
+            outs, w = self.module(x)
+            return F.binary_cross_entropy_with_logits(outs, y) + 0.5 * (self.outer() * w * w).sum()
+
+        def on_inner_loop_start(self):
+            self.module.w.data.zero_()
+
+    rng = np.random.RandomState(0)
+    torch.manual_seed(0)
+    w_gt = rng.randn(20)
+    x = rng.randn(1000, 20)
+    y = ((x @ w_gt + 0.1 * rng.randn(1000)) > 0).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    parent, child = Parent(), Child()
+    cfgs = {
+        "darts": Config(unroll_steps=100),
+        "cg": Config(type="cg", cg_iterations=3, cg_alpha=0.1, unroll_steps=100),
+        "neumann": Config(type="neumann", neumann_iterations=5, unroll_steps=100),
+    }
+    outer = Outer(name="outer", module=parent, optimizer=torch.optim.SGD(parent.parameters(), lr=1.0, momentum=0.9),
+                  train_data_loader=[(t(x[500:]), t(y[500:]))], config=Config())
+    inner = Inner(name="inner", module=child, optimizer=torch.optim.SGD(child.parameters(), lr=0.1),
+                  train_data_loader=[(t(x[:500]), t(y[:500]))], config=cfgs[algo])
+    engine = Engine(config=EngineConfig(train_iters=2000), problems=[outer, inner],
+                    dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}})
+    with use_backend(CpuCheckerBackend()):
+        engine.run()
+        loss = outer.training_step(outer.cur_batch)
+    assert len(calls) == 20  # 2000 iterations / unroll 100
+    assert all(c == ("inner", "outer", True, 1) for c in calls)  # the reference calls with sync=True here
+    assert float(loss.detach()) < 0.48  # test_regression.py:126,151,176
