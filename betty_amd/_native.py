@@ -87,6 +87,10 @@ SYMBOLS = {
     "bhg_scale_flat": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
     "bhg_darts_eps": (c_int, [_PP, c_int, _CH, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bhg_axpy_multi": (c_int, [_PP, _PP, c_int, _CH, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "bhg_sama_adam_precondition": (
+        c_int,
+        [_PP, _PP, _PP, _PP, c_int, _CH, c_int, c_void_p, c_double, c_double, c_double, c_double, c_void_p, c_void_p],
+    ),
     "bhg_timing_enable": (c_int, [c_int]),
     "bhg_timing_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
     "bhg_logreg_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -149,6 +149,20 @@ class HipBackend:
         )
         return eps32[0], out[1]
 
+    def sama_adam_precondition(self, layout, vector, last_grad, exp_avg, exp_avg_sq, out_flat, beta1, beta2, eps, lr) -> None:
+        tabs, keep = [], []
+        for lst in (vector, last_grad, exp_avg, exp_avg_sq):
+            prepared = self._prep(lst, layout)  # kept alive until the launch below is enqueued
+            tab, k = self._table(prepared)
+            tabs.append(tab)
+            keep.append((prepared, k))
+        _native.check(
+            self.lib.bhg_sama_adam_precondition(tabs[0], tabs[1], tabs[2], tabs[3], layout.T, layout.chunks_dev.data_ptr(),
+                                                layout.n_chunks, out_flat.data_ptr(), float(beta1), float(beta2), float(eps),
+                                                float(lr), layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_sama_adam_precondition",
+        )
+
     def axpy_multi(self, layout, dst, src, coef: Optional[torch.Tensor], mul: float) -> None:
         d = self._prep(dst, layout, writable=True)
         s = self._prep(src, layout)

@@ -22,9 +22,9 @@ constexpr size_t kWsScal = 0;                                 // 16 doubles
 constexpr size_t kWsPartP = 128;                              // kMaxBlocks doubles
 constexpr size_t kWsPartR = kWsPartP + 8 * kMaxBlocks;        // 2 x kMaxBlocks doubles
 constexpr size_t kWsBarrier = kWsPartR + 16 * kMaxBlocks;     // 64 x u32
-constexpr size_t kWsTables = kWsBarrier + 256;                // 2 x T pointers
+constexpr size_t kWsTables = kWsBarrier + 256;                // 4 x T pointers
 inline size_t ws_bytes(int T) {
-  size_t b = kWsTables + 2 * sizeof(void*) * (size_t)(T > 0 ? T : 0);
+  size_t b = kWsTables + 4 * sizeof(void*) * (size_t)(T > 0 ? T : 0);
   return (b + 255) & ~(size_t)255;
 }
 

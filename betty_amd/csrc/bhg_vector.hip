@@ -569,6 +569,49 @@ __global__ __launch_bounds__(kThreads) void k_axpy_multi(PtrTab dst, PtrTab src,
   }
 }
 
+// ---- SAMA: Adam-preconditioned direction (betty/hypergradient/utils.py:37-63) ---------------------------
+// out = v * scale * lr,  scale = ((1-b1) b2 u_old - b1 (1-b2) g m_old) / (sqrt(u) + eps)^3,
+// m_old = (m - (1-b1) g)/b1 (0 when b1 == 0),  u_old = (u - (1-b2) g g)/b2.
+// One pass: read v, g, m, u (4 tensors lists), write the flat preconditioned vector: 20*N bytes.
+struct SamaCoef { float one_m_b1, b1, one_m_b2, b2, c1 /*(1-b1)*b2*/, c2 /*b1*(1-b2)*/, eps, lr; };
+__global__ __launch_bounds__(kThreads) void k_sama_adam(PtrTab tv, PtrTab tg, PtrTab tm, PtrTab tu,
+                                                        const bhg_chunk* __restrict__ chunks, int n_chunks,
+                                                        float* __restrict__ out, SamaCoef k) {
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    const float* v = tab_ptr(tv, ck.tensor) + ck.src_off;
+    const float* g = tab_ptr(tg, ck.tensor) + ck.src_off;
+    const float* m = tab_ptr(tm, ck.tensor) + ck.src_off;
+    const float* u = tab_ptr(tu, ck.tensor) + ck.src_off;
+    float4 av[kVecPerThread], ag[kVecPerThread], am[kVecPerThread], au[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      av[i] = ld4(v, e, ck.len); ag[i] = ld4(g, e, ck.len); am[i] = ld4(m, e, ck.len); au[i] = ld4(u, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      const float vv[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+      const float gg[4] = {ag[i].x, ag[i].y, ag[i].z, ag[i].w};
+      const float mm[4] = {am[i].x, am[i].y, am[i].z, am[i].w};
+      const float uu[4] = {au[i].x, au[i].y, au[i].z, au[i].w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // same op order / roundings as the reference's ATen expression
+        const float m_old = k.b1 != 0.f ? sub_rn(mm[j], mul_rn(k.one_m_b1, gg[j])) / k.b1 : 0.f;
+        const float u_old = sub_rn(uu[j], mul_rn(mul_rn(k.one_m_b2, gg[j]), gg[j])) / k.b2;
+        float sc = sub_rn(mul_rn(k.c1, u_old), mul_rn(mul_rn(k.c2, gg[j]), m_old));
+        const float d = add_rn(sqrtf(uu[j]), k.eps);
+        sc = sc / mul_rn(mul_rn(d, d), d);
+        o[j] = mul_rn(mul_rn(vv[j], sc), k.lr);
+      }
+      st4(out + ck.flat_off, e, ck.len, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
+}
+
 inline int grid_for(int n_chunks) { return n_chunks < kMaxBlocks ? (n_chunks > 0 ? n_chunks : 1) : kMaxBlocks; }
 
 int g_num_cus = -1;
@@ -852,6 +895,33 @@ int bhg_timing_read(int kind, double* total_ms, int* launches) {
   }
   *total_ms = tot;
   *launches = n;
+  return BHG_OK;
+}
+
+int bhg_sama_adam_precondition(const void* const* vec, const void* const* last_grad, const void* const* exp_avg,
+                               const void* const* exp_avg_sq, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                               float* out_flat, double beta1, double beta2, double eps, double lr, void* ws,
+                               void* stream) {
+  BHG_COMMON_CHECKS(vec);
+  BHG_REQUIRE(last_grad && exp_avg && exp_avg_sq, "NULL state table");
+  BHG_REQUIRE(beta2 != 0.0, "beta2 must be non-zero");
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(out_flat, "out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PtrTab tv, tg, tm, tu;
+  if (int rc = make_table(&tv, vec, T, ws, 0, st)) return rc;
+  if (int rc = make_table(&tg, last_grad, T, ws, 1, st)) return rc;
+  if (int rc = make_table(&tm, exp_avg, T, ws, 2, st)) return rc;
+  if (int rc = make_table(&tu, exp_avg_sq, T, ws, 3, st)) return rc;
+  // Python-float (double) products first, then one rounding to fp32 — what `python_scalar * tensor` does
+  SamaCoef k;
+  k.one_m_b1 = (float)(1.0 - beta1); k.b1 = (float)beta1;
+  k.one_m_b2 = (float)(1.0 - beta2); k.b2 = (float)beta2;
+  k.c1 = (float)((1.0 - beta1) * beta2); k.c2 = (float)(beta1 * (1.0 - beta2));
+  k.eps = (float)eps; k.lr = (float)lr;
+  hipLaunchKernelGGL(k_sama_adam, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tv, tg, tm, tu, chunks_dev,
+                     n_chunks, out_flat, k);
+  BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
 

@@ -8,10 +8,12 @@ from __future__ import annotations
 from .cg import cg
 from .darts import darts
 from .neumann import neumann
+from .sama import sama
 from .utils import grad, replace_none_with_zero
 
 jvp_fn_mapping = {
     "darts": darts,
+    "sama": sama,
     "neumann": neumann,
     "cg": cg,
 }

@@ -259,3 +259,8 @@ class ImplicitProblem(Problem):
         if clip > 0.0:
             torch.nn.utils.clip_grad_norm_(self.trainable_parameters(), max_norm=clip)
         self.optimizer.step()
+        if self._config.type == "sama":  # implicit_problem.py:60-65: SAMA's preconditioner needs the last gradient
+            for param in self.trainable_parameters():
+                state = self.optimizer.state[param]
+                if param.grad is not None and len(state) != 0:
+                    state["last_grad"] = param.grad.detach().clone()

@@ -130,6 +130,17 @@ int bhg_darts_eps(const void* const* vec, int T, const bhg_chunk* chunks_dev, in
 int bhg_axpy_multi(void* const* dst, const void* const* src, int T, const bhg_chunk* chunks_dev,
                    int n_chunks, const float* coef_dev, float mul, void* ws, void* stream);
 
+/* ---- SAMA (betty/hypergradient/sama.py:25, utils.py:37-63): Adam-preconditioned direction ----------
+ * out_flat = vec * scale * lr with scale built from the optimizer state (last_grad, exp_avg,
+ * exp_avg_sq): one fused pass over the four tensor lists (20*N bytes) instead of ~14 ATen
+ * launches per tensor.  All tensors of one call share (beta1, beta2, eps, lr) — one call per
+ * optimizer param group.  The finite-difference part of SAMA is then bhg_darts_eps / bhg_axpy_multi
+ * on the views of out_flat, exactly as for `darts`.                                                 */
+int bhg_sama_adam_precondition(const void* const* vec, const void* const* last_grad,
+                               const void* const* exp_avg, const void* const* exp_avg_sq, int T,
+                               const bhg_chunk* chunks_dev, int n_chunks, float* out_flat,
+                               double beta1, double beta2, double eps, double lr, void* ws, void* stream);
+
 /* ---- optional kernel timing (measurement only) ----------------------------------
  * When enabled, every bhg_cg_step / bhg_neumann_step launch group carries start/stop
  * HIP events attached to its first/last kernel on the launch stream (kernel begin ->

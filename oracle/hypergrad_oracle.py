@@ -160,7 +160,85 @@ def darts(vector, curr, prev, sync):
     return [(a - b).div_(2 * eps) for a, b in zip(g_minus, g_plus)]  # 65-67
 
 
-JVP_FNS = {"cg": cg, "neumann": neumann, "darts": darts}
+# -- betty/hypergradient/utils.py:24-92 + sama.py:7-61 -------------------------------------------------------
+def _optimizer_family(optimizer):
+    """get_optimzer_type (utils.py:24-30)."""
+    name = type(optimizer).__name__.lower()
+    if "adam" in name:
+        return "adam"
+    if "rmsprop" in name:
+        return "rmsprop"
+    return "sgd"
+
+
+def adam_preconditioned(vectors, problem):
+    """precondition_adam (utils.py:37-63): d(Adam update)/d(gradient) applied to ``vectors``."""
+    result = []
+    for vec, param in zip(vectors, problem.meta_trainable_parameters()):
+        group = problem.get_opt_param_group_for_param(param)
+        state = problem.get_opt_state_for_param(param)
+        with torch.no_grad():
+            b1, b2 = group["betas"]
+            eps = group["eps"]
+            g = state.get("last_grad", torch.zeros_like(vec))
+            m = state.get("exp_avg", torch.zeros_like(vec))
+            u = state.get("exp_avg_sq", torch.zeros_like(vec))
+            m_prev = (m - (1 - b1) * g) / b1 if b1 != 0 else 0  # 50-52
+            u_prev = (u - (1 - b2) * g * g) / b2  # 53
+            factor = (1 - b1) * b2 * u_prev - b1 * (1 - b2) * g * m_prev  # 55-57
+            factor /= (torch.sqrt(u) + eps) ** 3  # 58
+        result.append(vec * factor * group["lr"])  # 59
+    return result
+
+
+def preconditioned(vectors, problem):
+    """precondition (utils.py:86-92)."""
+    family = _optimizer_family(problem.optimizer)
+    if family == "sgd":
+        return vectors
+    if family == "adam":
+        return adam_preconditioned(vectors, problem)
+    raise NotImplementedError(f"SAMA preconditioning for {family} is not implemented!")
+
+
+def sama(vector, curr, prev, sync):
+    cfg = curr.config
+    radius = cfg.sama_adam_alpha  # 23
+    vector = preconditioned(vector, curr)  # 25
+    norm = flat_scaled(vector).norm()  # 26
+    eps = radius / norm.add_(1e-15).item()  # 27
+
+    for w, v in zip(curr.meta_trainable_parameters(), vector):  # 29-30
+        w.data.add_(v.data, alpha=eps)
+    loss_plus = curr.training_step_exec(curr.cur_batch)
+    g_plus = torch.autograd.grad(loss_plus, prev.trainable_parameters(), allow_unused=True)  # 32
+    g_plus = zeros_for_missing(g_plus, prev.trainable_parameters())
+    if sync:  # 34-36
+        g_plus = [-g.div_(2 * eps) for g in g_plus]
+        prev.set_grads(prev.trainable_parameters(), g_plus)
+
+    for w, v in zip(curr.meta_trainable_parameters(), vector):  # 39-40
+        w.data.sub_(v.data, alpha=2 * eps)
+    loss_minus = curr.training_step_exec(curr.cur_batch)
+    if sync:  # 42-43
+        torch.autograd.backward(loss_minus / (2 * eps), inputs=prev.trainable_parameters())
+        g_minus = None
+    else:  # 45-48
+        g_minus = torch.autograd.grad(loss_minus, prev.trainable_parameters(), allow_unused=True)
+        g_minus = zeros_for_missing(g_minus, prev.trainable_parameters())
+
+    if not cfg.sama_multitask:  # 51-53
+        for w, v in zip(curr.meta_trainable_parameters(), vector):
+            w.data.add_(v.data, alpha=eps)
+    else:  # 54-55
+        curr.synchronize_params(curr.meta_trainable_parameters(), all_reduce=True)
+
+    if sync:
+        return None
+    return [(a - b).div_(2 * eps) for a, b in zip(g_minus, g_plus)]  # 57-59
+
+
+JVP_FNS = {"cg": cg, "neumann": neumann, "darts": darts, "sama": sama}
 
 
 # -- betty/hypergradient/__init__.py:22-39 ------------------------------------------------------------------

@@ -117,3 +117,14 @@ class CpuCheckerBackend:
         for d_, s_ in zip(dst, self._prep(src)):
             assert d_.is_contiguous() and d_.dtype == torch.float32
             self.orc.orc_axpy(d_.data_ptr(), s_.data_ptr(), d_.numel(), a)
+
+    def sama_adam_precondition(self, layout, vector, last_grad, exp_avg, exp_avg_sq, out_flat, beta1, beta2, eps, lr):
+        # fp32 ATen evaluation of betty/hypergradient/utils.py:37-63 (the checker for the fused kernel)
+        for v, g, m, u, dst in zip(self._prep(vector), self._prep(last_grad), self._prep(exp_avg),
+                                   self._prep(exp_avg_sq), self._slices(layout, out_flat)):
+            m_old = (m - (1 - beta1) * g) / beta1 if beta1 != 0 else 0
+            u_old = (u - (1 - beta2) * g * g) / beta2
+            scale = (1 - beta1) * beta2 * u_old - beta1 * (1 - beta2) * g * m_old
+            scale = scale / (torch.sqrt(u) + eps) ** 3
+            dst.copy_((v * scale * lr).reshape(-1))
+

@@ -31,6 +31,7 @@ REF = {
     "cg": sys.modules["betty.hypergradient.cg"].cg,
     "neumann": sys.modules["betty.hypergradient.neumann"].neumann,
     "darts": sys.modules["betty.hypergradient.darts"].darts,
+    "sama": sys.modules["betty.hypergradient.sama"].sama,
 }
 
 
@@ -62,7 +63,7 @@ def main():
                 blob[f"out/{case.name}/fp64/{i}"] = t.numpy()
             for i, t in enumerate(s32):
                 blob[f"out/{case.name}/sync32/{i}"] = t.numpy()
-            if case.algo == "darts":
+            if case.algo in ("darts", "sama"):
                 for i, t in enumerate(w32):
                     blob[f"out/{case.name}/w32/{i}"] = t.numpy()
             a = torch.cat([t.reshape(-1).double() for t in r32])

@@ -71,7 +71,7 @@ def test_hip_path_matches_reference(case, variant, be):
     assert rel <= case.rtol and mx <= 10 * case.rtol, (case.name, variant, rel, mx)
     for v, vb in zip(vector, v_before):
         assert torch.equal(v, vb), "direction vector must not be mutated"
-    if case.algo == "darts":
+    if case.algo in ("darts", "sama"):
         for p, w in zip(curr.trainable_parameters(), golden_list(outputs, case.name, "w32")):
             np.testing.assert_allclose(p.data.cpu().numpy(), w, rtol=0, atol=2e-7)
     else:

@@ -34,7 +34,7 @@ def test_host_path_matches_reference(case, checker):
     assert rel <= case.rtol and mx <= 10 * case.rtol, (rel, mx)
     for v, vb in zip(vector, v_before):  # the direction vector is never mutated (cg.py:35 copies)
         assert torch.equal(v, vb)
-    if case.algo == "darts":  # weights restored up to the reference's own drift
+    if case.algo in ("darts", "sama"):  # weights restored up to the reference's own drift
         for p, w in zip(curr.trainable_parameters(), golden_list(outputs, case.name, "w32")):
             np.testing.assert_allclose(p.data.numpy(), w, rtol=0, atol=1e-7)
     else:
@@ -59,7 +59,7 @@ def test_sync_accumulates_and_returns_none(case, checker):
 
 
 def test_registry_and_get_grads(checker):
-    assert set(hg.jvp_fn_mapping) == {"cg", "neumann", "darts"}
+    assert set(hg.jvp_fn_mapping) == {"cg", "neumann", "darts", "sama"}
     case = zoo.CASE_BY_NAME["logreg_cg5"]
     inputs, _ = load_golden("logreg")
     curr, prev, _ = zoo.build_case(case, inputs, Config)
@@ -114,7 +114,7 @@ def test_install_mutates_registry_in_place():
     betty_amd.install(FakeRef)
     assert FakeRef.jvp_fn_mapping is mapping
     assert mapping["cg"] is hg.cg and mapping["neumann"] is hg.neumann and mapping["darts"] is hg.darts
-    assert mapping["sama"] == 4
+    assert mapping["sama"] is hg.sama and mapping["reinforce"] == 5
 
 
 @pytest.mark.parametrize("name", ["reweight_cg20", "reweight_neumann10", "deep_cg6", "deep_neumann6"])

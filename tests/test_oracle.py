@@ -41,7 +41,7 @@ def test_oracle_reproduces_reference_fp32(case):
     assert len(got) == len(want)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
-    if case.algo == "darts":
+    if case.algo in ("darts", "sama"):
         for p, w in zip(curr.trainable_parameters(), golden_list(outputs, case.name, "w32")):
             np.testing.assert_array_equal(p.data.numpy(), w)
 
@@ -71,7 +71,7 @@ def test_golden_conditioning():
         if np.linalg.norm(np.concatenate([x.ravel() for x in b])) == 0:
             continue
         rel, _ = rel_err(a, b)
-        assert rel < (5e-4 if case.algo == "darts" else 5e-6), (case.name, rel)
+        assert rel < (5e-4 if case.algo in ("darts", "sama") else 5e-6), (case.name, rel)
 
 
 def test_logreg_closed_form():
@@ -107,7 +107,7 @@ def test_oracle_matches_live_reference_on_fresh_seed():
     try:
         import betty.hypergradient  # noqa: F401
         from betty.configs import Config as RefConfig
-        ref = {k: getattr(sys.modules[f"betty.hypergradient.{k}"], k) for k in ("cg", "neumann", "darts")}
+        ref = {k: getattr(sys.modules[f"betty.hypergradient.{k}"], k) for k in ("cg", "neumann", "darts", "sama")}
     finally:
         sys.path.remove("/root/reference")
     for case in zoo.CASES:

@@ -35,6 +35,20 @@ class StubProblem:
         self.paths = []
         self._strategy = "default"
         self.fwd = module  # what `training_step` calls; a DDP wrapper in the distributed tests
+        self.optimizer = None
+
+    # SAMA's preconditioner reads the inner optimizer's state (problem.py:697-722)
+    def get_opt_param_group_for_param(self, param):
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                if param is p:
+                    return group
+
+    def get_opt_state_for_param(self, param):
+        return self.optimizer.state[param]
+
+    def synchronize_params(self, params, all_reduce=False):
+        pass
 
     def training_step_exec(self, batch):
         return self._loss_fn(self, batch)
@@ -176,6 +190,9 @@ CASES: List[Case] = [
     Case("reweight_darts", "reweight", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
     # cfg 3 shape (reduced): conv net inner, prox-regularised to the upper copy (M = N)
     Case("imaml_cg10", "imaml", "cg", dict(type="cg", cg_iterations=10, cg_alpha=1.0)),
+    # SAMA: Adam-preconditioned finite difference; SGD = identity preconditioner
+    Case("reweight_sama_adam", "reweight", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
+    Case("logreg_sama_sgd", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01), rtol=2e-3),
     # many small tensors (T = 48 > 32): exercises the device pointer-table path (cfg 5 shape)
     Case("deep_neumann6", "deep", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.2)),
     Case("deep_cg6", "deep", "cg", dict(type="cg", cg_iterations=6, cg_alpha=1.0)),
@@ -238,6 +255,12 @@ def seed_family_inputs(family, seed=0):
         arrays[f"vec_{i}"] = 0.01 * torch.randn(p.shape, generator=g)
     for i, p in enumerate(upper.parameters()):
         arrays[f"upper_{i}"] = p.data.clone()
+    # a plausible Adam state for the SAMA cases (drawn last so the older inputs keep their values)
+    for i, p in enumerate(inner.parameters()):
+        gl = 0.01 * torch.randn(p.shape, generator=g)
+        arrays[f"opt_{i}_last_grad"] = gl
+        arrays[f"opt_{i}_exp_avg"] = 0.1 * gl + 0.005 * torch.randn(p.shape, generator=g)
+        arrays[f"opt_{i}_exp_avg_sq"] = 0.001 * gl * gl + 1e-5 * (1.0 + torch.rand(p.shape, generator=g))
     return {k: v.numpy() for k, v in arrays.items()}
 
 
@@ -268,6 +291,18 @@ def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cp
     batch = (T(inputs["batch_x"]), T(inputs["batch_y"]))
     prev = StubProblem("upper", upper, config=config_cls())
     curr = StubProblem("inner", inner, config=config_cls(**case.cfg), loss_fn=FAMILY_LOSS[case.family](prev), batch=batch)
+    if case.algo == "sama":
+        if case.family == "logreg":
+            curr.optimizer = torch.optim.SGD(inner.parameters(), lr=0.1)
+        else:
+            curr.optimizer = torch.optim.Adam(inner.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+            for i, p in enumerate(inner.parameters()):
+                curr.optimizer.state[p] = {
+                    "step": torch.tensor(3.0),
+                    "exp_avg": T(inputs[f"opt_{i}_exp_avg"]),
+                    "exp_avg_sq": T(inputs[f"opt_{i}_exp_avg_sq"]),
+                    "last_grad": T(inputs[f"opt_{i}_last_grad"]),
+                }
     return curr, prev, vector
 
 
