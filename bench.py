@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cg-iters", type=int, default=20)
     ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
-    ap.add_argument("--hvp", choices=["analytic", "autograd"], default="analytic",
+    ap.add_argument("--hvp", choices=["analytic", "analytic-aten", "autograd"], default="analytic",
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
@@ -217,6 +217,8 @@ def main():
     curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K)
     if args.hvp == "analytic":
         declare_structure(curr, "hip")
+    elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
+        declare_structure(curr, "torch")
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
     layout = be.layout(vector)

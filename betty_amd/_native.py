@@ -75,12 +75,12 @@ SYMBOLS = {
     "bhg_neumann_init": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bhg_neumann_step": (
         c_int,
-        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p],
+        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p],
     ),
     "bhg_cg_init": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bhg_cg_step": (
         c_int,
-        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_void_p, c_void_p],
+        [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_int, c_void_p, c_void_p],
     ),
     "bhg_cg_resident_capacity_chunks": (c_int, []),
     "bhg_cg_scalars_dev": (c_void_p, [c_void_p]),

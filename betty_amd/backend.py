@@ -99,12 +99,13 @@ class HipBackend:
             "bhg_neumann_init",
         )
 
-    def neumann_step(self, layout, hvp, v, p, alpha: float, out_scale: float = 0.0) -> None:
+    def neumann_step(self, layout, hvp, v, p, alpha: float, out_scale: float = 0.0, hvp_shift: float = 0.0) -> None:
         ts = self._prep(hvp, layout)
         tab, _keep = self._table(ts)
         _native.check(
             self.lib.bhg_neumann_step(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, v.data_ptr(),
-                                      p.data_ptr(), alpha, out_scale, layout.workspace.data_ptr(), _stream_ptr()),
+                                      p.data_ptr(), alpha, out_scale, hvp_shift, layout.workspace.data_ptr(),
+                                      _stream_ptr()),
             "bhg_neumann_step",
         )
 
@@ -119,12 +120,12 @@ class HipBackend:
         )
 
     def cg_step(self, layout, hvp, x, r, p, cg_alpha: float, it: int, out_scale: float = 0.0,
-                variant: Optional[int] = None) -> None:
+                variant: Optional[int] = None, hvp_shift: float = 0.0) -> None:
         ts = self._prep(hvp, layout)
         tab, _keep = self._table(ts)
         _native.check(
             self.lib.bhg_cg_step(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
-                                 r.data_ptr(), p.data_ptr(), cg_alpha, it, out_scale,
+                                 r.data_ptr(), p.data_ptr(), cg_alpha, it, out_scale, hvp_shift,
                                  self.cg_variant if variant is None else variant,
                                  layout.workspace.data_ptr(), _stream_ptr()),
             "bhg_cg_step",

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void k_neumann_init(PtrTab tab, const bhg
 __global__ __launch_bounds__(kThreads) void k_neumann_step(PtrTab tab, const bhg_chunk* __restrict__ chunks,
                                                            int n_chunks, float* __restrict__ v,
                                                            float* __restrict__ p, float alpha,
-                                                           float out_scale) {
+                                                           float out_scale, float shift) {
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const bhg_chunk ck = chunks[c];
     const float* hsrc = tab_ptr(tab, ck.tensor) + ck.src_off;
@@ -134,6 +134,10 @@ __global__ __launch_bounds__(kThreads) void k_neumann_step(PtrTab tab, const bhg
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) {
       const int e = 4 * (threadIdx.x + kThreads * i);
+      if (shift != 0.f) {  // H v = (raw HVP) + shift * v  (diagonal part of the Hessian kept out of the producer)
+        h[i].x = add_rn(h[i].x, mul_rn(shift, a[i].x)); h[i].y = add_rn(h[i].y, mul_rn(shift, a[i].y));
+        h[i].z = add_rn(h[i].z, mul_rn(shift, a[i].z)); h[i].w = add_rn(h[i].w, mul_rn(shift, a[i].w));
+      }
       float4 nv, np;
       nv.x = sub_rn(a[i].x, mul_rn(alpha, h[i].x)); nv.y = sub_rn(a[i].y, mul_rn(alpha, h[i].y));
       nv.z = sub_rn(a[i].z, mul_rn(alpha, h[i].z)); nv.w = sub_rn(a[i].w, mul_rn(alpha, h[i].w));
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_init(PtrTab tab, const bhg_chun
 // K1: den = (cg_alpha*Hp).p   (cg.py:42,44,46) — reads Hp, p: 8*N bytes.
 __global__ __launch_bounds__(kThreads) void k_cg_dot(PtrTab tab, const bhg_chunk* __restrict__ chunks,
                                                      int n_chunks, const float* __restrict__ p,
-                                                     float cg_alpha, double* __restrict__ partP) {
+                                                     float cg_alpha, float shift, double* __restrict__ partP) {
   __shared__ double red[kWaves];
   double acc = 0.0;
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -202,6 +206,10 @@ __global__ __launch_bounds__(kThreads) void k_cg_dot(PtrTab tab, const bhg_chunk
     }
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) {
+      if (shift != 0.f) {
+        h[i].x = add_rn(h[i].x, mul_rn(shift, q[i].x)); h[i].y = add_rn(h[i].y, mul_rn(shift, q[i].y));
+        h[i].z = add_rn(h[i].z, mul_rn(shift, q[i].z)); h[i].w = add_rn(h[i].w, mul_rn(shift, q[i].w));
+      }
       acc += (double)mul_rn(cg_alpha, h[i].x) * q[i].x + (double)mul_rn(cg_alpha, h[i].y) * q[i].y +
              (double)mul_rn(cg_alpha, h[i].z) * q[i].z + (double)mul_rn(cg_alpha, h[i].w) * q[i].w;
     }
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_dot(PtrTab tab, const bhg_chunk
 // reads Hp, r; writes r: 12*N bytes.  x += a*p is deferred to K3, which reads p anyway.
 __global__ __launch_bounds__(kThreads) void k_cg_resid(PtrTab tab, const bhg_chunk* __restrict__ chunks,
                                                        int n_chunks, float* __restrict__ r,
+                                                       const float* __restrict__ p, float shift,
                                                        const double* __restrict__ partP,
                                                        const double* __restrict__ partR_old,
                                                        double* __restrict__ partR_new, int n_part,
@@ -233,6 +242,11 @@ __global__ __launch_bounds__(kThreads) void k_cg_resid(PtrTab tab, const bhg_chu
       const int e = 4 * (threadIdx.x + kThreads * i);
       h[i] = ld4(hsrc, e, ck.len);
       a[i] = ld4(rrp, e, ck.len);
+      if (shift != 0.f) {  // (12+4)*N bytes in this case: the direction is re-read for the diagonal term
+        const float4 q = ld4(p + ck.flat_off, e, ck.len);
+        h[i].x = add_rn(h[i].x, mul_rn(shift, q.x)); h[i].y = add_rn(h[i].y, mul_rn(shift, q.y));
+        h[i].z = add_rn(h[i].z, mul_rn(shift, q.z)); h[i].w = add_rn(h[i].w, mul_rn(shift, q.w));
+      }
     }
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) {
@@ -404,7 +418,7 @@ __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const b
 
 __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
-    float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale,
+    float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale, float shift,
     const double* __restrict__ partR_old, double* __restrict__ partR_new,
     double* __restrict__ partP, unsigned* __restrict__ barrier_words, double* __restrict__ scal) {
   __shared__ double red[kResWaves];
@@ -445,6 +459,10 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
   for (int i = 0; i < kResMax; ++i) {
 #pragma unroll
     for (int j = 0; j < kResV; ++j) {
+      if (shift != 0.f) {  // H p = (raw HVP) + shift * p: the Hessian's diagonal part never round-trips through HBM
+        h[i][j].x = add_rn(h[i][j].x, mul_rn(shift, q[i][j].x)); h[i][j].y = add_rn(h[i][j].y, mul_rn(shift, q[i][j].y));
+        h[i][j].z = add_rn(h[i][j].z, mul_rn(shift, q[i][j].z)); h[i][j].w = add_rn(h[i][j].w, mul_rn(shift, q[i][j].w));
+      }
       acc += (double)mul_rn(cg_alpha, h[i][j].x) * q[i][j].x + (double)mul_rn(cg_alpha, h[i][j].y) * q[i][j].y +
              (double)mul_rn(cg_alpha, h[i][j].z) * q[i][j].z + (double)mul_rn(cg_alpha, h[i][j].w) * q[i][j].w;
     }
@@ -750,7 +768,7 @@ int bhg_neumann_init(const void* const* vec, int T, const bhg_chunk* chunks_dev,
 }
 
 int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* v,
-                     float* p, float alpha, float out_scale, void* ws, void* stream) {
+                     float* p, float alpha, float out_scale, float hvp_shift, void* ws, void* stream) {
   BHG_COMMON_CHECKS(hvp);
   if (n_chunks == 0) return BHG_OK;
   BHG_REQUIRE(v && p, "state vector is NULL");
@@ -760,7 +778,7 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
   hipEvent_t ea, eb;
   const bool timed = span_begin(BHG_TIMING_NEUMANN_STEP, &ea, &eb);
   hipExtLaunchKernelGGL(k_neumann_step, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, timed ? ea : nullptr,
-                        timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, v, p, alpha, out_scale);
+                        timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, v, p, alpha, out_scale, hvp_shift);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
@@ -789,7 +807,8 @@ const double* bhg_cg_scalars_dev(const void* ws) {
 }
 
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
-                float* p, float cg_alpha, int iter, float out_scale, int variant, void* ws, void* stream) {
+                float* p, float cg_alpha, int iter, float out_scale, float hvp_shift, int variant, void* ws,
+                void* stream) {
   BHG_COMMON_CHECKS(hvp);
   BHG_REQUIRE(ws, "workspace is NULL");
   BHG_REQUIRE(iter >= 0, "negative iteration index");
@@ -821,9 +840,9 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
     // start event rides on the first kernel, stop event on the last: the span is the whole
     // iteration's recurrence including the two inter-kernel boundaries.
     hipExtLaunchKernelGGL(k_cg_dot, dim3(n_stream), dim3(kThreads), 0, st, timed ? ea : nullptr, nullptr, 0, tab,
-                          chunks_dev, n_chunks, (const float*)p, cg_alpha, partP);
+                          chunks_dev, n_chunks, (const float*)p, cg_alpha, hvp_shift, partP);
     hipLaunchKernelGGL(k_cg_resid, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, r,
-                       (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
+                       (const float*)p, hvp_shift, (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
     hipExtLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, nullptr, timed ? eb : nullptr, 0,
                           chunks_dev, n_chunks, x, (const float*)r, p, (const double*)partR_new, n_stream,
                           out_scale, scal);
@@ -831,7 +850,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
     const int G = num_cus();
     hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
                           timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
-                          (const double*)partR_old, partR_new, partP,
+                          hvp_shift, (const double*)partR_old, partR_new, partP,
                           reinterpret_cast<unsigned*>(w + kWsBarrier), scal);
   }
   BHG_HIP_CHECK(hipGetLastError());

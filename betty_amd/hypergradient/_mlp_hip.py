@@ -85,7 +85,7 @@ class HipMLPState:
                 d.mask[l] = self.mask[l].data_ptr()
                 d.Rh[l] = self.Rh[l].data_ptr()
         d.prob, d.sd = self.prob.data_ptr(), self.sd.data_ptr()
-        d.ridge2 = 2.0 * spec.ridge
+        d.ridge2 = 0.0  # the ridge's 2*ridge*I is applied by the recurrence kernel (spec.hvp_shift)
         n_part = int(self.lib.bhg_mlp_partial_floats(ctypes.byref(d)))
         self.partial = torch.empty(max(n_part, 1), device=dev)
         d.partial, d.partial_floats = self.partial.data_ptr(), n_part

@@ -38,11 +38,13 @@ def cg(vector, curr, prev, sync):
     p_views = layout.views(p, vector)
 
     K = int(config.cg_iterations)
+    # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
+    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.cg_alpha)
     for k in range(K):
         hvp = hvp_fn(p_views)  # H p   (cg.py:39-41)
         # cg.py:42-55 in one launch group; the last one also applies cg.py:56 and the negation
-        be.cg_step(layout, hvp, x, r, p, alpha, k, out_scale=(-alpha if k == K - 1 else 0.0))
+        be.cg_step(layout, hvp, x, r, p, alpha, k, out_scale=(-alpha if k == K - 1 else 0.0), hvp_shift=shift)
     # K == 0: x is identically zero, -alpha * 0 needs no pass.
 
     neg_x = layout.views(x, vector)

@@ -33,10 +33,11 @@ def neumann(vector, curr, prev, sync):
     v_views = layout.views(v, vector)
 
     K = int(config.neumann_iterations)
+    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.neumann_alpha)
     for k in range(K):
         hvp = hvp_fn(v_views)  # neumann.py:62
-        be.neumann_step(layout, hvp, v, p, alpha, out_scale=(-alpha if k == K - 1 else 0.0))  # 63-64 (+66)
+        be.neumann_step(layout, hvp, v, p, alpha, out_scale=(-alpha if k == K - 1 else 0.0), hvp_shift=shift)  # 63-64 (+66)
     if K == 0:
         be.scale_flat(p, -alpha)  # alpha * p with p = v   (neumann.py:66)
 

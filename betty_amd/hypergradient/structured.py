@@ -52,6 +52,9 @@ class WeightedCEMLP:
                     H(b_l) = sum_batch Rdelta_l + 2 ridge c_l
       mixed VJP to lam: c_i = (p_i - onehot_i).Rz_i(x) / B, then backward of sum_i c_i s_i(lam).
 
+    The HVP callable returns the Hessian WITHOUT its ``2*ridge*I`` part; ``hvp_shift = 2*ridge`` tells
+    cg/neumann to add ``hvp_shift * direction`` inside the fused recurrence kernel.
+
     ``impl="hip"`` (default on a GPU) runs the GEMM chain on the MFMA kernels of libbhg;
     ``impl="torch"`` evaluates the same formulas with ATen ops (used by the tests to validate the
     math against autograd and to cross-check the kernels).
@@ -63,6 +66,9 @@ class WeightedCEMLP:
         self.layers = list(layers)
         self.weight_fn = weight_fn
         self.ridge = float(ridge)
+        # the ridge's Hessian 2*ridge*I is applied inside the CG/Neumann recurrence kernel (it holds the
+        # direction in registers anyway), so the HVP kernels neither read V again nor add it
+        self.hvp_shift = 2.0 * self.ridge
         self.batch = batch
         self.impl = impl
         params = list(curr.parameters())
@@ -141,7 +147,7 @@ class _TorchMLPState:
 
     def hvp(self, direction_views):
         Vs, cs = direction_views[0::2], direction_views[1::2]
-        rho2 = 2.0 * self.spec.ridge
+        rho2 = 0.0  # ridge part handled by the recurrence kernel (spec.hvp_shift)
         Rz, Rhs = self._r_forward(Vs, cs)
         Rd = self.sd[:, None] * (self.p * Rz - self.p * (self.p * Rz).sum(1, keepdim=True))
         out = [None] * (2 * len(self.Ws))

@@ -84,11 +84,14 @@ int bhg_scatter(const float* flat, void* const* dst, int T, const bhg_chunk* chu
  * init:  v = p = vector                                    (neumann.py:60)
  * step:  v <- v - alpha*Hv ; p <- p + v                    (neumann.py:62-64)
  *        on the LAST step pass out_scale = -alpha to fold `alpha * p` (66) and the
- *        negation of neumann.py:45/54 into the same pass; otherwise out_scale = 0. */
+ *        negation of neumann.py:45/54 into the same pass; otherwise out_scale = 0.
+ *        hvp_shift: the operator applied is (HVP + hvp_shift * I); lets a producer leave a diagonal
+ *        part of the Hessian (a ridge / proximal term) out of its output (0 for plain autograd HVPs). */
 int bhg_neumann_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
                      float* v, float* p, void* ws, void* stream);
 int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
-                     float* v, float* p, float alpha, float out_scale, void* ws, void* stream);
+                     float* v, float* p, float alpha, float out_scale, float hvp_shift, void* ws,
+                     void* stream);
 
 /* ---- Conjugate gradient: betty/hypergradient/cg.py:34-56 ----------------------
  * init:  x = 0 ; r = p = vector ; rr = r.r                 (cg.py:34-36,45)
@@ -107,7 +110,8 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
                 float* x, float* r, float* p, void* ws, void* stream);
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, float cg_alpha, int iter, float out_scale,
-                int variant, void* ws, void* stream);
+                float hvp_shift /* operator = HVP + hvp_shift*I, see bhg_neumann_step */, int variant,
+                void* ws, void* stream);
 /* Largest number of chunks BHG_CG_RESIDENT can hold on the current device (0 when
  * no device is visible). */
 int bhg_cg_resident_capacity_chunks(void);

@@ -83,8 +83,10 @@ class CpuCheckerBackend:
             a.copy_(t.reshape(-1))
             b.copy_(t.reshape(-1))
 
-    def neumann_step(self, layout, hvp, v, p, alpha, out_scale=0.0):
+    def neumann_step(self, layout, hvp, v, p, alpha, out_scale=0.0, hvp_shift=0.0):
         for h, a, b in zip(self._prep(hvp), self._slices(layout, v), self._slices(layout, p)):
+            if hvp_shift:
+                h = h.reshape(-1) + torch.tensor(hvp_shift, dtype=torch.float32) * a
             self.orc.orc_neumann_step(h.data_ptr(), a.data_ptr(), b.data_ptr(), h.numel(), alpha, out_scale)
 
     def cg_init(self, layout, vector, x, r, p):
@@ -94,9 +96,11 @@ class CpuCheckerBackend:
             rr += self.orc.orc_sqnorm(t.data_ptr(), t.numel())
         self._rr[id(layout)] = rr
 
-    def cg_step(self, layout, hvp, x, r, p, cg_alpha, it, out_scale=0.0, variant=None):
+    def cg_step(self, layout, hvp, x, r, p, cg_alpha, it, out_scale=0.0, variant=None, hvp_shift=0.0):
         hs = self._prep(hvp)
         xs, rs, ps = self._slices(layout, x), self._slices(layout, r), self._slices(layout, p)
+        if hvp_shift:
+            hs = [h.reshape(-1) + torch.tensor(hvp_shift, dtype=torch.float32) * q for h, q in zip(hs, ps)]
         rr = self._rr[id(layout)]
         den = sum(self.orc.orc_dot_scaled(h.data_ptr(), q.data_ptr(), h.numel(), cg_alpha) for h, q in zip(hs, ps))
         a = _f32(_f32(rr) / _f32(den))

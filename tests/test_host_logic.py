@@ -142,7 +142,7 @@ def test_analytic_mlp_hvp_equals_autograd_hvp_fp64():
     zoo.attach_mlp_structure(curr, case.family, impl="torch")
     prov = curr.hypergradient_structure(prev)
     hvp_fn = prov.prepare()
-    got = hvp_fn(vector)
+    got = [h + prov.hvp_shift * v for h, v in zip(hvp_fn(vector), vector)]  # + ridge part (applied by the recurrence kernel)
     loss = curr.training_step_exec(curr.cur_batch)
     g = torch.autograd.grad(loss, curr.parameters(), create_graph=True)
     want = torch.autograd.grad(g, curr.parameters(), grad_outputs=vector, retain_graph=True)
