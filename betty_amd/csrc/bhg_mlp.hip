@@ -666,7 +666,8 @@ int pick_splits(int tiles, int K, int pairs) {
   static const int target = getenv("BHG_SPLIT_TARGET") ? atoi(getenv("BHG_SPLIT_TARGET")) : 512;
   int s = (target + tiles - 1) / tiles;
   if (s > ksteps) s = ksteps;
-  if (s > 16) s = 16;
+  static const int cap = getenv("BHG_SPLIT_CAP") ? atoi(getenv("BHG_SPLIT_CAP")) : 16;
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
   return s;
 }
