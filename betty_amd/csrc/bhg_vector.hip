@@ -354,12 +354,12 @@ __device__ __forceinline__ void grid_arrive(double block_value, double* part, un
   }
 }
 __device__ __forceinline__ double grid_wait_sum(const double* part, unsigned* counter, unsigned target,
-                                                double* red, unsigned* timeout_word) {
+                                                double* red, unsigned* timeout_word, unsigned spin_limit) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) {  // bounded spin: flag and fall through instead of hanging the GPU
+      if (++spins > spin_limit) {  // bounded spin: flag and fall through instead of hanging the GPU
         __hip_atomic_store((gu32*)timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -376,6 +376,7 @@ __device__ __forceinline__ double grid_wait_sum(const double* part, unsigned* co
 // f(i, j, loaded_float4) -> float4 to store back.  The compiler cannot hoist the loads of chunk
 // i+1 above the stores of chunk i to the same array itself, so the pipeline is explicit.
 constexpr int kResDepth = 3;
+constexpr unsigned kSpinLimit = 1u << 22;  // ~4 s of polling before a grid barrier gives up
 template <typename F>
 __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const bhg_chunk* __restrict__ chunks,
                                                 int n_chunks, F f) {
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
     float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale, float shift,
     const double* __restrict__ partR_old, double* __restrict__ partR_new,
-    double* __restrict__ partP, unsigned* __restrict__ barrier_words, double* __restrict__ scal) {
+    double* __restrict__ partP, unsigned* __restrict__ barrier_words, double* __restrict__ scal,
+    unsigned spin_limit) {
   __shared__ double red[kResWaves];
   const int G = gridDim.x;
 
@@ -468,7 +470,8 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     }
   }
   grid_arrive(block_sum_res(acc, red), partP, barrier_words);
-  const double den = grid_wait_sum(partP, barrier_words, (unsigned)G * (2u * iter + 1u), red, barrier_words + 1);
+  const double den = grid_wait_sum(partP, barrier_words, (unsigned)G * (2u * iter + 1u), red, barrier_words + 1,
+                                   spin_limit);
   const float alpha = (float)rr / (float)den;
 
   // ---- phase 2a: r' = r - a*Hp (kept in h, stored once) ; partial r'.r' ; ARRIVE
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     return nx;
   });
   const double rr_new = grid_wait_sum(partR_new, barrier_words, (unsigned)G * (2u * iter + 2u), red,
-                                      barrier_words + 1);
+                                      barrier_words + 1, spin_limit);
   const float beta = (float)rr_new / (float)rr;
 
   // ---- phase 3: p = r' + b*p (registers only -> store)
@@ -802,6 +805,41 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
 
 int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMax; }
 
+// One-time residency census (MI355X_MICROARCH.md "Residency and cooperative launch": size grid-barrier
+// grids from measured residency, never from the occupancy API alone): launch the real resident kernel on
+// an EMPTY problem — every workgroup only walks the two grid barriers — with a short spin limit.  If all
+// `num_cus()` workgroups are not co-resident (CU masking, a shared GPU, a partitioned device) the barrier
+// times out, the flag is read back and BHG_CG_AUTO never picks the resident variant in this process.
+int bhg_cg_resident_ok(void) {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  const int G = num_cus();
+  if (G <= 0) return cached = 0;
+  void* ws = nullptr;
+  const size_t bytes = ws_bytes(0);
+  if (hipMalloc(&ws, bytes) != hipSuccess) { (void)hipGetLastError(); return cached = 0; }
+  int ok = 0;
+  do {
+    if (hipMemset(ws, 0, bytes) != hipSuccess) break;
+    char* w = static_cast<char*>(ws);
+    double* partR = reinterpret_cast<double*>(w + kWsPartR);
+    PtrTab tab;
+    memset(&tab, 0, sizeof(tab));
+    hipLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, nullptr, tab, (const bhg_chunk*)nullptr, 0,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 1.0f, 0, 0.0f, 0.0f,
+                       (const double*)partR, partR + kMaxBlocks, reinterpret_cast<double*>(w + kWsPartP),
+                       reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal),
+                       1u << 16);
+    if (hipGetLastError() != hipSuccess) break;
+    unsigned words[2] = {0, 1};
+    if (hipMemcpy(words, w + kWsBarrier, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess) break;
+    ok = (words[1] == 0 && words[0] == 2u * (unsigned)G) ? 1 : 0;
+  } while (0);
+  (void)hipFree(ws);
+  (void)hipGetLastError();
+  return cached = ok;
+}
+
 const double* bhg_cg_scalars_dev(const void* ws) {
   return reinterpret_cast<const double*>(static_cast<const char*>(ws) + kWsScal);
 }
@@ -816,7 +854,8 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   BHG_REQUIRE(x && r && p, "state vector is NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int cap = bhg_cg_resident_capacity_chunks();
-  if (variant == BHG_CG_AUTO) variant = (n_chunks <= cap && cap > 0) ? BHG_CG_RESIDENT : BHG_CG_STREAM;
+  if (variant == BHG_CG_AUTO)
+    variant = (n_chunks <= cap && cap > 0 && bhg_cg_resident_ok()) ? BHG_CG_RESIDENT : BHG_CG_STREAM;
   if (variant == BHG_CG_RESIDENT && n_chunks > cap) {
     set_error("bhg_cg_step: %d chunks exceed the resident capacity of %d", n_chunks, cap);
     return BHG_ERR_CAPACITY;
@@ -851,7 +890,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
     hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
                           timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
                           hvp_shift, (const double*)partR_old, partR_new, partP,
-                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal);
+                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal, kSpinLimit);
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;

@@ -115,6 +115,10 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
 /* Largest number of chunks BHG_CG_RESIDENT can hold on the current device (0 when
  * no device is visible). */
 int bhg_cg_resident_capacity_chunks(void);
+/* 1 when a one-time census found all workgroups of the resident kernel co-resident on the current
+ * device (needed by its grid barrier), else 0; BHG_CG_AUTO falls back to BHG_CG_STREAM when 0.
+ * Synchronises the device the first time it is called. */
+int bhg_cg_resident_ok(void);
 /* Device address (inside ws) of 8 doubles: {rr_old, pHp, alpha, rr_new, beta, 0,0,0}
  * written by the most recent bhg_cg_step on that workspace. */
 const double* bhg_cg_scalars_dev(const void* ws);

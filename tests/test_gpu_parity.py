@@ -430,3 +430,60 @@ def test_structured_logreg_path_matches_reference(name, sync, be):
         out = [p.grad for p in prev.trainable_parameters()]
     rel, mx = rel_err(_np(out), golden_list(outputs, case.name, "fp32"))
     assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)
+
+
+# ------------------------------------------------------------------------------------------------
+# robustness / edge cases
+# ------------------------------------------------------------------------------------------------
+def test_resident_census_passes_on_a_dedicated_gpu(be):
+    assert be.lib.bhg_cg_resident_ok() == 1
+    assert be.lib.bhg_cg_resident_capacity_chunks() >= 2453  # the BASELINE cfg-2 vector fits
+
+
+def test_zero_sized_and_odd_inputs(be):
+    """Empty tensors inside a list, non-contiguous and fp16 inputs (converted), 1-element tensors."""
+    gen = torch.Generator().manual_seed(1)
+    sizes = [0, 5, 0, 4097, 1]
+    vec = _rand_list(sizes, gen)
+    lay = be.layout(vec)
+    assert lay.n_chunks == 4 and lay.total == sum(sizes)
+    v, p = lay.new_flat(), lay.new_flat()
+    be.neumann_init(lay, vec, v, p)
+    hv = _rand_list(sizes, gen)
+    hv[3] = hv[3].to(torch.float16)  # converted to fp32 by the backend
+    base = torch.randn(10, generator=gen).to(DEV)
+    hv[1] = base[::2]  # non-contiguous view of 5 elements
+    be.neumann_step(lay, hv, v, p, 0.5)
+    want_v = torch.cat([a - 0.5 * b.float().reshape(-1) for a, b in zip(vec, hv)])
+    got_v = torch.cat([v[s : s + n] for s, n in zip(lay.starts, lay.numels)])
+    assert torch.equal(got_v, want_v)
+    # an entirely empty problem is a no-op
+    empty = [torch.empty(0, device=DEV)]
+    le = be.layout(empty)
+    be.cg_init(le, empty, le.new_flat(), le.new_flat(), le.new_flat())
+    be.cg_step(le, empty, le.new_flat(), le.new_flat(), le.new_flat(), 1.0, 0)
+
+
+@pytest.mark.parametrize("sizes", RAGGED[:5], ids=lambda s: f"T{len(s)}_N{sum(s)}")
+def test_sama_precondition_kernel_vs_aten(sizes, be):
+    gen = torch.Generator().manual_seed(5 + sum(sizes))
+    vec = _rand_list(sizes, gen)
+    g = _rand_list(sizes, gen, scale=0.01)
+    m = [0.1 * a + 0.005 * b for a, b in zip(g, _rand_list(sizes, gen))]
+    u = [0.001 * a * a + 1e-5 * (1.0 + torch.rand(a.shape, generator=gen).to(DEV)) for a in g]
+    lay = be.layout(vec)
+    out = lay.new_flat()
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+    be.sama_adam_precondition(lay, vec, g, m, u, out, b1, b2, eps, lr)
+    got = _flat_concat(lay, out)
+    # betty/hypergradient/utils.py:50-59 with ATen ops on the same device (fp32)
+    want = []
+    for v_, g_, m_, u_ in zip(vec, g, m, u):
+        m_old = (m_ - (1 - b1) * g_) / b1
+        u_old = (u_ - (1 - b2) * g_ * g_) / b2
+        sc = (1 - b1) * b2 * u_old - b1 * (1 - b2) * g_ * m_old
+        sc = sc / (torch.sqrt(u_) + eps) ** 3
+        want.append((v_ * sc * lr).cpu().numpy())
+    want = np.concatenate(want)
+    # same formula and rounding sequence; sqrt/div/pow may differ in the last ulp between ATen and the kernel
+    np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-12)
