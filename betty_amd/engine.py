@@ -23,6 +23,7 @@ class EngineConfig:
     valid_step: int = 500
     strategy: str = "default"  # "default" | "distributed" (DDP over RCCL; one process per GPU)
     backend: str = "nccl"
+    roll_back: bool = False  # warm-start roll-back (engine_dataclass.py; problem.py:417-436)
 
 
 class Engine:
@@ -57,9 +58,15 @@ class Engine:
                 self.device = torch.device("cuda", local)
         if self.device is None:
             self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        world = 1
+        if strategy == "distributed":
+            import torch.distributed as dist
+
+            world = dist.get_world_size()
         for p in self.problems:
             p.device = self.device
             p._strategy = strategy
+            p._world_size = world
             if p.module is not None:
                 p.module.to(self.device)
                 p.fwd = p.module
@@ -94,6 +101,7 @@ class Engine:
         return [list(reversed(t)) + [dst] for t in found]
 
     def _parse_dependency(self):
+        self.leaves = []
         for p in self.problems:
             p.leaf = False
             p.clear_dependencies()
@@ -104,6 +112,8 @@ class Engine:
             for upper in uppers:
                 lower.add_parent(upper)
                 upper.add_child(lower)
+        for p in self.problems:  # configure_roll_back (problem.py:681-689): only problems that have parents
+            p._roll_back = bool(self.config.roll_back and len(p.parents) > 0)
         fed_by_someone = {u for uppers in self.dependencies.get("l2u", {}).values() for u in uppers}
         for p in self.problems:
             if p not in fed_by_someone:

@@ -12,8 +12,11 @@ user keeps using ``betty.Engine`` + ``betty_amd.install()``; this module exists 
 """
 from __future__ import annotations
 
+import copy
+
 import torch
 
+from .backend import get_backend
 from .configs import Config
 from .hypergradient import get_grads
 
@@ -48,6 +51,9 @@ class Problem:
         self._training = True
         self._strategy = "default"
         self.leaf = False
+        self._roll_back = False
+        self._world_size = 1
+        self._snapshot = None
         # forward module seen by other problems (a DDP wrapper under strategy "distributed")
         self.fwd = module
 
@@ -193,11 +199,113 @@ class Problem:
                     self.set_grads(params, grads)
 
     def set_grads(self, params, grads):
-        """problem.py:583-597: out-of-place accumulate, skip None."""
+        """problem.py:583-597: accumulate ``grads`` into ``.grad`` (assign where there is none), skip
+        None.  When many tensors already hold a gradient (e.g. iMAML, M = N in 122 tensors) the T
+        ``param.grad + grad`` launches become ONE multi-tensor accumulate."""
+        acc_dst, acc_src = [], []
         for param, grad in zip(params, grads):
             if grad is None:
                 continue
-            param.grad = grad if getattr(param, "grad", None) is None else param.grad + grad
+            cur = getattr(param, "grad", None)
+            if cur is None:
+                param.grad = grad
+            elif (cur.is_cuda and cur.dtype == torch.float32 and cur.is_contiguous() and cur.shape == grad.shape
+                  and cur.data_ptr() % 16 == 0):
+                acc_dst.append(cur)
+                acc_src.append(grad)
+            else:
+                param.grad = cur + grad
+        if len(acc_dst) >= 4:
+            be = get_backend()
+            be.axpy_multi(be.layout(acc_dst), acc_dst, acc_src, None, 1.0)
+        else:
+            for cur, grad in zip(acc_dst, acc_src):
+                cur.add_(grad)
+
+    def synchronize_params(self, params, all_reduce=False):
+        """problem.py:599-609 with ONE collective instead of one per tensor:
+        gather the tensors into a flat buffer, broadcast from rank 0 (or average over ranks), scatter
+        back.  Matters for T = 1,399 (DARTS supernet) and 201 (RoBERTa) over RCCL."""
+        import torch.distributed as dist
+
+        if self._world_size <= 1 or not dist.is_available() or not dist.is_initialized():
+            return
+        tensors = [p.data for p in params]
+        if not tensors:
+            return
+        be = get_backend()
+        layout = be.layout(tensors)
+        flat = layout.new_flat()
+        be.flatten(layout, tensors, flat, 1.0)
+        if all_reduce:
+            flat.div_(self._world_size)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        else:
+            dist.broadcast(flat, 0)
+        be.scatter(layout, flat, tensors, 1.0)
+
+    # ---- roll-back snapshot (implicit_problem.py:67-78, SURVEY §8f rank 4) ------------------------------------
+    @staticmethod
+    def _is_bulk(v):
+        return torch.is_tensor(v) and v.dtype == torch.float32 and v.numel() > 1 and v.is_contiguous()
+
+    def _snapshot_entries(self):
+        """(kind, owner, key, tensor) of every fp32 tensor that defines the problem's state:
+        parameters, float buffers, optimizer state."""
+        entries = [("param", p, None, p.data) for p in self.module.parameters()]
+        entries += [("buffer", b, None, b) for b in self.module.buffers() if self._is_bulk(b)]
+        if self.optimizer is not None:
+            for p in self.module.parameters():
+                for k, v in self.optimizer.state.get(p, {}).items():
+                    if self._is_bulk(v):
+                        entries.append(("opt", p, k, v))
+        return entries
+
+    def cache_states(self):
+        """Device-side snapshot: one flat HBM buffer written by one multi-tensor kernel instead of
+        ``copy.deepcopy(state_dict())`` of every tensor (the reference does this at every inner-loop
+        start when ``roll_back=True``)."""
+        entries = self._snapshot_entries()
+        tensors = [e[3] for e in entries]
+        be = get_backend()
+        layout = be.layout(tensors)
+        flat = layout.new_flat()
+        be.flatten(layout, tensors, flat, 1.0)
+        small = None
+        if self.optimizer is not None:  # step counters / scalars / non-fp32 entries: tiny, copied as is
+            small = {
+                id(p): {k: copy.deepcopy(v) for k, v in self.optimizer.state.get(p, {}).items() if not self._is_bulk(v)}
+                for p in self.module.parameters()
+            }
+        other_buffers = [b.clone() for b in self.module.buffers() if not self._is_bulk(b)]
+        keys = [(kind, id(owner), key) for kind, owner, key, _ in entries]
+        self._snapshot = (layout, flat, keys, small, other_buffers)
+
+    def recover_states(self, clean=True):
+        layout, flat, keys, small, other_buffers = self._snapshot
+        now = {(kind, id(owner), key): t for kind, owner, key, t in self._snapshot_entries()}
+        missing = [k for k in keys if k not in now]
+        if missing:
+            raise RuntimeError("recover_states: tensors present at cache_states() have disappeared")
+        get_backend().scatter(layout, flat, [now[k] for k in keys], 1.0)
+        if small is not None:
+            saved = set(keys)
+            for p in self.module.parameters():
+                st = self.optimizer.state.get(p)
+                if st is None:
+                    continue
+                # drop state created after the snapshot (e.g. Adam moments born inside the window) ...
+                for k in [k for k, v in st.items() if self._is_bulk(v) and ("opt", id(p), k) not in saved]:
+                    del st[k]
+                # ... and put the small entries back; an empty saved state means "not initialised yet"
+                if not small[id(p)] and not any(kk[0] == "opt" and kk[1] == id(p) for kk in keys):
+                    st.clear()
+                else:
+                    st.update(copy.deepcopy(small[id(p)]))
+        for b, saved_b in zip([b for b in self.module.buffers() if not self._is_bulk(b)], other_buffers):
+            b.copy_(saved_b)
+        if clean:
+            self._snapshot = None
 
     def optimizer_step(self):
         raise NotImplementedError
@@ -217,10 +325,12 @@ class Problem:
             if hasattr(self, "on_inner_loop_start"):
                 self.on_inner_loop_start()
             self._inner_loop_start = False
+            if self._roll_back:  # problem.py:379-381
+                self.cache_states()
         if self._training:
             self._count += 1
         self.one_step_descent()
-        if self.scheduler is not None:
+        if self.scheduler is not None and not self._roll_back:
             self.scheduler.step()
         period = self._config.unroll_steps * self.gas
         if self._training and self._count % period == 0 and self._count > self._config.warmup_steps:
@@ -230,8 +340,25 @@ class Problem:
             self._inner_loop_start = True
         self.ready = [False] * len(self._children)
 
+    def step_after_roll_back(self):
+        """problem.py:417-436: restore the state cached at the inner-loop start, take ONE step on the
+        last batch, and let the parents do the same."""
+        if self.check_ready() and self._training:
+            if self._roll_back:
+                self.recover_states()
+                self.one_step_descent(batch=self.cur_batch)
+                if self.scheduler is not None:
+                    self.scheduler.step()
+                for parent in self._parents:
+                    parent.ready[parent.children.index(self)] = True
+                    parent.step_after_roll_back()
+            self.ready = [False] * len(self._children)
+
     def step(self, global_step=None):
         self.step_normal(global_step=global_step)
+        period = self._config.unroll_steps * self.gas
+        if self._count % period == 0 and self._count > self._config.warmup_steps:
+            self.step_after_roll_back()
 
     def train(self):
         self._training = True

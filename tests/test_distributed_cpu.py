@@ -91,3 +91,54 @@ def test_sync_hop_averages_over_ranks(case_name):
         # DDP's mean of per-rank results; 1e-6 = fp32 all-reduce rounding (darts: finite differences)
         assert err < (2e-4 if "darts" in case_name else 2e-6), (rank, err)
         assert differs > 1e-3, "ranks must see different data for the test to mean anything"
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _cpu_checker_backend import CpuCheckerBackend
+
+        from betty_amd import Config
+        from betty_amd.backend import use_backend
+        from betty_amd.problems import ImplicitProblem
+
+        torch.manual_seed(100 + rank)
+        module = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))  # 4 tensors, ragged sizes
+        prob = ImplicitProblem(name="p", module=module, config=Config())
+        prob._world_size = world
+        mine = torch.cat([p.data.reshape(-1) for p in module.parameters()]).clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        with use_backend(CpuCheckerBackend()):
+            prob.synchronize_params(prob.trainable_parameters(), all_reduce=True)  # problem.py:607-609
+            avg = torch.cat([p.data.reshape(-1) for p in module.parameters()]).clone()
+            with torch.no_grad():
+                for p in module.parameters():
+                    p.add_(float(rank))  # diverge again
+            prob.synchronize_params(prob.trainable_parameters())  # broadcast from rank 0 (problem.py:605-606)
+            bcast = torch.cat([p.data.reshape(-1) for p in module.parameters()]).clone()
+        want_avg = torch.stack(gathered).mean(0)
+        q.put((rank, float((avg - want_avg).abs().max()), float((bcast - want_avg).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_synchronize_params_is_one_flat_collective():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err_avg, err_bcast in sorted(q.get(timeout=5) for _ in range(world)):
+        assert err_avg < 1e-6  # all ranks hold the mean
+        assert err_bcast < 1e-6  # rank 0 added 0.0, so after the broadcast everyone holds the mean again

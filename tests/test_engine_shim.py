@@ -140,3 +140,52 @@ def test_regression_scenario_gpu(algo, structured):
     engine.run()
     loss = outer.training_step(outer.cur_batch)
     assert float(loss.detach()) < 0.48, float(loss.detach())
+
+
+def test_roll_back_snapshot_and_flow():
+    """cache_states/recover_states through the flat snapshot, and the roll-back step flow
+    (problem.py:379-381,417-436): after every unroll window the inner problem sits at
+    (state at loop start) + ONE step on the last batch."""
+    from _cpu_checker_backend import CpuCheckerBackend
+    from betty_amd.backend import use_backend
+
+    with use_backend(CpuCheckerBackend()):
+        # (1) snapshot round trip incl. optimizer state born after the snapshot
+        engine, outer, inner = _scenario(Config(type="darts", unroll_steps=5), torch.device("cpu"))
+        inner.optimizer = torch.optim.Adam(inner.module.parameters(), lr=0.05)
+        w0 = inner.module.w.data.clone()
+        inner.cache_states()
+        loss = inner.training_step(inner.get_batch())
+        loss.backward()
+        inner.optimizer.step()  # creates exp_avg / exp_avg_sq, moves w
+        assert not torch.equal(inner.module.w.data, w0) and len(inner.optimizer.state[inner.module.w]) > 0
+        inner.recover_states()
+        assert torch.equal(inner.module.w.data, w0)
+        assert len(inner.optimizer.state[inner.module.w]) == 0  # back to "not initialised"
+        # with existing state: moments restored bit for bit
+        inner.zero_grad()
+        inner.training_step(inner.get_batch()).backward()
+        inner.optimizer.step()
+        m0 = inner.optimizer.state[inner.module.w]["exp_avg"].clone()
+        inner.cache_states()
+        inner.zero_grad()
+        inner.training_step(inner.get_batch()).backward()
+        inner.optimizer.step()
+        assert not torch.equal(inner.optimizer.state[inner.module.w]["exp_avg"], m0)
+        inner.recover_states()
+        assert torch.equal(inner.optimizer.state[inner.module.w]["exp_avg"], m0)
+
+        # (2) flow with plain SGD: w_end = w_start - lr * grad(w_start)
+        engine, outer, inner = _scenario(Config(type="darts", unroll_steps=5), torch.device("cpu"))
+        engine.config.roll_back = True
+        engine._parse_dependency()
+        assert inner._roll_back and not outer._roll_back
+        w_start = torch.zeros(20)  # on_inner_loop_start zeroes the weights
+        x, y = inner.train_data_loader[0]
+        z = x @ w_start
+        lam = outer.module.w.data.clone()
+        g = x.t() @ (torch.sigmoid(z) - y) / x.shape[0] + lam * w_start
+        engine.config.train_iters = 5
+        engine.run()
+        assert inner.count == 5 and outer.count == 1
+        torch.testing.assert_close(inner.module.w.data, w_start - 0.1 * g, rtol=1e-5, atol=1e-7)

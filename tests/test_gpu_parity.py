@@ -487,3 +487,21 @@ def test_sama_precondition_kernel_vs_aten(sizes, be):
     want = np.concatenate(want)
     # same formula and rounding sequence; sqrt/div/pow may differ in the last ulp between ATen and the kernel
     np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-12)
+
+
+def test_set_grads_multi_tensor_accumulate(be):
+    """Problem.set_grads (problem.py:583-597) on many tensors = one multi-tensor accumulate."""
+    from betty_amd.problems import ImplicitProblem
+
+    module = zoo.MLP([12] + [12] * 5 + [4]).to(DEV)  # 12 tensors
+    prob = ImplicitProblem(name="p", module=module, config=Config())
+    params = prob.trainable_parameters()
+    gen = torch.Generator().manual_seed(0)
+    g1 = [torch.randn(p.shape, generator=gen).to(DEV) for p in params]
+    g2 = [torch.randn(p.shape, generator=gen).to(DEV) for p in params]
+    g2[3] = None  # skipped (allow_unused)
+    prob.set_grads(params, g1)  # assigns
+    prob.set_grads(params, g2)  # accumulates in one launch
+    for p, a, b in zip(params, g1, g2):
+        want = a if b is None else a + b
+        assert torch.equal(p.grad, want)
