@@ -256,16 +256,20 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
 // pair's loads are issued before the first pair's MFMAs and parked in registers.  The accumulators
 // are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
 constexpr int kOK = 128;                      // max K of the outer-product kernel
-constexpr int kOA = kOK * kTM / (256 * 4);    // float4 per thread for a full [128][128] A tile = 16
-constexpr int kOB = kOK * kTN / (256 * 4);    // = 8
+constexpr int kOH = kOK / 2;                  // K rows per pipeline stage (half of a pair)
+constexpr int kOA = kOH * kTM / (256 * 4);    // float4 per thread for one [64][128] A stage = 8
+constexpr int kOB = kOH * kTN / (256 * 4);    // = 4
 constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging tile (16-B aligned rows)
 
+// Each operand pair is cut in two K halves => up to 4 pipeline stages; a stage is ONE round of global
+// loads (all in flight together) parked in registers while the previous stage's MFMAs run from the
+// single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
 __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = a.K;                      // <= kOK
-  const int Kp = (K + 1) & ~1;
-  float* sA = smem;                       // [Kp][128]
-  float* sB = smem + Kp * kTM;            // [Kp][64]
+  const int Kh = (((K + 1) / 2) + 1) & ~1;  // rows per stage, even
+  float* sA = smem;                       // [Kh][128]
+  float* sB = smem + Kh * kTM;            // [Kh][64]
   const int n0 = blockIdx.x * kTN;
   const int m0 = blockIdx.y * kTM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,14 +284,18 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   float4 ra[kOA], rb[kOB];
-  auto gload = [&](const GemmPair& pr) {
+  // stage s: pair s/2, K rows [ (s&1)*Kh, min(K, (s&1)*Kh + Kh) )
+  auto gload = [&](int stage) {
+    const GemmPair& pr = a.pr[stage >> 1];
+    const int kb = (stage & 1) * Kh;
     const bool fa = m0 + kTM <= a.M && (pr.lda & 3) == 0;  // workgroup-uniform
     const bool fb = n0 + kTN <= a.N && (pr.ldb & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < kOA; ++i) {   // A tile: 32 float4 per k-row, 8 k-rows per pass
-      const int k = (t >> 5) + 8 * i;
+    for (int i = 0; i < kOA; ++i) {   // A stage: 32 float4 per k-row, 8 k-rows per pass
+      const int kl = (t >> 5) + 8 * i;
+      const int k = kb + kl;
       const int r = m0 + 4 * (t & 31);
-      const bool kok = k < K;
+      const bool kok = kl < Kh && k < K;
       const int64_t base = (int64_t)(kok ? k : 0) * pr.lda + r;
       if (fa) {
         const float4 v = *reinterpret_cast<const float4*>(pr.A + base);
@@ -300,10 +308,11 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < kOB; ++i) {   // B tile: 16 float4 per k-row, 16 k-rows per pass
-      const int k = (t >> 4) + 16 * i;
+    for (int i = 0; i < kOB; ++i) {   // B stage: 16 float4 per k-row, 16 k-rows per pass
+      const int kl = (t >> 4) + 16 * i;
+      const int k = kb + kl;
       const int r = n0 + 4 * (t & 15);
-      const bool kok = k < K;
+      const bool kok = kl < Kh && k < K;
       const int64_t base = (int64_t)(kok ? k : 0) * pr.ldb + r;
       if (fb) {
         const float4 v = *reinterpret_cast<const float4*>(pr.B + base);
@@ -320,16 +329,18 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < kOA; ++i) {
       const int k = (t >> 5) + 8 * i;
-      if (k < Kp) *reinterpret_cast<float4*>(sA + k * kTM + 4 * (t & 31)) = ra[i];
+      if (k < Kh) *reinterpret_cast<float4*>(sA + k * kTM + 4 * (t & 31)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < kOB; ++i) {
       const int k = (t >> 4) + 16 * i;
-      if (k < Kp) *reinterpret_cast<float4*>(sB + k * kTN + 4 * (t & 15)) = rb[i];
+      if (k < Kh) *reinterpret_cast<float4*>(sB + k * kTN + 4 * (t & 15)) = rb[i];
     }
   };
-  auto compute = [&]() {
-    const int nkp = Kp / 2;
+  auto compute = [&](int stage) {
+    const int kb = (stage & 1) * Kh;
+    const int kvalid = min(Kh, K - kb);           // rows of this stage that carry data (rest is zero)
+    const int nkp = kvalid > 0 ? (kvalid + 1) / 2 : 0;
     int kp = 0;
     for (; kp + 4 <= nkp; kp += 4) {  // 12 LDS reads in flight, then 8 MFMAs
       float b[4], a0[4], a1[4];
@@ -356,16 +367,15 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     }
   };
 
-  gload(a.pr[0]);
+  const int nstages = 2 * a.pairs;
+  gload(0);
   lstore();
-  if (a.pairs > 1) gload(a.pr[1]);  // in flight during the first pair's MFMAs
-  __syncthreads();
-  compute();
-  if (a.pairs > 1) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    compute();
+  for (int stage = 0; stage < nstages; ++stage) {
+    if (stage + 1 < nstages) gload(stage + 1);  // in flight during this stage's MFMAs
+    __syncthreads();                            // this stage's tile is complete in LDS
+    compute(stage);
+    __syncthreads();                            // everyone is done reading it
+    if (stage + 1 < nstages) lstore();
   }
   __syncthreads();  // LDS is reused as the C staging tile below
 
@@ -538,20 +548,26 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   }
   const float* rhb = Rh ? Rh + (int64_t)b * K : nullptr;
   const float* hb = h + (int64_t)b * K;
-  // every wave owns up to 8 classes (w, w+4, ...); all their partial dots advance together so that
-  // 2 + 2*8 independent loads are in flight per k (the kernel is pure latency otherwise)
+  // every wave owns up to 8 classes (w, w+4, ...); lanes take float4 slices of K (K % 4 == 0), so a
+  // 384-wide feature row is covered in two trips with 2 + 2*classes independent 16-B loads each
   float acc[kSmallC / 4];
 #pragma unroll
   for (int j = 0; j < kSmallC / 4; ++j) acc[j] = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float hv = hb[k];
-    const float rv = rhb ? rhb[k] : 0.f;
+  for (int k = 4 * lane; k < K; k += 256) {
+    const float4 hv = *reinterpret_cast<const float4*>(hb + k);
+    const float4 rv = rhb ? *reinterpret_cast<const float4*>(rhb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < kSmallC / 4; ++j) {
       const int c = wave + 4 * j;
       if (c < C) {
-        acc[j] = fmaf(hv, V[(int64_t)c * K + k], acc[j]);
-        if (rhb) acc[j] = fmaf(rv, W[(int64_t)c * K + k], acc[j]);
+        const float4 vv = *reinterpret_cast<const float4*>(V + (int64_t)c * K + k);
+        float t = acc[j];
+        t = fmaf(hv.x, vv.x, t); t = fmaf(hv.y, vv.y, t); t = fmaf(hv.z, vv.z, t); t = fmaf(hv.w, vv.w, t);
+        if (rhb) {
+          const float4 ww = *reinterpret_cast<const float4*>(W + (int64_t)c * K + k);
+          t = fmaf(rv.x, ww.x, t); t = fmaf(rv.y, ww.y, t); t = fmaf(rv.z, ww.z, t); t = fmaf(rv.w, ww.w, t);
+        }
+        acc[j] = t;
       }
     }
   }
@@ -765,8 +781,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     a.splits = 1;
     a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
     a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
-    const int Kp = (B + 1) & ~1;
-    size_t lds = (size_t)Kp * (kTM + kTN) * sizeof(float);
+    const int Kh = (((B + 1) / 2) + 1) & ~1;  // K rows per pipeline stage (see k_outer)
+    size_t lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
     const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
     if (lds < lds_c) lds = lds_c;
     dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
