@@ -137,19 +137,21 @@ __device__ __forceinline__ float frag(const float* __restrict__ lds, int row, in
 
 // C[M][N] (+)= sum over pairs  A_pair (M x K) * B_pair (K x N), operands in layouts LA / LB.
 // grid = (ceil(N/64), ceil(M/128), splits), block = 256 (4 waves: 2 along M x 2 along N).
-template <int LA, int LB>
+template <int LA, int LB, int TN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  static_assert(TN == 64 || TN == 32, "tile width");
+  constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
   constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
-  constexpr int B_ELEMS = (LB == LAYOUT_KC) ? kTN * kPadK : kTK * kTN;
+  constexpr int B_ELEMS = (LB == LAYOUT_KC) ? TN * kPadK : kTK * TN;
   __shared__ __attribute__((aligned(16))) float sA[2][A_ELEMS];
   __shared__ __attribute__((aligned(16))) float sB[2][B_ELEMS];
 
-  const int n0 = blockIdx.x * kTN;
+  const int n0 = blockIdx.x * TN;
   const int m0 = blockIdx.y * kTM;
   const int split = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64;  // wave's row offset inside the tile
-  const int wn = (wave & 1) * 32;   // wave's col offset
+  const int wm = TN == 64 ? (wave >> 1) * 64 : wave * 32;  // wave's row offset inside the tile
+  const int wn = TN == 64 ? (wave & 1) * 32 : 0;           // wave's col offset
   const int li = lane & 31, lk = lane >> 5;
 
   // K range of this split (multiples of kTK except possibly the end)
@@ -160,30 +162,30 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int nsteps_pair = kbeg < kend ? (kend - kbeg + kTK - 1) / kTK : 0;
   const int nsteps = nsteps_pair * a.pairs;
 
-  f32x16 acc[2];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   // Two register stages: the global loads of step s+2 are issued before the MFMAs of step s, so every
   // load has two compute phases (plus the other resident workgroups) to land.
-  float4 ra0[kTM / 32], rb0[kTN / 32], ra1[kTM / 32], rb1[kTN / 32];
-  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[kTN / 32]) {
+  float4 ra0[kTM / 32], rb0[TN / 32], ra1[kTM / 32], rb1[TN / 32];
+  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32]) {
     const int pi = step / nsteps_pair;
     const int k0 = kbeg + (step - pi * nsteps_pair) * kTK;
     const GemmPair& pr = a.pr[pi];
     const bool kfull = k0 + kTK <= kend;  // workgroup-uniform
     const bool fa = kfull && m0 + kTM <= a.M && (pr.lda & 3) == 0;
-    const bool fb = kfull && n0 + kTN <= a.N && (pr.ldb & 3) == 0;
+    const bool fb = kfull && n0 + TN <= a.N && (pr.ldb & 3) == 0;
     if (LA == LAYOUT_KC) load_kc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
     else load_rc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
-    if (LB == LAYOUT_KC) load_kc<kTN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
-    else load_rc<kTN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
+    if (LB == LAYOUT_KC) load_kc<TN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
+    else load_rc<TN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
   };
-  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], const float4 (&rb)[kTN / 32]) {
+  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], const float4 (&rb)[TN / 32]) {
     if (LA == LAYOUT_KC) store_kc<kTM>(sA[buf], ra); else store_rc<kTM>(sA[buf], ra);
-    if (LB == LAYOUT_KC) store_kc<kTN>(sB[buf], rb); else store_rc<kTN>(sB[buf], rb);
+    if (LB == LAYOUT_KC) store_kc<TN>(sB[buf], rb); else store_rc<TN>(sB[buf], rb);
   };
   auto compute = [&](int step) {
     const float* A = sA[step & 1];
@@ -194,26 +196,30 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
 #pragma unroll
       for (int kp = 0; kp < kTK / 2; ++kp) {
         const int k = 2 * kp + lk;
-        const float b = frag<LB, kTN>(B, wn + li, k);
+        const float b = frag<LB, TN>(B, wn + li, k);
         const float a0 = frag<LA, kTM>(A, wm + li, k);
-        const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        if (NACC == 2) {
+          const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
+          acc[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[NACC - 1], 0, 0, 0);
+        }
       }
     } else {
       for (int kp = 0; kp < (klen + 1) / 2; ++kp) {
         const int k = 2 * kp + lk;
-        const float b = frag<LB, kTN>(B, wn + li, k);
+        const float b = frag<LB, TN>(B, wn + li, k);
         const float a0 = frag<LA, kTM>(A, wm + li, k);
-        const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        if (NACC == 2) {
+          const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
+          acc[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[NACC - 1], 0, 0, 0);
+        }
       }
     }
   };
   // body for one step whose NEXT step's data sits in (ran, rbn) and whose step+2 loads go to (raf, rbf)
-  auto body = [&](int step, float4 (&raf)[kTM / 32], float4 (&rbf)[kTN / 32], const float4 (&ran)[kTM / 32],
-                  const float4 (&rbn)[kTN / 32]) {
+  auto body = [&](int step, float4 (&raf)[kTM / 32], float4 (&rbf)[TN / 32], const float4 (&ran)[kTM / 32],
+                  const float4 (&rbn)[TN / 32]) {
     if (step + 2 < nsteps) gload(step + 2, raf, rbf);
     compute(step);
     if (step + 1 < nsteps) lstore((step + 1) & 1, ran, rbn);
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int col = n0 + wn + li;
   if (col < a.N) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NACC; ++t) {
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
         const int row = m0 + wm + 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
@@ -658,9 +664,14 @@ __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd
 }
 
 template <int LA, int LB>
-void launch_gemm(const GemmArgs& a, hipStream_t st) {
-  dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, a.splits);
-  hipLaunchKernelGGL((k_gemm<LA, LB>), grid, dim3(256), 0, st, a);
+void launch_gemm(const GemmArgs& a, int tn, hipStream_t st) {
+  dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
+  if (tn == 64) hipLaunchKernelGGL((k_gemm<LA, LB, 64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_gemm<LA, LB, 32>), grid, dim3(256), 0, st, a);
+}
+inline int skinny_tile_n() {
+  static const int tn = getenv("BHG_MLP_TN") ? atoi(getenv("BHG_MLP_TN")) : 32;  // 32 measured +2 % over 64
+  return tn == 64 ? 64 : 32;
 }
 
 void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
@@ -701,9 +712,9 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
   for (int l = 0; l < m->L; ++l) {
     // R-forward of layer l (N = dims[l+1], K = dims[l]) and R-backward into layer l (N = dims[l], K = dims[l+1])
     const int Nf = m->dims[l + 1], Kf = m->dims[l];
-    const int sf = pick_splits((Nf + kTN - 1) / kTN, Kf, 2);
+    const int sf = pick_splits((Nf + skinny_tile_n() - 1) / skinny_tile_n(), Kf, 2);
     mx = mx > (size_t)sf * m->Bp * Nf ? mx : (size_t)sf * m->Bp * Nf;
-    const int sb = pick_splits((Kf + kTN - 1) / kTN, Nf, 2);
+    const int sb = pick_splits((Kf + skinny_tile_n() - 1) / skinny_tile_n(), Nf, 2);
     mx = mx > (size_t)sb * m->Bp * Kf ? mx : (size_t)sb * m->Bp * Kf;
   }
   return mx;
@@ -740,9 +751,10 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     a.pairs = 1;
     if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
     a.M = Bp; a.N = N; a.K = K;
-    a.splits = pick_splits((N + kTN - 1) / kTN, K, a.pairs);
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
-    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, st);
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
     const int slab = Bp * N;
     if (l + 1 < L) {
       launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
@@ -810,9 +822,10 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
     a.pairs = 2;
     a.M = Bp; a.N = N; a.K = K;
-    a.splits = pick_splits((N + kTN - 1) / kTN, K, 2);
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, 2);
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
-    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, st);
+    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
     const int slab = Bp * N;
     launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
   }

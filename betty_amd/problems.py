@@ -202,25 +202,33 @@ class Problem:
         """problem.py:583-597: accumulate ``grads`` into ``.grad`` (assign where there is none), skip
         None.  When many tensors already hold a gradient (e.g. iMAML, M = N in 122 tensors) the T
         ``param.grad + grad`` launches become ONE multi-tensor accumulate."""
-        acc_dst, acc_src = [], []
+        acc_par, acc_cur, acc_new = [], [], []
         for param, grad in zip(params, grads):
             if grad is None:
                 continue
             cur = getattr(param, "grad", None)
             if cur is None:
                 param.grad = grad
-            elif (cur.is_cuda and cur.dtype == torch.float32 and cur.is_contiguous() and cur.shape == grad.shape
-                  and cur.data_ptr() % 16 == 0):
-                acc_dst.append(cur)
-                acc_src.append(grad)
+            elif cur.is_cuda and cur.dtype == torch.float32 and grad.dtype == torch.float32 and cur.shape == grad.shape:
+                acc_par.append(param)
+                acc_cur.append(cur)
+                acc_new.append(grad)
             else:
                 param.grad = cur + grad
-        if len(acc_dst) >= 4:
+        if len(acc_par) >= 4:
+            # out-of-place like the reference (`param.grad = param.grad + grad`: nobody's tensor is mutated),
+            # but as two multi-tensor launches into one fresh flat buffer instead of T `add` launches
             be = get_backend()
-            be.axpy_multi(be.layout(acc_dst), acc_dst, acc_src, None, 1.0)
+            layout = be.layout(acc_cur)
+            flat = layout.new_flat()
+            be.flatten(layout, acc_cur, flat, 1.0)
+            views = layout.views(flat, acc_cur)
+            be.axpy_multi(layout, views, acc_new, None, 1.0)
+            for param, v in zip(acc_par, views):
+                param.grad = v
         else:
-            for cur, grad in zip(acc_dst, acc_src):
-                cur.add_(grad)
+            for param, cur, grad in zip(acc_par, acc_cur, acc_new):
+                param.grad = cur + grad
 
     def synchronize_params(self, params, all_reduce=False):
         """problem.py:599-609 with ONE collective instead of one per tensor:

@@ -500,8 +500,10 @@ def test_set_grads_multi_tensor_accumulate(be):
     g1 = [torch.randn(p.shape, generator=gen).to(DEV) for p in params]
     g2 = [torch.randn(p.shape, generator=gen).to(DEV) for p in params]
     g2[3] = None  # skipped (allow_unused)
-    prob.set_grads(params, g1)  # assigns
-    prob.set_grads(params, g2)  # accumulates in one launch
-    for p, a, b in zip(params, g1, g2):
+    g1_copy = [t.clone() for t in g1]
+    prob.set_grads(params, g1)  # assigns (p.grad IS g1[i], as in the reference)
+    prob.set_grads(params, g2)  # accumulates: two multi-tensor launches, out of place
+    for p, a, a0, b in zip(params, g1, g1_copy, g2):
+        assert torch.equal(a, a0), "set_grads must not mutate the caller's tensors (problem.py:594 is out of place)"
         want = a if b is None else a + b
         assert torch.equal(p.grad, want)
