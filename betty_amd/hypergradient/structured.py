@@ -55,9 +55,10 @@ class WeightedCEMLP:
     The HVP callable returns the Hessian WITHOUT its ``2*ridge*I`` part; ``hvp_shift = 2*ridge`` tells
     cg/neumann to add ``hvp_shift * direction`` inside the fused recurrence kernel.
 
-    ``impl="hip"`` (default on a GPU) runs the GEMM chain on the MFMA kernels of libbhg;
-    ``impl="torch"`` evaluates the same formulas with ATen ops (used by the tests to validate the
-    math against autograd and to cross-check the kernels).
+    ``impl="hip"`` (the default, and the only path the package ever takes on its own) runs the GEMM
+    chain on the MFMA kernels of libbhg and raises on CPU tensors; ``impl="torch"`` must be requested
+    explicitly and evaluates the same formulas with ATen ops — it exists for the tests (math vs
+    autograd, cross-check of the kernels) and for ``bench.py --hvp analytic-aten``.
     """
 
     def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
@@ -81,7 +82,7 @@ class WeightedCEMLP:
     # ---------------------------------------------------------------------------------------------
     def prepare(self):
         x, y = self.batch if self.batch is not None else self.curr.cur_batch
-        impl = self.impl or ("hip" if x.is_cuda else "torch")
+        impl = self.impl or "hip"  # the product path; it raises on CPU tensors (no CPU fallback)
         if impl == "hip":
             from ._mlp_hip import HipMLPState  # noqa: PLC0415
 

@@ -153,3 +153,15 @@ def test_analytic_mlp_hvp_equals_autograd_hvp_fp64():
     for a, b in zip(mixed, want_m):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-14)
 
+
+def test_structured_provider_has_no_silent_cpu_path():
+    """Default impl is the HIP one: CPU tensors raise instead of falling back to ATen."""
+    from betty_amd import NativeLibraryError
+
+    case = zoo.CASE_BY_NAME["reweight_cg20"]
+    inputs, _ = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config)
+    zoo.attach_mlp_structure(curr, case.family, impl=None)
+    with pytest.raises(NativeLibraryError, match="no CPU fallback"):
+        curr.hypergradient_structure(prev).prepare()
+
