@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ part, int splits, int slab,
                                                      const float* __restrict__ bias, const float* __restrict__ mask,
-                                                     float* __restrict__ out, int rows, int N, int B) {
+                                                     float* __restrict__ out, int rows, int N, int B,
+                                                     float* __restrict__ relu_mask_out) {
+  // relu_mask_out != NULL: forward-pass mode — out = relu(sum + bias), relu_mask_out = (sum + bias > 0)
   const int64_t total = (int64_t)rows * N / VEC;
   const int nv = N / VEC;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -452,6 +454,16 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
         if (bias) v[j] += bias[n + j];
         if (mask) v[j] *= mask[i * VEC + j];
       }
+    }
+    if (relu_mask_out) {
+      float mk[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        mk[j] = v[j] > 0.f ? 1.f : 0.f;
+        v[j] = v[j] > 0.f ? v[j] : 0.f;
+      }
+      if (VEC == 4) *reinterpret_cast<float4*>(relu_mask_out + i * VEC) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+      else relu_mask_out[i] = mk[0];
     }
     if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
     else out[i] = v[0];
@@ -537,6 +549,7 @@ __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
 // A 128x64-tile MFMA kernel is the wrong tool for the classifier head (10 x 384 at the benchmark): three
 // small kernels replace two split-K GEMM+reduce pairs and one outer-product launch.
 constexpr int kSmallC = 32;
+enum : int { HEAD_JVP = 0, HEAD_COEFF = 1, HEAD_LOGITS = 2 };
 
 // Rz[b][c] = Rh[b].W[c] + h[b].V[c] + cb[c], then Rd_L[b] = sd[b] * (p*Rz - p (p.Rz)).
 // One workgroup per sample row; wave w handles classes w, w+4, ...; lanes stride K (coalesced rows).
@@ -544,12 +557,17 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       const float* __restrict__ W, const float* __restrict__ V,
                                                       const float* __restrict__ cb, const float* __restrict__ prob,
                                                       const float* __restrict__ sd, float* __restrict__ rd, int K,
-                                                      int C, int B) {
+                                                      int C, int B, int mode, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ aux) {
+  // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
+  // mode HEAD_COEFF:  aux[b]   = (p - onehot(y)).Rz / B                         (mixed-derivative coefficient)
+  // mode HEAD_LOGITS: rd[b][:] = softmax(z), aux[b] = -log softmax(z)[y]        (forward pass; V = W, cb = bias)
   __shared__ float rz[kSmallC];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (b >= B) {
-    if (threadIdx.x < C) rd[(int64_t)b * C + threadIdx.x] = 0.f;
+    if (mode != HEAD_COEFF && threadIdx.x < C) rd[(int64_t)b * C + threadIdx.x] = 0.f;
+    if (mode != HEAD_JVP && threadIdx.x == 0) aux[b] = 0.f;
     return;
   }
   const float* rhb = Rh ? Rh + (int64_t)b * K : nullptr;
@@ -586,11 +604,30 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
     if (lane == 0 && c < C) rz[c] = a + cb[c];
   }
   __syncthreads();
-  if (threadIdx.x < C) {
-    float dot = 0.f;
-    for (int c = 0; c < C; ++c) dot += prob[(int64_t)b * C + c] * rz[c];
-    const float p = prob[(int64_t)b * C + threadIdx.x];
-    rd[(int64_t)b * C + threadIdx.x] = sd[b] * (p * rz[threadIdx.x] - p * dot);
+  if (mode == HEAD_JVP) {
+    if (threadIdx.x < C) {
+      float dot = 0.f;
+      for (int c = 0; c < C; ++c) dot += prob[(int64_t)b * C + c] * rz[c];
+      const float p = prob[(int64_t)b * C + threadIdx.x];
+      rd[(int64_t)b * C + threadIdx.x] = sd[b] * (p * rz[threadIdx.x] - p * dot);
+    }
+  } else if (mode == HEAD_COEFF) {
+    if (threadIdx.x == 0) {
+      const int y = (int)labels[b];
+      float acc2 = 0.f;
+      for (int c = 0; c < C; ++c) acc2 += (prob[(int64_t)b * C + c] - (c == y ? 1.f : 0.f)) * rz[c];
+      aux[b] = acc2 / (float)B;
+    }
+  } else {  // HEAD_LOGITS: numerically stable log-softmax, one thread per row (C <= 32)
+    if (threadIdx.x == 0) {
+      float mx = rz[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, rz[c]);
+      float sum = 0.f;
+      for (int c = 0; c < C; ++c) sum += expf(rz[c] - mx);
+      const float lse = mx + logf(sum);
+      for (int c = 0; c < C; ++c) rd[(int64_t)b * C + c] = expf(rz[c] - lse);
+      aux[b] = lse - rz[(int)labels[b]];
+    }
   }
 }
 
@@ -606,11 +643,14 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b < B) {
       for (int c = 0; c < C; ++c) {
-        const float d = delta[(int64_t)b * C + c], r = rd[(int64_t)b * C + c];
-        const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * N + n);
+        const float r = rd[(int64_t)b * C + c];
         const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)c * N + n);
-        acc.x += d * v.x + r * w.x; acc.y += d * v.y + r * w.y;
-        acc.z += d * v.z + r * w.z; acc.w += d * v.w + r * w.w;
+        acc.x += r * w.x; acc.y += r * w.y; acc.z += r * w.z; acc.w += r * w.w;
+        if (V) {  // second operand pair (absent in the plain backward pass of bhg_mlp_backward)
+          const float d = delta[(int64_t)b * C + c];
+          const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * N + n);
+          acc.x += d * v.x; acc.y += d * v.y; acc.z += d * v.z; acc.w += d * v.w;
+        }
       }
       const float4 m = *reinterpret_cast<const float4*>(mask + (int64_t)b * N + n);
       acc.x *= m.x; acc.y *= m.y; acc.z *= m.z; acc.w *= m.w;
@@ -663,6 +703,16 @@ __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd
   }
 }
 
+// delta_L[b][c] = sd[b] * (prob[b][c] - onehot(y_b)[c]); rows >= B zero.
+__global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ prob, const float* __restrict__ sd,
+                                                   const int64_t* __restrict__ labels, float* __restrict__ delta,
+                                                   int rows, int C, int B) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int b = i / C, c = i - b * C;
+  delta[i] = b < B ? sd[b] * (prob[i] - ((int)labels[b] == c ? 1.f : 0.f)) : 0.f;
+}
+
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a, int tn, hipStream_t st) {
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
@@ -675,15 +725,17 @@ inline int skinny_tile_n() {
 }
 
 void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
-                        const float* mask, float* out, int rows, int N, int B) {
+                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr) {
   if ((N & 3) == 0) {
     int blocks = (slab / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B);
+    hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
+                       relu_mask_out);
   } else {
     int blocks = (slab + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B);
+    hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
+                       relu_mask_out);
   }
 }
 
@@ -743,7 +795,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
     if (head && l == L - 1) {
       hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
-                         m->h[l], m->W[l], V, c, m->prob, m->sd, m->Rd[l], K, N, B);
+                         m->h[l], m->W[l], V, c, m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP,
+                         (const int64_t*)nullptr, (float*)nullptr);
       continue;
     }
     GemmArgs a{};
@@ -850,6 +903,117 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
   }
   if (timed) BHG_HIP_CHECK(hipEventRecord(t_b, st));
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// ---- once-per-step passes (replace ~80 ATen dispatches around the K loop with 3 native calls) ----------------
+static int check_head_problem(const bhg_mlp* m) {
+  BHG_REQUIRE(m, "NULL descriptor");
+  BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
+  BHG_REQUIRE(m->Bp == kTM && m->B >= 1 && m->B <= m->Bp, "batch must fit one 128-row tile");
+  BHG_REQUIRE(m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0,
+              "native prepare needs a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
+  BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
+  return BHG_OK;
+}
+
+int bhg_mlp_supports_native_prepare(const bhg_mlp* m) {
+  return m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp == kTM && m->dims[m->L] <= kSmallC &&
+         (m->dims[m->L - 1] & 3) == 0;
+}
+
+// Forward pass: h[l+1] = relu(h[l] W_l^T + b_l), mask[l]; prob = softmax(z); ce[b] = -log prob[b][y_b].
+// h[0] (the padded input batch) must be filled by the caller; h[1..], mask[], prob and ce are written.
+int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* stream) {
+  if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(bias && labels && ce, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  for (int l = 0; l < L; ++l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const float* b = static_cast<const float*>(bias[l]);
+    if (l == L - 1) {
+      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, (const float*)nullptr, (const float*)m->h[l],
+                         (const float*)nullptr, m->W[l], b, (const float*)nullptr, (const float*)nullptr,
+                         const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce);
+      break;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->h[l], m->W[l], K, K};
+    a.pairs = 1;
+    a.M = Bp; a.N = N; a.K = K;
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, 1);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    launch_reduce_mask(st, m->partial, a.splits, Bp * N, b, nullptr, const_cast<float*>(m->h[l + 1]), Bp, N, B,
+                       const_cast<float*>(m->mask[l]));
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// Backward pass for the deltas (needs sd = sample weight / B from the caller):
+// delta[L-1] = sd * (prob - onehot(y)); delta[l-1] = mask[l-1] * (delta[l] W_l).
+int bhg_mlp_backward(const bhg_mlp* m, const int64_t* labels, void* stream) {
+  if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(labels, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  const int C = m->dims[L];
+  hipLaunchKernelGGL(k_delta_top, dim3((Bp * C + 255) / 256), dim3(256), 0, st, m->prob, m->sd, labels,
+                     const_cast<float*>(m->delta[L - 1]), Bp, C, B);
+  for (int l = L - 1; l >= 1; --l) {
+    const int K = m->dims[l + 1], N = m->dims[l];
+    if (l == L - 1) {
+      const int blocks = (Bp * (N / 4) + 255) / 256;
+      hipLaunchKernelGGL(k_head_backward, dim3(blocks), dim3(256), 0, st, (const float*)nullptr, m->delta[l], m->W[l],
+                         (const float*)nullptr, m->mask[l - 1], const_cast<float*>(m->delta[l - 1]), N, K, B, Bp);
+      continue;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->delta[l], m->W[l], K, N};
+    a.pairs = 1;
+    a.M = Bp; a.N = N; a.K = K;
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, 1);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
+    launch_reduce_mask(st, m->partial, a.splits, Bp * N, nullptr, m->mask[l - 1], const_cast<float*>(m->delta[l - 1]), Bp,
+                       N, B);
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// Mixed-derivative coefficient: coeff[b] = (prob[b] - onehot(y_b)) . Rz_b(direction) / B — one R-forward.
+int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t* labels, float* coeff, void* stream) {
+  if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(dir && labels && coeff, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  for (int l = 0; l < L; ++l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    const float* c = static_cast<const float*>(dir[2 * l + 1]);
+    if (l == L - 1) {
+      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
+                         (const float*)m->h[l], m->W[l], V, c, m->prob, (const float*)nullptr, (float*)nullptr, K, N, B,
+                         HEAD_COEFF, labels, coeff);
+      break;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->h[l], V, K, K};
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }
+    a.M = Bp; a.N = N; a.K = K;
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    launch_reduce_mask(st, m->partial, a.splits, Bp * N, c, m->mask[l], m->Rh[l], Bp, N, B);
+  }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

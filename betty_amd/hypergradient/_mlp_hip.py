@@ -1,8 +1,16 @@
-"""HIP (MFMA) evaluation of the analytic MLP HVP: per-step cache + ``bhg_mlp_hvp`` calls.
+"""HIP (MFMA) evaluation of the analytic MLP HVP: per-step cache + ``bhg_mlp_*`` calls.
 
-The once-per-step quantities (forward activations, ReLU masks, softmax, back-propagated deltas)
-are 1/K of the work and are computed with ATen ops into 128-row padded buffers; the K HVPs of a
-hypergradient step run on libbhg's fp32 matrix-core kernels (csrc/bhg_mlp.hip).
+Per hypergradient step:
+  1. ``bhg_mlp_forward``   activations, ReLU masks, softmax, per-sample CE           (native, ~8 launches)
+  2. the sample weights ``s = weight_fn(ce)`` come from the UPPER problem's module      (PyTorch: it is
+     an arbitrary user module whose graph the final mixed VJP needs)
+  3. ``bhg_mlp_backward``  back-propagated deltas                                      (native)
+  4. K x ``bhg_mlp_hvp``   the Hessian-vector products on the fp32 matrix cores        (native)
+  5. ``bhg_mlp_mixed_coeff`` one R-forward for the mixed second derivative, then a backward through
+     ``s``'s graph                                                                    (native + PyTorch)
+All [Bp = 128, d] activation buffers are allocated once per (shapes, device) and reused across steps.
+Networks whose last layer is wider than 32 outputs fall back to ATen for steps 1, 3 and 5 only (the
+K HVPs — the hot part — always run on the HIP kernels).
 """
 from __future__ import annotations
 
@@ -15,69 +23,31 @@ from .. import _native
 
 BP = 128  # batch rows of every activation buffer (one 128-row MFMA workgroup tile)
 
-
-def _pad_rows(t: torch.Tensor) -> torch.Tensor:
-    out = torch.zeros((BP,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
-    out[: t.shape[0]] = t
-    return out
+_BUFFERS = {}
 
 
-class HipMLPState:
-    def __init__(self, spec, x, y):
-        if not x.is_cuda:
-            raise _native.NativeLibraryError("WeightedCEMLP(impl='hip') needs CUDA/HIP tensors; there is no CPU fallback")
-        self.lib = _native.load()
-        self.spec = spec
-        Ws = [lin.weight.detach() for lin in spec.layers]
-        bs = [lin.bias.detach() for lin in spec.layers]
-        L, B = len(Ws), x.shape[0]
-        if B > BP:
-            raise ValueError(f"WeightedCEMLP(impl='hip') supports batches up to {BP} rows, got {B}")
-        if L > _native.BHG_MLP_MAX_LAYERS:
-            raise ValueError("too many layers")
-        for W in Ws:
-            if W.dtype != torch.float32 or not W.is_contiguous():
-                raise ValueError("weights must be contiguous fp32")
-        # ---- once per step (ATen) -------------------------------------------------------------------
-        hs, masks = [x.detach().to(torch.float32)], []
-        h = hs[0]
-        for l in range(L):
-            a = torch.addmm(bs[l], h, Ws[l].t())
-            if l + 1 < L:
-                m = (a > 0).to(torch.float32)
-                h = a * m
-                masks.append(m)
-                hs.append(h)
-            else:
-                z = a
-        logp = F.log_softmax(z, dim=1)
-        p = logp.exp()
-        ce = -logp.gather(1, y.reshape(-1, 1)).reshape(-1)
-        self.sample_weight = spec.weight_fn(ce.detach())  # graph to prev's parameters
-        sd = self.sample_weight.detach().reshape(-1).to(torch.float32) / B
-        self.err = p - F.one_hot(y, z.shape[1]).to(torch.float32)
-        deltas = [None] * L
-        deltas[L - 1] = sd[:, None] * self.err
-        for l in range(L - 1, 0, -1):
-            deltas[l - 1] = masks[l - 1] * (deltas[l] @ Ws[l])
-        self.B, self.L = B, L
-        self.Ws, self.hs_raw, self.masks_raw = Ws, hs, masks
-        # ---- padded device buffers + descriptor ---------------------------------------------------------
-        dev = x.device
-        self.h = [_pad_rows(t) for t in hs]
-        self.mask = [_pad_rows(t) for t in masks]
-        self.delta = [_pad_rows(t) for t in deltas]
-        self.prob = _pad_rows(p)
-        self.sd = _pad_rows(sd)
-        dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
-        self.Rh = [torch.zeros(BP, dims[l + 1], device=dev) for l in range(L - 1)]
-        self.Rd = [torch.zeros(BP, dims[l + 1], device=dev) for l in range(L)]
+class _Buffers:
+    """Device buffers + descriptor for one (dims, device); contents are rewritten every step."""
+
+    def __init__(self, dims, device, lib):
+        L = len(dims) - 1
+        self.dims, self.L = dims, L
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        self.h = [z(BP, dims[l]) for l in range(L)]
+        self.mask = [z(BP, dims[l + 1]) for l in range(L - 1)]
+        self.delta = [z(BP, dims[l + 1]) for l in range(L)]
+        self.prob = z(BP, dims[L])
+        self.sd = z(BP)
+        self.ce = z(BP)
+        self.coeff = z(BP)
+        self.labels = torch.zeros(BP, dtype=torch.int64, device=device)
+        self.Rh = [z(BP, dims[l + 1]) for l in range(L - 1)]
+        self.Rd = [z(BP, dims[l + 1]) for l in range(L)]
         d = _native.Mlp()
-        d.L, d.B, d.Bp = L, B, BP
+        d.L, d.Bp = L, BP
         for i, v in enumerate(dims):
             d.dims[i] = v
         for l in range(L):
-            d.W[l] = Ws[l].data_ptr()
             d.h[l] = self.h[l].data_ptr()
             d.delta[l] = self.delta[l].data_ptr()
             d.Rd[l] = self.Rd[l].data_ptr()
@@ -86,10 +56,66 @@ class HipMLPState:
                 d.Rh[l] = self.Rh[l].data_ptr()
         d.prob, d.sd = self.prob.data_ptr(), self.sd.data_ptr()
         d.ridge2 = 0.0  # the ridge's 2*ridge*I is applied by the recurrence kernel (spec.hvp_shift)
-        n_part = int(self.lib.bhg_mlp_partial_floats(ctypes.byref(d)))
-        self.partial = torch.empty(max(n_part, 1), device=dev)
+        d.B = 1
+        n_part = int(lib.bhg_mlp_partial_floats(ctypes.byref(d)))
+        self.partial = torch.empty(max(n_part, 1), dtype=torch.float32, device=device)
         d.partial, d.partial_floats = self.partial.data_ptr(), n_part
         self.desc = d
+        self.native_prepare = bool(lib.bhg_mlp_supports_native_prepare(ctypes.byref(d)))
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class HipMLPState:
+    def __init__(self, spec, x, y):
+        if not x.is_cuda:
+            raise _native.NativeLibraryError("WeightedCEMLP(impl='hip') needs CUDA/HIP tensors; there is no CPU fallback")
+        self.lib = lib = _native.load()
+        self.spec = spec
+        Ws = [lin.weight.detach() for lin in spec.layers]
+        bs = [lin.bias.detach() for lin in spec.layers]
+        L, B = len(Ws), x.shape[0]
+        if B > BP:
+            raise ValueError(f"WeightedCEMLP(impl='hip') supports batches up to {BP} rows, got {B}")
+        if L > _native.BHG_MLP_MAX_LAYERS:
+            raise ValueError("too many layers")
+        for t in Ws + bs:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0:
+                raise ValueError("weights and biases must be contiguous, 16-byte aligned fp32 tensors")
+        dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
+        key = (id(spec.layers[0]), dims, str(x.device))  # one set of buffers per inner network
+        buf = _BUFFERS.get(key)
+        if buf is None:
+            buf = _BUFFERS[key] = _Buffers(dims, x.device, lib)
+        self.buf, self.B, self.L, self.Ws = buf, B, L, Ws
+        d = buf.desc
+        d.B = B
+        for l in range(L):
+            d.W[l] = Ws[l].data_ptr()
+        self.desc = d
+        # padded input batch and labels (rows >= B of h[0] stay zero from allocation)
+        if getattr(buf, "last_B", B) > B:  # a smaller batch than last time: clear the now-unused rows
+            buf.h[0][B:].zero_()
+        buf.last_B = B
+        buf.h[0][:B].copy_(x.detach().to(torch.float32).reshape(B, -1))
+        buf.labels[:B].copy_(y.reshape(-1))
+
+        if buf.native_prepare:
+            bias_tab, self._bias_keep = _native.ptr_array([b.data_ptr() for b in bs])
+            _native.check(lib.bhg_mlp_forward(ctypes.byref(d), bias_tab, buf.labels.data_ptr(), buf.ce.data_ptr(), _stream()),
+                          "bhg_mlp_forward")
+            ce = buf.ce[:B]
+        else:
+            ce = self._aten_forward(Ws, bs, y)
+        # sample weights from the upper problem's module (keeps the graph to prev's parameters)
+        self.sample_weight = spec.weight_fn(ce.detach().clone())
+        buf.sd[:B].copy_(self.sample_weight.detach().reshape(-1).to(torch.float32) / B)
+        if buf.native_prepare:
+            _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
+        else:
+            self._aten_backward(Ws, y)
         # HVP outputs are consumed by the recurrence kernel on the same stream before the next
         # HVP is launched, so one set of output tensors serves all K iterations.
         self.out = []
@@ -97,27 +123,64 @@ class HipMLPState:
             self.out += [torch.empty_like(lin.weight), torch.empty_like(lin.bias)]
         self._out_tab, self._out_keep = _native.ptr_array([t.data_ptr() for t in self.out])
 
-    def hvp(self, direction_views):
+    # ---- ATen path of the once-per-step passes for wide output layers ------------------------------------------
+    def _aten_forward(self, Ws, bs, y):
+        buf, B, L = self.buf, self.B, self.L
+        h = buf.h[0][:B]
+        for l in range(L):
+            a = torch.addmm(bs[l], h, Ws[l].t())
+            if l + 1 < L:
+                m = (a > 0).to(torch.float32)
+                h = a * m
+                buf.mask[l][:B].copy_(m)
+                buf.h[l + 1][:B].copy_(h)
+            else:
+                logp = F.log_softmax(a, dim=1)
+        buf.prob[:B].copy_(logp.exp())
+        return -logp.gather(1, y.reshape(-1, 1)).reshape(-1)
+
+    def _aten_backward(self, Ws, y):
+        buf, B, L = self.buf, self.B, self.L
+        err = buf.prob[:B] - F.one_hot(y.reshape(-1), buf.prob.shape[1]).to(torch.float32)
+        delta = buf.sd[:B, None] * err
+        buf.delta[L - 1][:B].copy_(delta)
+        for l in range(L - 1, 0, -1):
+            delta = buf.mask[l - 1][:B] * (delta @ Ws[l])
+            buf.delta[l - 1][:B].copy_(delta)
+
+    # ---- per iteration -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _dir_table(direction_views):
         dirs = []
         for t in direction_views:
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
                 t = t.detach().to(torch.float32).contiguous().clone()
             dirs.append(t)
-        tab, _keep = _native.ptr_array([t.data_ptr() for t in dirs])
-        _native.check(
-            self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), tab, self._out_tab, int(torch.cuda.current_stream().cuda_stream)),
-            "bhg_mlp_hvp",
-        )
+        tab, keep = _native.ptr_array([t.data_ptr() for t in dirs])
+        return tab, (dirs, keep)
+
+    def hvp(self, direction_views):
+        tab, _keep = self._dir_table(direction_views)
+        _native.check(self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), tab, self._out_tab, _stream()), "bhg_mlp_hvp")
         return self.out
 
     def mixed_coeff(self, dir_views):
-        """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step (ATen)."""
+        """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step."""
+        buf, B = self.buf, self.B
+        if buf.native_prepare:
+            tab, _keep = self._dir_table(dir_views)
+            _native.check(
+                self.lib.bhg_mlp_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(), _stream()),
+                "bhg_mlp_mixed_coeff",
+            )
+            return buf.coeff[:B].clone()
         Vs, cs = dir_views[0::2], dir_views[1::2]
         Rh = None
         for l in range(self.L):
-            Ra = torch.addmm(cs[l], self.hs_raw[l], Vs[l].t())
+            Ra = torch.addmm(cs[l], buf.h[l][:B], Vs[l].t())
             if Rh is not None:
                 Ra = Ra + Rh @ self.Ws[l].t()
             if l + 1 < self.L:
-                Rh = self.masks_raw[l] * Ra
-        return (self.err * Ra).sum(1) / self.B
+                Rh = buf.mask[l][:B] * Ra
+        err = buf.prob[:B] - F.one_hot(buf.labels[:B], buf.prob.shape[1]).to(torch.float32)
+        return (err * Ra).sum(1) / B

@@ -200,6 +200,17 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m);
  * (contiguous fp32, 16-byte aligned; out tensors are fully overwritten).                         */
 int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream);
 
+/* Once-per-step passes on the same descriptor (narrow classifier head: dims[L] <= 32, dims[L-1] % 4 == 0;
+ * bhg_mlp_supports_native_prepare tells).  They write the direction-independent buffers the HVP reads:
+ *   bhg_mlp_forward   h[1..L-1], mask[], prob, and ce[b] = -log softmax(z_b)[y_b]   (h[0] = padded input, bias = L ptrs)
+ *   bhg_mlp_backward  delta[]  from sd (= per-sample weight / B, written by the caller between the two calls)
+ *   bhg_mlp_mixed_coeff  coeff[b] = (prob_b - onehot(y_b)) . Rz_b(dir) / B  (the mixed second derivative's
+ *                     coefficient w.r.t. the sample weights; cg.py:58-68 for this structure)            */
+int bhg_mlp_supports_native_prepare(const bhg_mlp* m);
+int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* stream);
+int bhg_mlp_backward(const bhg_mlp* m, const int64_t* labels, void* stream);
+int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t* labels, float* coeff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
