@@ -12,7 +12,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbhg.so")
+LIB_PATH = os.environ.get("BHG_LIB") or os.path.join(_HERE, "csrc", "libbhg.so")  # BHG_LIB: A/B builds of the same ABI
 
 BHG_CHUNK_ELEMS = 4096
 BHG_FLAT_ALIGN = 64
