@@ -558,7 +558,11 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       const float* __restrict__ cb, const float* __restrict__ prob,
                                                       const float* __restrict__ sd, float* __restrict__ rd, int K,
                                                       int C, int B, int mode, const int64_t* __restrict__ labels,
-                                                      float* __restrict__ aux) {
+                                                      float* __restrict__ aux, const float* __restrict__ delta_top,
+                                                      const float* __restrict__ mask_prev,
+                                                      float* __restrict__ rd_prev) {
+  // HEAD_JVP with rd_prev != NULL also performs the R-backward step through the head for this sample row
+  // (it only needs the row's own Rd_L):  rd_prev[b][k] = mask_prev[b][k] * sum_c (delta_top[b][c] V[c][k] + Rd_L[b][c] W[c][k])
   // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
   // mode HEAD_COEFF:  aux[b]   = (p - onehot(y)).Rz / B                         (mixed-derivative coefficient)
   // mode HEAD_LOGITS: rd[b][:] = softmax(z), aux[b] = -log softmax(z)[y]        (forward pass; V = W, cb = bias)
@@ -568,6 +572,8 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   if (b >= B) {
     if (mode != HEAD_COEFF && threadIdx.x < C) rd[(int64_t)b * C + threadIdx.x] = 0.f;
     if (mode != HEAD_JVP && threadIdx.x == 0) aux[b] = 0.f;
+    if (mode == HEAD_JVP && rd_prev)
+      for (int k = 4 * threadIdx.x; k < K; k += 1024) *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   const float* rhb = Rh ? Rh + (int64_t)b * K : nullptr;
@@ -605,11 +611,31 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   }
   __syncthreads();
   if (mode == HEAD_JVP) {
+    __shared__ float rdl[kSmallC], dtl[kSmallC];
     if (threadIdx.x < C) {
       float dot = 0.f;
       for (int c = 0; c < C; ++c) dot += prob[(int64_t)b * C + c] * rz[c];
       const float p = prob[(int64_t)b * C + threadIdx.x];
-      rd[(int64_t)b * C + threadIdx.x] = sd[b] * (p * rz[threadIdx.x] - p * dot);
+      const float v = sd[b] * (p * rz[threadIdx.x] - p * dot);
+      rd[(int64_t)b * C + threadIdx.x] = v;
+      rdl[threadIdx.x] = v;
+      if (rd_prev) dtl[threadIdx.x] = delta_top[(int64_t)b * C + threadIdx.x];
+    }
+    if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
+      __syncthreads();
+      for (int k = 4 * threadIdx.x; k < K; k += 1024) {
+        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < C; ++c) {
+          const float r = rdl[c], d = dtl[c];
+          const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)c * K + k);
+          const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * K + k);
+          acc2.x += d * v.x + r * w.x; acc2.y += d * v.y + r * w.y;
+          acc2.z += d * v.z + r * w.z; acc2.w += d * v.w + r * w.w;
+        }
+        const float4 mk = *reinterpret_cast<const float4*>(mask_prev + (int64_t)b * K + k);
+        acc2.x *= mk.x; acc2.y *= mk.y; acc2.z *= mk.z; acc2.w *= mk.w;
+        *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
+      }
     }
   } else if (mode == HEAD_COEFF) {
     if (threadIdx.x == 0) {
@@ -796,7 +822,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     if (head && l == L - 1) {
       hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
                          m->h[l], m->W[l], V, c, m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP,
-                         (const int64_t*)nullptr, (float*)nullptr);
+                         (const int64_t*)nullptr, (float*)nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
+                         l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr);
       continue;
     }
     GemmArgs a{};
@@ -824,8 +851,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   static hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS], ev_join = nullptr;
   if (!side) {
     BHG_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // > 64 KiB dynamic LDS
   }
@@ -864,12 +891,7 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     }
     const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
     const float* V = static_cast<const float*>(dir[2 * l]);
-    if (head && l == L - 1) {
-      int blocks = (Bp * (N / 4) + 255) / 256;
-      hipLaunchKernelGGL(k_head_backward, dim3(blocks), dim3(256), 0, st, m->delta[l], (const float*)m->Rd[l], m->W[l],
-                         V, m->mask[l - 1], m->Rd[l - 1], N, K, B, Bp);
-      continue;
-    }
+    if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
     GemmArgs a{};
     a.pr[0] = {m->delta[l], V, K, N};
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
@@ -881,11 +903,6 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
     const int slab = Bp * N;
     launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
-  }
-  launch_outer(0, st);  // needs Rd_0, the end of the chain
-  if (L > 1 && !no_side) {
-    BHG_HIP_CHECK(hipEventRecord(ev_join, side));
-    BHG_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
   }
   {
     BiasArgs ba{};
@@ -900,7 +917,18 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
       blk += (m->dims[l + 1] + 63) / 64;
     }
     ba.blk0[L] = blk;
-    hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
+    if (L > 1 && !no_side) {  // needs every Rd_l (complete on the main stream now); runs beside H(W_0)
+      BHG_HIP_CHECK(hipEventRecord(ev_rd[0], st));
+      BHG_HIP_CHECK(hipStreamWaitEvent(side, ev_rd[0], 0));
+      hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, side, ba);
+    } else {
+      hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
+    }
+  }
+  launch_outer(0, st);  // needs Rd_0, the end of the chain
+  if (L > 1 && !no_side) {
+    BHG_HIP_CHECK(hipEventRecord(ev_join, side));
+    BHG_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
   }
   if (timed) BHG_HIP_CHECK(hipEventRecord(t_b, st));
   BHG_HIP_CHECK(hipGetLastError());
@@ -936,7 +964,8 @@ int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* la
     if (l == L - 1) {
       hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, (const float*)nullptr, (const float*)m->h[l],
                          (const float*)nullptr, m->W[l], b, (const float*)nullptr, (const float*)nullptr,
-                         const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce);
+                         const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce, (const float*)nullptr,
+                         (const float*)nullptr, (float*)nullptr);
       break;
     }
     GemmArgs a{};
@@ -1000,7 +1029,7 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
     if (l == L - 1) {
       hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
                          (const float*)m->h[l], m->W[l], V, c, m->prob, (const float*)nullptr, (float*)nullptr, K, N, B,
-                         HEAD_COEFF, labels, coeff);
+                         HEAD_COEFF, labels, coeff, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
       break;
     }
     GemmArgs a{};
