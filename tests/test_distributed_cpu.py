@@ -142,3 +142,47 @@ def test_synchronize_params_is_one_flat_collective():
     for rank, err_avg, err_bcast in sorted(q.get(timeout=5) for _ in range(world)):
         assert err_avg < 1e-6  # all ranks hold the mean
         assert err_bcast < 1e-6  # rank 0 added 0.0, so after the broadcast everyone holds the mean again
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _cpu_checker_backend import CpuCheckerBackend
+
+        from betty_amd.backend import use_backend
+        from betty_amd.distributed import exchange_async
+
+        g = torch.Generator().manual_seed(10 + rank)
+        grads = [torch.randn(s, generator=g) for s in ((7, 5), (5,), (4097,), (1,))]
+        flat_mine = torch.cat([t.reshape(-1) for t in grads])
+        gathered = [torch.zeros_like(flat_mine) for _ in range(world)]
+        dist.all_gather(gathered, flat_mine)
+        with use_backend(CpuCheckerBackend()):
+            handle = exchange_async(grads)
+            out = handle.wait()
+        got = torch.cat([t.reshape(-1) for t in out])
+        want = torch.stack(gathered).mean(0)
+        shapes_ok = all(a.shape == b.shape for a, b in zip(out, grads))
+        q.put((rank, float((got - want).abs().max()), shapes_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_async_exchange_of_a_hypergradient():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, shapes_ok in sorted(q.get(timeout=5) for _ in range(world)):
+        assert shapes_ok and err < 1e-6
