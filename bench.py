@@ -107,7 +107,7 @@ def make_loss(upper):
     return loss
 
 
-def build(device, seed, dtype=torch.float32, ddp=False, K=20):
+def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg"):
     torch.manual_seed(seed)
     inner = InnerMLP().to(device=device, dtype=dtype)
     mwn = MWN(100).to(device=device, dtype=dtype)
@@ -124,7 +124,12 @@ def build(device, seed, dtype=torch.float32, ddp=False, K=20):
         # the wrapper the reference uses, problem.py:220-224
         fwd = DDP(mwn, device_ids=[device.index], gradient_as_bucket_view=True, find_unused_parameters=True)
     prev = Problem("upper", mwn, Config(), forward_module=fwd)
-    curr = Problem("inner", inner, Config(type="cg", cg_iterations=K, cg_alpha=1.0), loss_fn=make_loss(prev), batch=(x, y))
+    cfg = {
+        "cg": Config(type="cg", cg_iterations=K, cg_alpha=1.0),
+        "neumann": Config(type="neumann", neumann_iterations=K, neumann_alpha=0.1),
+        "darts": Config(type="darts", darts_alpha=0.01),
+    }[algo]
+    curr = Problem("inner", inner, cfg, loss_fn=make_loss(prev), batch=(x, y))
     return curr, prev, vector
 
 
@@ -180,7 +185,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cg-iters", type=int, default=20)
+    ap.add_argument("--cg-iters", type=int, default=20, help="K: CG / Neumann iterations")
+    ap.add_argument("--algo", choices=["cg", "neumann", "darts"], default="cg",
+                    help="cg = the BASELINE metric; neumann / darts = secondary lines (BASELINE cfg 2 uses neumann K=10)")
     ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
     ap.add_argument("--hvp", choices=["analytic", "analytic-aten", "autograd"], default="analytic",
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
@@ -214,7 +221,8 @@ def main():
     be = get_backend()
     be.cg_variant = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}[args.variant]
     K = args.cg_iters
-    curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K)
+    curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
+    jvp_fn = hg.jvp_fn_mapping[args.algo]
     if args.hvp == "analytic":
         declare_structure(curr, "hip")
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
@@ -231,7 +239,7 @@ def main():
     def step():
         for p in prev.parameters():
             p.grad = None
-        out = hg.cg(vector, curr, prev, True)
+        out = jvp_fn(vector, curr, prev, True)
         assert out is None
 
     for _ in range(args.warmup):
@@ -256,7 +264,7 @@ def main():
         import ctypes
 
         tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
-        _native.check(be.lib.bhg_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
+        _native.check(be.lib.bhg_timing_read(0 if args.algo == "cg" else 1, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
         kern_total_ms, kern_launches = tot.value, cnt.value
         _native.check(be.lib.bhg_timing_read(2, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
         hvp_total_ms, hvp_calls = tot.value, cnt.value
@@ -273,16 +281,18 @@ def main():
         roof = None
         if kern_launches:
             avg_us = 1e3 * kern_total_ms / kern_launches
-            alg_bytes = 28.0 * N  # read Hp,p,r,x; write x,r,p (fp32) per CG iteration
+            # CG iteration 28*N B (read Hp,p,r,x; write x,r,p), Neumann iteration 20*N B
+            alg_bytes = (28.0 if args.algo == "cg" else 20.0) * N
             achieved = alg_bytes / (avg_us * 1e-6) / 1e9
             roof = {
                 "bound": "hbm",
-                "kernel": "k_cg_resident (1 launch/iter)" if resident else "k_cg_dot+k_cg_resid+k_cg_dir (3 launches/iter)",
+                "kernel": ("k_neumann_step (1 launch/iter)" if args.algo == "neumann" else
+                           "k_cg_resident (1 launch/iter)" if resident else "k_cg_dot+k_cg_resid+k_cg_dir (3 launches/iter)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(resident, N),
+                "traffic": pmc_traffic(resident, N) if args.algo == "cg" else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": avg_us,
                 "launches_timed": kern_launches,
@@ -308,7 +318,8 @@ def main():
                 "calls_timed": hvp_calls,
             }
         out = {
-            "metric": "hypergradient-steps/sec (CG K=20, 10M inner params)",
+            "metric": "hypergradient-steps/sec (CG K=20, 10M inner params)" if (args.algo == "cg" and K == 20)
+            else f"hypergradient-steps/sec ({args.algo} K={K}, 10M inner params)",
             "value": value,
             "unit": "hypergradient-steps/sec",
             "n_gpus": world,
@@ -322,7 +333,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE cfg2/metric: MLP 3072-2048-1536-384-10 inner (N=%d, 8 tensors), MWN 1-100-1 upper (M=%d), "
-                "batch %d, cg K=%d alpha=1, sync=True" % (N, M, BATCH, K),
+                "batch %d, %s K=%d, sync=True" % (N, M, BATCH, args.algo, K),
                 "hvp": "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp)" if args.hvp == "analytic" else "pytorch-rocm autograd double backward",
                 "cg_variant": "resident" if resident else "stream",
                 "parallelism": "replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU",
