@@ -891,8 +891,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
     hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
                           timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
                           hvp_shift, (const double*)partR_old, partR_new, partP,
-                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal,
-                          getenv("BHG_DEBUG_NO_BARRIER") ? 0u : kSpinLimit);  // 0 = timing experiment only (wrong results)
+                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal, kSpinLimit);
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;

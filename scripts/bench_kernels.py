@@ -78,7 +78,7 @@ def main():
         med, mn = timeit(step, refresh(pv), args.iters)
         out[name] = dict(us=med, min_us=mn, GBps=28.0 * N / med / 1e3, frac_of_8TBps=28.0 * N / med / 1e3 / 8000)
         to = int(lay.workspace[24708:24712].view(torch.int32).item())
-        assert to == 0 or os.environ.get("BHG_DEBUG_NO_BARRIER"), "grid barrier timed out"
+        assert to == 0, "grid barrier timed out"
 
     v, pp = lay.state(2)
     be.neumann_init(lay, vec, v, pp)
