@@ -28,7 +28,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kTM = 128;  // workgroup tile rows
 constexpr int kTN = 64;   // workgroup tile cols
 constexpr int kTK = 32;   // K step
-constexpr int kPadK = kTK + 1;  // LDS row stride of K-contiguous tiles (conflict-free fragment reads)
+constexpr int kPadK = kTK + 4;  // LDS row stride (36 floats = 144 B) of K-contiguous tiles: rows stay 16-B aligned so
+                                // tiles are written with ds_write_b128 and fragments read with ds_read_b128, and
+                                // 36*i mod 64 is a distinct multiple of 4 for i < 16 => conflict-free 16-lane groups
 
 // Operand layouts in global memory.
 enum : int { LAYOUT_KC = 0 /* [rows][K], K contiguous */, LAYOUT_RC = 1 /* [K][rows], rows contiguous */ };
@@ -87,8 +89,7 @@ __device__ __forceinline__ void store_kc(float* __restrict__ lds, const float4 (
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
-    float* d = lds + ((t >> 3) + 32 * i) * kPadK + 4 * (t & 7);
-    d[0] = regs[i].x; d[1] = regs[i].y; d[2] = regs[i].z; d[3] = regs[i].w;
+    *reinterpret_cast<float4*>(lds + ((t >> 3) + 32 * i) * kPadK + 4 * (t & 7)) = regs[i];
   }
 }
 // rows-contiguous operand ([K][rows]): tile 32 x ROWS, stored [k][ROWS].
@@ -190,31 +191,38 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   auto compute = [&](int step) {
     const float* A = sA[step & 1];
     const float* B = sB[step & 1];
-    // valid k in this tile (the tail of a K range is zero-filled in LDS; skip its MFMAs)
-    const int klen = min(kTK, kend - (kbeg + (step % nsteps_pair) * kTK));
-    if (klen == kTK) {
+    // Lane l works on k = 8*k8 + 4*(l>>5) + t, t = 0..3, in the t-th MFMA of each group of four: any
+    // assignment is valid as long as the A and the B fragment of a lane refer to the same k.  K-contiguous
+    // tiles therefore deliver four k per lane with ONE ds_read_b128.  (The tail of a K range is zero-filled
+    // in LDS, so running all 32 k of a partial tile only adds zeros.)
 #pragma unroll
-      for (int kp = 0; kp < kTK / 2; ++kp) {
-        const int k = 2 * kp + lk;
-        const float b = frag<LB, TN>(B, wn + li, k);
-        const float a0 = frag<LA, kTM>(A, wm + li, k);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-        if (NACC == 2) {
-          const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
-          acc[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[NACC - 1], 0, 0, 0);
+    for (int k8 = 0; k8 < kTK / 8; ++k8) {
+      const int kb = 8 * k8 + 4 * lk;
+      float av[NACC][4], bv[4];
+      if (LA == LAYOUT_KC) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(A + (wm + 32 * i + li) * kPadK + kb);
+          av[i][0] = v.x; av[i][1] = v.y; av[i][2] = v.z; av[i][3] = v.w;
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) av[i][t] = A[(kb + t) * kTM + wm + 32 * i + li];
       }
-    } else {
-      for (int kp = 0; kp < (klen + 1) / 2; ++kp) {
-        const int k = 2 * kp + lk;
-        const float b = frag<LB, TN>(B, wn + li, k);
-        const float a0 = frag<LA, kTM>(A, wm + li, k);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-        if (NACC == 2) {
-          const float a1 = frag<LA, kTM>(A, wm + 32 + li, k);
-          acc[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[NACC - 1], 0, 0, 0);
-        }
+      if (LB == LAYOUT_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(B + (wn + li) * kPadK + kb);
+        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = B[(kb + t) * TN + wn + li];
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
     }
   };
   // body for one step whose NEXT step's data sits in (ran, rbn) and whose step+2 loads go to (raf, rbf)
