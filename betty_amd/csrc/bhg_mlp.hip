@@ -50,6 +50,7 @@ struct GemmArgs {
   int out_rows;    // rows per partial slab
   const float* addend;  // optional: out = acc + addend_scale * addend[m][n] (same ld as out)
   float addend_scale;
+  int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
 };
 
 // LDS tile loaders -----------------------------------------------------------------------------------
@@ -280,8 +281,9 @@ constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging
 // single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
 __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int K = a.K;                      // <= kOK
-  const int Kh = (((K + 1) / 2) + 1) & ~1;  // rows per stage, even
+  const int K = a.K;
+  const int nsp = a.kstages;                          // stages per pair
+  const int Kh = (((K + nsp - 1) / nsp) + 1) & ~1;    // rows per stage, even, <= kOH
   float* sA = smem;                       // [Kh][128]
   float* sB = smem + Kh * kTM;            // [Kh][64]
   const int n0 = blockIdx.x * kTN;
@@ -298,10 +300,10 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   float4 ra[kOA], rb[kOB];
-  // stage s: pair s/2, K rows [ (s&1)*Kh, min(K, (s&1)*Kh + Kh) )
+  // stage s: pair s / nsp, K rows [ (s % nsp)*Kh, min(K, (s % nsp)*Kh + Kh) )
   auto gload = [&](int stage) {
-    const GemmPair& pr = a.pr[stage >> 1];
-    const int kb = (stage & 1) * Kh;
+    const GemmPair& pr = a.pr[stage / nsp];
+    const int kb = (stage % nsp) * Kh;
     const bool fa = m0 + kTM <= a.M && (pr.lda & 3) == 0;  // workgroup-uniform
     const bool fb = n0 + kTN <= a.N && (pr.ldb & 3) == 0;
 #pragma unroll
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     }
   };
   auto compute = [&](int stage) {
-    const int kb = (stage & 1) * Kh;
+    const int kb = (stage % nsp) * Kh;
     const int kvalid = min(Kh, K - kb);           // rows of this stage that carry data (rest is zero)
     const int nkp = kvalid > 0 ? (kvalid + 1) / 2 : 0;
     int kp = 0;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     }
   };
 
-  const int nstages = 2 * a.pairs;
+  const int nstages = nsp * a.pairs;
   gload(0);
   lstore();
   for (int stage = 0; stage < nstages; ++stage) {
@@ -809,7 +811,7 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
 int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream) {
   BHG_REQUIRE(m && dir && out, "NULL argument");
   BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
-  BHG_REQUIRE(m->Bp == kTM && m->B >= 1 && m->B <= m->Bp, "batch must fit one 128-row tile");
+  BHG_REQUIRE(m->Bp > 0 && m->Bp % kTM == 0 && m->B >= 1 && m->B <= m->Bp, "Bp must be a multiple of 128 rows >= B");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int L = m->L, Bp = m->Bp, B = m->B;
@@ -881,7 +883,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     a.splits = 1;
     a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
     a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
-    const int Kh = (((B + 1) / 2) + 1) & ~1;  // K rows per pipeline stage (see k_outer)
+    a.kstages = (B + kOH - 1) / kOH < 2 ? 2 : (B + kOH - 1) / kOH;   // <= 64 K rows per pipeline stage
+    const int Kh = (((B + a.kstages - 1) / a.kstages) + 1) & ~1;      // (see k_outer)
     size_t lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
     const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
     if (lds < lds_c) lds = lds_c;
@@ -947,7 +950,7 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
 static int check_head_problem(const bhg_mlp* m) {
   BHG_REQUIRE(m, "NULL descriptor");
   BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
-  BHG_REQUIRE(m->Bp == kTM && m->B >= 1 && m->B <= m->Bp, "batch must fit one 128-row tile");
+  BHG_REQUIRE(m->Bp > 0 && m->Bp % kTM == 0 && m->B >= 1 && m->B <= m->Bp, "Bp must be a multiple of 128 rows >= B");
   BHG_REQUIRE(m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0,
               "native prepare needs a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
@@ -955,7 +958,7 @@ static int check_head_problem(const bhg_mlp* m) {
 }
 
 int bhg_mlp_supports_native_prepare(const bhg_mlp* m) {
-  return m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp == kTM && m->dims[m->L] <= kSmallC &&
+  return m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && m->dims[m->L] <= kSmallC &&
          (m->dims[m->L - 1] & 3) == 0;
 }
 

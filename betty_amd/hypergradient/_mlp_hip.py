@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .. import _native
 
-BP = 128  # batch rows of every activation buffer (one 128-row MFMA workgroup tile)
+TILE_M = 128  # activation buffers hold a multiple of 128 rows (the MFMA workgroup tile height)
 
 _BUFFERS = {}
 
@@ -29,8 +29,9 @@ _BUFFERS = {}
 class _Buffers:
     """Device buffers + descriptor for one (dims, device); contents are rewritten every step."""
 
-    def __init__(self, dims, device, lib):
+    def __init__(self, dims, BP, device, lib):
         L = len(dims) - 1
+        self.BP = BP
         self.dims, self.L = dims, L
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
         self.h = [z(BP, dims[l]) for l in range(L)]
@@ -77,18 +78,17 @@ class HipMLPState:
         Ws = [lin.weight.detach() for lin in spec.layers]
         bs = [lin.bias.detach() for lin in spec.layers]
         L, B = len(Ws), x.shape[0]
-        if B > BP:
-            raise ValueError(f"WeightedCEMLP(impl='hip') supports batches up to {BP} rows, got {B}")
+        BP = (B + TILE_M - 1) // TILE_M * TILE_M
         if L > _native.BHG_MLP_MAX_LAYERS:
             raise ValueError("too many layers")
         for t in Ws + bs:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0:
                 raise ValueError("weights and biases must be contiguous, 16-byte aligned fp32 tensors")
         dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
-        key = (id(spec.layers[0]), dims, str(x.device))  # one set of buffers per inner network
+        key = (id(spec.layers[0]), dims, BP, str(x.device))  # one set of buffers per inner network and batch tile count
         buf = _BUFFERS.get(key)
         if buf is None:
-            buf = _BUFFERS[key] = _Buffers(dims, x.device, lib)
+            buf = _BUFFERS[key] = _Buffers(dims, BP, x.device, lib)
         self.buf, self.B, self.L, self.Ws = buf, B, L, Ws
         d = buf.desc
         d.B = B

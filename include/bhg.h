@@ -178,7 +178,8 @@ int bhg_logreg_hvp(const float* X, const float* s, const float* lam, const float
  * hypergradient step and describes them here; bhg_mlp_hvp then evaluates
  *   H(W_l) = Rd_l^T h_{l-1} + delta_l^T Rh_{l-1} + ridge2 * V_l ,  H(b_l) = colsum(Rd_l) + ridge2 * c_l
  * on the fp32 matrix cores.  Layer l (0-based) maps dims[l] -> dims[l+1]; all [Bp, d] buffers are
- * row-major with Bp = 128 rows, rows >= B zero.                                                   */
+ * row-major with Bp rows (a multiple of 128, >= B); rows >= B must hold finite values and are
+ * ignored / written as zero.                                                   */
 #define BHG_MLP_MAX_LAYERS 32
 typedef struct bhg_mlp {
   int32_t L, B, Bp;

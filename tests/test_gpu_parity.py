@@ -332,7 +332,8 @@ def _mlp_problem(dims, B, ridge, seed):
 
 @pytest.mark.parametrize(
     "dims,B",
-    [([48, 64, 32, 10], 40), ([70, 130, 33, 10], 100), ([256, 192, 10], 128), ([33, 7], 5), ([12] + [12] * 5 + [4], 17)],
+    [([48, 64, 32, 10], 40), ([70, 130, 33, 10], 100), ([256, 192, 10], 128), ([33, 7], 5), ([12] + [12] * 5 + [4], 17),
+     ([70, 130, 36, 10], 200), ([64, 48, 10], 300), ([40, 52, 50], 129)],  # > 128 rows: several 128-row M tiles
     ids=lambda v: str(v),
 )
 def test_mlp_hvp_kernels_vs_aten_and_autograd(dims, B):
