@@ -508,3 +508,27 @@ def test_set_grads_multi_tensor_accumulate(be):
         assert torch.equal(a, a0), "set_grads must not mutate the caller's tensors (problem.py:594 is out of place)"
         want = a if b is None else a + b
         assert torch.equal(p.grad, want)
+
+
+def test_cg_auto_falls_back_to_stream_beyond_resident_capacity(be):
+    """2 x the cfg-2 tensor list (N = 20 M) exceeds the register-resident capacity: BHG_CG_AUTO must take
+    the 3-kernel streaming form and still solve the 4-eigenvalue diagonal system exactly; forcing the
+    resident variant must be refused with BHG_ERR_CAPACITY, not mis-computed."""
+    sizes = CFG2_SIZES * 2
+    gen = torch.Generator().manual_seed(8)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
+    diag = [dvals[torch.arange(n, device=DEV) % 4] for n in sizes]
+    lay = be.layout(vec)
+    assert lay.n_chunks > be.lib.bhg_cg_resident_capacity_chunks()
+    x, r, p = lay.state(3)
+    be.cg_init(lay, vec, x, r, p)
+    with pytest.raises(_native.NativeLibraryError, match="capacity"):
+        be.cg_step(lay, [d * t for d, t in zip(diag, lay.views(p, vec))], x, r, p, 1.0, 0, variant=_native.BHG_CG_RESIDENT)
+    K = 4
+    for k in range(K):
+        hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
+        be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == K - 1 else 0.0), variant=_native.BHG_CG_AUTO)
+    for xv, v, d in zip(lay.views(x, vec), vec, diag):
+        want = -(v / d)
+        assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item()

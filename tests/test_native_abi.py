@@ -93,3 +93,41 @@ def test_layout_builder_rejects_bad_sizes():
     chunks = (_native.Chunk * 4)()
     assert lib.bhg_layout_build(arr, 2, starts, chunks) == -1
     assert b"negative" in lib.bhg_last_error()
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any HIP call: negative return code + message, no crash.
+    (Runs on the CPU-only box: none of these paths touches the device.)"""
+    lib = _native.load()
+    one = (ctypes.c_void_p * 1)(0)
+    tab = ctypes.cast(one, _native._PP)
+    null_tab = ctypes.cast(None, _native._PP)
+    # NULL tensor table with T > 0
+    assert lib.bhg_neumann_step(null_tab, 1, None, 1, None, None, 0.1, 0.0, 0.0, None, None) == -1
+    assert b"NULL" in lib.bhg_last_error()
+    # negative sizes
+    assert lib.bhg_flatten(tab, -1, None, 0, None, 1.0, None, None) == -1
+    assert b"negative" in lib.bhg_last_error()
+    # chunk table missing
+    assert lib.bhg_cg_init(tab, 1, None, 3, None, None, None, None, None) == -1
+    # workspace missing
+    assert lib.bhg_cg_step(tab, 1, 1, 1, None, None, None, 1.0, 0, 0.0, 0.0, 0, None, None) == -1
+    assert b"workspace" in lib.bhg_last_error()
+    # negative iteration index
+    assert lib.bhg_cg_step(tab, 1, 1, 1, None, None, None, 1.0, -1, 0.0, 0.0, 0, 1, None) == -1
+    # empty problems are a no-op, not an error
+    assert lib.bhg_flatten(null_tab, 0, None, 0, None, 1.0, None, None) == 0
+    assert lib.bhg_scale_flat(None, 0, 2.0, None) == 0
+    # MLP descriptor checks
+    assert lib.bhg_mlp_partial_floats(None) == 0
+    d = _native.Mlp()
+    d.L, d.B, d.Bp = 0, 1, 128
+    assert lib.bhg_mlp_hvp(ctypes.byref(d), tab, tab, None) == -1
+    d.L, d.Bp = 2, 100  # Bp must be a multiple of 128
+    assert lib.bhg_mlp_hvp(ctypes.byref(d), tab, tab, None) == -1
+    assert b"multiple of 128" in lib.bhg_last_error()
+    # timing API
+    tot, cnt = ctypes.c_double(1.0), ctypes.c_int(7)
+    assert lib.bhg_timing_enable(0) == 0
+    assert lib.bhg_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value == 0
+    assert lib.bhg_timing_read(0, None, None) == -1
