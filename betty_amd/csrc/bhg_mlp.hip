@@ -164,9 +164,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int nsteps_pair = kbeg < kend ? (kend - kbeg + kTK - 1) / kTK : 0;
   const int nsteps = nsteps_pair * a.pairs;
 
-  f32x16 acc[NACC];
+  // Two K-interleaved accumulators per 32x32 output tile: consecutive MFMAs never depend on each other, so
+  // the instructions hipcc schedules between them (LDS reads, waits) do not stretch a dependent chain.
+  constexpr int KI = 2;
+  f32x16 acc[NACC * KI];
 #pragma unroll
-  for (int i = 0; i < NACC; ++i)
+  for (int i = 0; i < NACC * KI; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
+          acc[i * KI + (t & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i * KI + (t & 1)], 0, 0, 0);
     }
   };
   // body for one step whose NEXT step's data sits in (ran, rbn) and whose step+2 loads go to (raf, rbf)
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       for (int rg = 0; rg < 16; ++rg) {
         const int row = m0 + wm + 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
         if (row < a.M) {
-          float v = acc[t][rg];
+          float v = acc[t * KI][rg] + acc[t * KI + 1][rg];
           if (a.addend) v += a.addend_scale * a.addend[(int64_t)row * a.ldo + col];
           out[(int64_t)row * a.ldo + col] = v;
         }
