@@ -227,3 +227,49 @@ class LogisticRegressionL2:
             return None
         return list(torch.autograd.grad(self.lam, upper, grad_outputs=coeff))
 
+
+class ProximalRegularized:
+    """Inner loss = data loss + reg * ||w - theta||^2 with theta the UPPER problem's parameters, one per
+    inner parameter — implicit MAML (examples/implicit_maml/main.py:87-92,122-129).
+
+    The proximal term's Hessian is 2*reg*I and its mixed derivative is -2*reg*I, so
+      * the HVP callback differentiates the DATA loss only (PyTorch double backward through the user's
+        network) and ``hvp_shift = 2*reg`` lets the CG/Neumann kernel add 2*reg*p from the direction it
+        already holds in registers — the T elementwise double-backward kernels of the prox term disappear;
+      * the final hop is closed form: hypergradient = +2*reg*x, i.e. ``-2*reg * (-alpha*x)`` applied to the
+        flat result — no second-order autograd call at all.
+    ``data_loss(batch)`` must return the loss WITHOUT the proximal term; ``prev.trainable_parameters()`` must
+    align one-to-one with ``curr.parameters()``.
+    """
+
+    def __init__(self, curr, prev, data_loss: Callable, reg: float, batch=None):
+        self.curr, self.prev, self.data_loss, self.reg, self.batch = curr, prev, data_loss, float(reg), batch
+        self.hvp_shift = 2.0 * self.reg
+        inner, upper = list(curr.parameters()), list(prev.trainable_parameters())
+        if len(inner) != len(upper) or any(a.shape != b.shape for a, b in zip(inner, upper)):
+            raise ValueError("ProximalRegularized: upper and inner parameters must match one-to-one")
+
+    def prepare(self):
+        import warnings  # noqa: PLC0415
+
+        batch = self.batch if self.batch is not None else self.curr.cur_batch
+        loss = self.data_loss(batch)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self._in_grad = torch.autograd.grad(loss, self.curr.trainable_parameters(), create_graph=True)
+        params = list(self.curr.parameters())
+
+        def hvp(direction_views):
+            return torch.autograd.grad(self._in_grad, params, grad_outputs=direction_views, retain_graph=True)
+
+        return hvp
+
+    def mixed_vjp(self, neg_x_views, sync: bool):
+        self._in_grad = None  # release the double-backward graph
+        grads = [(-2.0 * self.reg) * t for t in neg_x_views]  # = +2*reg*(alpha*x)
+        if sync:
+            # accumulate into .grad THROUGH autograd so DistributedDataParallel's reducer hooks fire
+            torch.autograd.backward(list(self.prev.trainable_parameters()), grad_tensors=grads)
+            return None
+        return grads
+

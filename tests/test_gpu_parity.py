@@ -532,3 +532,18 @@ def test_cg_auto_falls_back_to_stream_beyond_resident_capacity(be):
     for xv, v, d in zip(lay.views(x, vec), vec, diag):
         want = -(v / d)
         assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_structured_proximal_path_matches_reference(sync, be):
+    case = zoo.CASE_BY_NAME["imaml_cg10"]
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    zoo.attach_prox_structure(curr)
+    out = hg.cg(vector, curr, prev, sync)
+    if sync:
+        assert out is None
+        out = [p.grad for p in prev.trainable_parameters()]
+    rel, mx = rel_err(_np(out), golden_list(outputs, case.name, "fp32"))
+    assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)
+

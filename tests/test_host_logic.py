@@ -165,3 +165,18 @@ def test_structured_provider_has_no_silent_cpu_path():
     with pytest.raises(NativeLibraryError, match="no CPU fallback"):
         curr.hypergradient_structure(prev).prepare()
 
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_proximal_structure_matches_reference(sync, checker):
+    """iMAML closed form: data-loss HVP + shift 2*reg, mixed VJP = +2*reg*x."""
+    case = zoo.CASE_BY_NAME["imaml_cg10"]
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config)
+    zoo.attach_prox_structure(curr)
+    out = hg.cg(vector, curr, prev, sync)
+    if sync:
+        assert out is None
+        out = [p.grad for p in prev.trainable_parameters()]
+    rel, mx = rel_err([o.detach().numpy() for o in out], golden_list(outputs, case.name, "fp32"))
+    assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)
+

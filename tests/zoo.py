@@ -329,3 +329,14 @@ def attach_logreg_structure(curr):
     curr.hypergradient_structure = lambda prev: LogisticRegressionL2(curr, prev, curr.module.w, lam_fn=lambda: prev.fwd())
     return curr
 
+
+def attach_prox_structure(curr):
+    """iMAML structure: data loss = CE only, prox coefficient of make_imaml_loss (0.5)."""
+    from betty_amd.hypergradient.structured import ProximalRegularized
+
+    def structure(prev):
+        return ProximalRegularized(curr, prev, data_loss=lambda batch: F.cross_entropy(curr.module(batch[0]), batch[1]), reg=0.5)
+
+    curr.hypergradient_structure = structure
+    return curr
+
