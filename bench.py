@@ -154,29 +154,40 @@ def cpu_baseline(steps, K):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hypergrad_oracle as orc
 
-    # torch's CPU kernels stop scaling (and oversubscribe badly) far below the 256 hardware
-    # threads of the GPU box's host: use at most 32 and say so.
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    # torch's CPU kernels stop scaling far below the 256 hardware threads of the GPU box's host (EPYC 9575F:
+    # 8 thr 0.68 s, 16 thr 0.55 s, 32 thr 0.98 s, 64 thr 1.8 s, 128 thr 5.3 s per step): time a few thread
+    # counts and report the BEST one, so the baseline is the reference path at its fastest on this host.
     curr, prev, vector = build(torch.device("cpu"), seed=0, K=K)
-    orc.cg(vector, curr, prev, False)  # warm-up
-    times = []
-    budget_t0 = time.perf_counter()
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        orc.cg(vector, curr, prev, False)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - budget_t0 > 25.0:  # bounded sample
-            break
+    best = None
+    per_setting = max(2, steps)
+    for threads in (8, 16, 32):
+        if threads > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(threads)
+        orc.cg(vector, curr, prev, False)  # warm-up
+        times = []
+        budget_t0 = time.perf_counter()
+        for _ in range(per_setting):
+            t0 = time.perf_counter()
+            orc.cg(vector, curr, prev, False)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - budget_t0 > 10.0:  # bounded sample
+                break
+        times.sort()
+        med_t = times[len(times) // 2]
+        if best is None or med_t < best[0]:
+            best = (med_t, threads, times)
+    med, used_threads, times = best
     steps = len(times)
-    times.sort()
-    med = times[len(times) // 2]
+    torch.set_num_threads(used_threads)
     return {
         "value": 1.0 / med,
         "unit": "hypergradient-steps/sec",
-        "cores": torch.get_num_threads(),
+        "cores": used_threads,
         "kind": "port",
-        "sample": f"{steps} steps of the same workload (cg K={K}, N=10,034,826, batch {BATCH}), median; "
-        f"oracle/hypergrad_oracle.py on torch CPU fp32, min {times[0]:.3f}s max {times[-1]:.3f}s",
+        "sample": f"{steps} steps of the same workload (cg K={K}, N=10,034,826, batch {BATCH}), median, at the best of "
+        f"8/16/32 torch threads ({used_threads}); oracle/hypergrad_oracle.py on torch CPU fp32, "
+        f"min {times[0]:.3f}s max {times[-1]:.3f}s",
     }
 
 
