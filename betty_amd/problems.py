@@ -99,6 +99,8 @@ class Problem:
 
     def set_problem_attr(self, problem):
         """Other problems are reachable as attributes by name (``self.inner(x)``), problem.py:792-806."""
+        if self.__dict__.get(problem.name) is problem:
+            return  # already wired (a second Engine over the same problems)
         if problem.name in self.__dict__ or hasattr(type(self), problem.name):
             raise ValueError(f"problem name {problem.name!r} clashes with an attribute")
         setattr(self, problem.name, problem)

@@ -186,3 +186,57 @@ def test_flat_async_exchange_of_a_hypergradient():
         assert p.exitcode == 0
     for rank, err, shapes_ok in sorted(q.get(timeout=5) for _ in range(world)):
         assert shapes_ok and err < 1e-6
+
+
+def _engine_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import test_engine_shim as tes
+        from _cpu_checker_backend import CpuCheckerBackend
+
+        from betty_amd import Config
+        from betty_amd.backend import use_backend
+        from betty_amd.engine import Engine, EngineConfig
+
+        # same model init on every rank (seeded inside _scenario), different data order per rank
+        engine, outer, inner = tes._scenario(Config(type="cg", cg_iterations=3, cg_alpha=0.1, unroll_steps=20),
+                                             torch.device("cpu"))
+        x, y = inner.train_data_loader[0]
+        half = x.shape[0] // world
+        inner.train_data_loader = [(x[rank * half:(rank + 1) * half], y[rank * half:(rank + 1) * half])]
+        engine = Engine(config=EngineConfig(train_iters=100, strategy="distributed", backend="gloo"),
+                        problems=[outer, inner], dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}},
+                        device=torch.device("cpu"))
+        with use_backend(CpuCheckerBackend()):
+            engine.run()
+        lam = outer.module.w.detach().clone()
+        gathered = [torch.zeros_like(lam) for _ in range(world)]
+        dist.all_gather(gathered, lam)
+        q.put((rank, outer.count, float((gathered[0] - gathered[1]).abs().max()), float((lam - 1.0).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_distributed_strategy_keeps_upper_parameters_in_sync():
+    """Engine(strategy="distributed"): the upper module is DDP-wrapped, the synced hypergradient hop
+    averages over ranks, so after 5 upper steps on different data every rank holds the same lambda."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for rank, upper_steps, diff, moved in sorted(q.get(timeout=5) for _ in range(world)):
+        assert upper_steps == 5
+        assert diff < 1e-6, "ranks diverged: the hypergradient was not averaged"
+        assert moved > 1e-3, "lambda did not move at all"
