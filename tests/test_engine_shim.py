@@ -189,3 +189,21 @@ def test_roll_back_snapshot_and_flow():
         engine.run()
         assert inner.count == 5 and outer.count == 1
         torch.testing.assert_close(inner.module.w.data, w_start - 0.1 * g, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["cg", "neumann", "darts"])
+def test_autocast_precision_runs_on_gpu(algo):
+    """Config(precision="bf16") wraps training_step in autocast (problem.py:327-332); parameters and the
+    hypergradient vectors stay fp32, so the kernels see fp32 tensors (SURVEY §7 'AMP')."""
+    cfg = {
+        "cg": Config(type="cg", cg_iterations=3, cg_alpha=0.1, unroll_steps=20, precision="bf16"),
+        "neumann": Config(type="neumann", neumann_iterations=3, unroll_steps=20, precision="bf16"),
+        "darts": Config(type="darts", unroll_steps=20, precision="bf16"),
+    }[algo]
+    engine, outer, inner = _scenario(cfg, torch.device("cuda:0"))
+    engine.config.train_iters = 100
+    engine.run()
+    assert outer.count == 5
+    lam = outer.module.w.detach()
+    assert torch.isfinite(lam).all() and (lam - 1.0).abs().max() > 1e-4
