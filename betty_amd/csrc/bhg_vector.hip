@@ -356,18 +356,19 @@ __device__ __forceinline__ void grid_arrive(double block_value, double* part, un
 }
 __device__ __forceinline__ double grid_wait_sum(const double* part, unsigned* counter, unsigned target,
                                                 double* red, unsigned* timeout_word, unsigned spin_limit) {
+  double a = 0.0;
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > spin_limit) {  // bounded spin: flag and fall through instead of hanging the GPU
+      if (++spins > spin_limit) {  // bounded spin: flag and fall through instead of hanging the GPU ...
         __hip_atomic_store((gu32*)timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = __builtin_nan("");      // ... and poison the sum: a wrong answer must not look like a right one
         break;
       }
     }
   }
   __syncthreads();
-  double a = 0.0;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += kResThreads)
     a += __hip_atomic_load((gf64*)(part + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return block_sum_res(a, red);
@@ -804,6 +805,15 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
   return BHG_OK;
 }
 
+// BHG_CG_SPIN_LIMIT overrides the barrier's polling bound (tests force a time-out with 0).
+static unsigned spin_limit() {
+  static const unsigned v = [] {
+    const char* e = getenv("BHG_CG_SPIN_LIMIT");
+    return e ? (unsigned)strtoul(e, nullptr, 10) : kSpinLimit;
+  }();
+  return v;
+}
+
 int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMax; }
 
 // One-time residency census (MI355X_MICROARCH.md "Residency and cooperative launch": size grid-barrier
@@ -891,7 +901,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
     hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
                           timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
                           hvp_shift, (const double*)partR_old, partR_new, partP,
-                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal, kSpinLimit);
+                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;

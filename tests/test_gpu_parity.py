@@ -547,3 +547,40 @@ def test_structured_proximal_path_matches_reference(sync, be):
     rel, mx = rel_err(_np(out), golden_list(outputs, case.name, "fp32"))
     assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)
 
+
+
+_TIMEOUT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from betty_amd import _native
+from betty_amd.backend import get_backend
+be = get_backend()
+dev = torch.device("cuda:0")
+vec = [torch.randn(600 * 4096, device=dev)]          # every one of the 256 workgroups owns chunks
+hv = [2.0 * vec[0]]
+lay = be.layout(vec)
+x, r, p = lay.state(3)
+be.cg_init(lay, vec, x, r, p)
+be.cg_step(lay, hv, x, r, p, 1.0, 0, 0.0, variant=_native.BHG_CG_RESIDENT)
+torch.cuda.synchronize()
+print("TIMED_OUT", int(be.cg_barrier_timed_out(lay)), "NAN", int(torch.isnan(x).any().item()))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit,expect", [("0", (1, 1)), (None, (0, 0))])
+def test_resident_barrier_timeout_poisons_the_result(limit, expect):
+    """A grid barrier that gives up (GPU shared mid-run) must not return a plausible wrong answer:
+    the flag is raised AND the iterate is NaN.  BHG_CG_SPIN_LIMIT=0 forces the time-out."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("BHG_CG_SPIN_LIMIT", None)
+    if limit is not None:
+        env["BHG_CG_SPIN_LIMIT"] = limit
+    out = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("TIMED_OUT")][-1].split()
+    assert (int(line[1]), int(line[3])) == expect, out.stdout
