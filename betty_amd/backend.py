@@ -135,8 +135,9 @@ class HipBackend:
         """True if a grid barrier of the resident CG kernel gave up polling since the last cg_init
         (the GPU was shared or partitioned mid-run).  The kernel also poisons its result with NaN, so
         this is the diagnosis, not the alarm.  Synchronises the host (debug / health checks only)."""
-        off = 24704 + 4  # kWsBarrier + one word (bhg_common.hpp)
-        return bool(layout.workspace[off:off + 4].view(torch.int32).item())
+        ws = layout.workspace
+        off = int(self.lib.bhg_cg_timeout_flag_dev(ws.data_ptr())) - ws.data_ptr()
+        return bool(ws[off:off + 4].view(torch.int32).item())
 
     def cg_scalars(self, layout) -> torch.Tensor:
         """{rr_old, pHp, alpha, rr_new, beta} of the last CG step (device -> host copy; debug)."""

@@ -855,6 +855,10 @@ const double* bhg_cg_scalars_dev(const void* ws) {
   return reinterpret_cast<const double*>(static_cast<const char*>(ws) + kWsScal);
 }
 
+const unsigned* bhg_cg_timeout_flag_dev(const void* ws) {
+  return reinterpret_cast<const unsigned*>(static_cast<const char*>(ws) + kWsBarrier) + 1;
+}
+
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
                 float* p, float cg_alpha, int iter, float out_scale, float hvp_shift, int variant, void* ws,
                 void* stream) {

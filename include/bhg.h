@@ -122,6 +122,9 @@ int bhg_cg_resident_ok(void);
 /* Device address (inside ws) of 8 doubles: {rr_old, pHp, alpha, rr_new, beta, 0,0,0}
  * written by the most recent bhg_cg_step on that workspace. */
 const double* bhg_cg_scalars_dev(const void* ws);
+/* Device address (inside ws) of one u32 that the resident kernel sets to 1 when a grid barrier gave up
+ * polling since the last bhg_cg_init on that workspace (the result is NaN-poisoned as well). */
+const unsigned* bhg_cg_timeout_flag_dev(const void* ws);
 
 /* ---- flat helpers ------------------------------------------------------------- */
 /* flat <- scale * flat  (cg.py:56 / neumann.py:66 when iterations == 0)           */

@@ -77,8 +77,7 @@ def main():
 
         med, mn = timeit(step, refresh(pv), args.iters)
         out[name] = dict(us=med, min_us=mn, GBps=28.0 * N / med / 1e3, frac_of_8TBps=28.0 * N / med / 1e3 / 8000)
-        to = int(lay.workspace[24708:24712].view(torch.int32).item())
-        assert to == 0, "grid barrier timed out"
+        assert not be.cg_barrier_timed_out(lay), "grid barrier timed out"
 
     v, pp = lay.state(2)
     be.neumann_init(lay, vec, v, pp)
