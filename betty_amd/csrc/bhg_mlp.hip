@@ -269,10 +269,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
 }
 
 // ---- weight-shaped outputs: C[M][N] = sum_pairs A_pair^T B_pair (+ addend), K = batch (<= 128) -----------
-// The whole K extent of a pair is ONE LDS tile ([K][128] + [K][64], <= 96 KiB): a single round of
-// global loads per pair (all in flight together) instead of a 4-step latency chain; the second
-// pair's loads are issued before the first pair's MFMAs and parked in registers.  The accumulators
-// are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
+// The accumulators are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
 constexpr int kOK = 128;                      // max K of the outer-product kernel
 constexpr int kOH = kOK / 2;                  // K rows per pipeline stage (half of a pair)
 constexpr int kOA = kOH * kTM / (256 * 4);    // float4 per thread for one [64][128] A stage = 8
