@@ -193,6 +193,9 @@ CASES: List[Case] = [
     # SAMA: Adam-preconditioned finite difference; SGD = identity preconditioner
     Case("reweight_sama_adam", "reweight", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
     Case("logreg_sama_sgd", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01), rtol=2e-3),
+    # *_multitask=True: the perturbed inner weights are NOT restored (darts.py:61-63, sama.py:51-53)
+    Case("reweight_darts_multitask", "reweight", "darts", dict(type="darts", darts_alpha=0.1, darts_multitask=True), rtol=2e-3),
+    Case("logreg_sama_multitask", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01, sama_multitask=True), rtol=2e-3),
     # many small tensors (T = 48 > 32): exercises the device pointer-table path (cfg 5 shape)
     Case("deep_neumann6", "deep", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.2)),
     Case("deep_cg6", "deep", "cg", dict(type="cg", cg_iterations=6, cg_alpha=1.0)),
