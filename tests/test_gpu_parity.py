@@ -584,3 +584,126 @@ def test_resident_barrier_timeout_poisons_the_result(limit, expect):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("TIMED_OUT")][-1].split()
     assert (int(line[1]), int(line[3])) == expect, out.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json cfg 3 at full size: ResNet-12 inner (8.0 M parameters, 50 tensors), prox-regularised to
+# the upper copy (M = N), CG K = 20 — checker = the oracle's restatement of cg.py running on the same
+# device tensors (per-tensor ATen, i.e. what the reference itself would launch on this GPU)
+# ------------------------------------------------------------------------------------------------
+def _resnet12_case(cfg):
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    inner, upper = zoo.ResNet12().to(DEV), zoo.ResNet12().to(DEV)
+    for p, q in zip(inner.parameters(), upper.parameters()):
+        q.data.copy_(p.data + 0.05 * torch.randn(p.shape, generator=g).to(DEV))
+    x = torch.randn(25, 3, 32, 32, generator=g).to(DEV)          # 5-way 5-shot, synthetic
+    y = torch.arange(5).repeat_interleave(5).to(DEV)
+    vector = [0.01 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    curr = zoo.StubProblem("inner", inner, config=Config(**cfg), loss_fn=zoo.make_imaml_loss(prev, 0.5), batch=(x, y))
+    return curr, prev, vector
+
+
+@pytest.mark.parametrize("variant", ["resident", "stream"])
+def test_cfg3_resnet12_full_size_cg20(variant, be):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
+    assert len(vector) == 50 and sum(v.numel() for v in vector) == 7_999_365
+    want = horc.cg(vector, curr, prev, False)
+    again = horc.cg(vector, curr, prev, False)      # the checker's own run-to-run spread (MIOpen atomics)
+    noise, _ = rel_err(_np(again), _np(want))
+    be.cg_variant = VARIANTS[variant]
+    try:
+        got = hg.jvp_fn_mapping["cg"](vector, curr, prev, False)
+    finally:
+        be.cg_variant = _native.BHG_CG_AUTO
+    rel, mx = rel_err(_np(got), _np(want))
+    # rtol 1e-4 (north_star) unless the convolution double backward is itself noisier than that on this box
+    tol = max(1e-4, 20 * noise)
+    print(f"resnet12 cg20 [{variant}]: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
+    assert rel <= tol and mx <= 10 * tol, (variant, rel, mx, noise)
+    assert not be.cg_barrier_timed_out(be.layout(vector))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json cfg 4 at full size (single-GPU part): RoBERTa-base-shaped inner (124 M parameters),
+# data-reweighting upper, finite-difference DARTS hypergradient
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("radius", [0.01, 1.0])   # 0.01 = Config's default darts_alpha; 1.0 = well above fp32 resolution
+def test_cfg4_roberta_scale_darts(radius, be):
+    import copy
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    g = torch.Generator().manual_seed(91)
+    torch.manual_seed(91)
+    inner, upper = zoo.TokenClassifier().to(DEV), zoo.MWN(100).to(DEV)
+    tokens = torch.randint(0, 50265, (8, 128), generator=g).to(DEV)
+    labels = torch.randint(0, 2, (8,), generator=g).to(DEV)
+    vector = [1e-3 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+    assert sum(v.numel() for v in vector) == 124_055_810
+    cfg = dict(type="darts", darts_alpha=radius)
+
+    def problems(inner_m, upper_m):
+        prev = zoo.StubProblem("upper", upper_m, config=Config())
+        curr = zoo.StubProblem("inner", inner_m, config=Config(**cfg), loss_fn=zoo.make_reweight_loss(prev, 0.0),
+                               batch=(tokens, labels))
+        return curr, prev
+
+    # truth: the same algorithm in fp64 (the finite difference perturbs 124 M weights by ~1e-6 each, a few
+    # ulps of an fp32 weight, so the fp32 result is noise-limited for ANY implementation)
+    curr64, prev64 = problems(copy.deepcopy(inner).double(), copy.deepcopy(upper).double())
+    truth = horc.darts([v.double() for v in vector], curr64, prev64, False)
+    del curr64, prev64
+    # the reference's algorithm in fp32 on this device (per-tensor ATen) ...
+    w_before = [p.data.clone() for p in inner.parameters()]
+    curr, prev = problems(inner, upper)
+    want = horc.darts(vector, curr, prev, False)
+    for p, w in zip(inner.parameters(), w_before):      # start both runs from identical weights
+        p.data.copy_(w)
+    # ... and the HIP path
+    got = hg.jvp_fn_mapping["darts"](vector, curr, prev, False)
+    e_ref, _ = rel_err(_np(want), _np(truth))
+    e_got, _ = rel_err(_np(got), _np(truth))
+    rel, mx = rel_err(_np(got), _np(want))
+    print(f"roberta-scale darts R={radius}: vs fp64 truth: reference-fp32 {e_ref:.2e}, hip {e_got:.2e}; "
+          f"hip vs reference-fp32 {rel:.2e}")
+    # the HIP result differs from the reference's fp32 result by no more than that differs from the truth,
+    # and is within 2x of its distance to the truth (2e-3 floor = the golden darts cases' Case.rtol)
+    assert rel <= max(2e-3, e_ref), (rel, e_ref)
+    assert e_got <= max(2e-3, 2.0 * e_ref), (e_got, e_ref)
+    # perturb / restore drift of the 124 M weights: three roundings, each <= 1/2 ulp of the weight
+    drift = max(((p.data - w).abs() / w.abs().clamp_min(1e-3)).max().item() for p, w in zip(inner.parameters(), w_before))
+    assert drift <= 2.4e-7, drift
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json cfg 5 shape: mixed-op supernet inner (621 tensors), architecture parameters upper,
+# Neumann K = 20
+# ------------------------------------------------------------------------------------------------
+def test_cfg5_supernet_neumann20(be):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    g = torch.Generator().manual_seed(55)
+    torch.manual_seed(55)
+    inner, upper = zoo.Supernet().to(DEV), zoo.ArchParams().to(DEV)
+    x = torch.randn(16, 3, 16, 16, generator=g).to(DEV)
+    y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+    vector = [1e-2 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+    assert len(vector) == 621
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    curr = zoo.StubProblem("inner", inner, config=Config(type="neumann", neumann_iterations=20, neumann_alpha=0.1),
+                           loss_fn=zoo.make_supernet_loss(prev, 0.1), batch=(x, y))
+    want = horc.neumann(vector, curr, prev, False)
+    again = horc.neumann(vector, curr, prev, False)
+    noise, _ = rel_err(_np(again), _np(want))
+    got = hg.jvp_fn_mapping["neumann"](vector, curr, prev, False)
+    rel, mx = rel_err(_np(got), _np(want))
+    print(f"supernet neumann20: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
+    tol = max(1e-4, 20 * noise)
+    assert rel <= tol and mx <= 10 * tol, (rel, mx, noise)

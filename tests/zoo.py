@@ -124,6 +124,116 @@ class SmallConv(nn.Module):
         return self.fc(x.flatten(1))
 
 
+class _Res12Block(nn.Module):
+    """Three 3x3 conv + BN (batch statistics) + LeakyReLU with a 1x1 projection shortcut, then 2x2 max-pool."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        chans = [cin, cout, cout, cout]
+        self.convs = nn.ModuleList([nn.Conv2d(a, b, 3, padding=1, bias=False) for a, b in zip(chans[:-1], chans[1:])])
+        self.norms = nn.ModuleList([nn.BatchNorm2d(cout, track_running_stats=False) for _ in range(3)])
+        self.proj = nn.Conv2d(cin, cout, 1, bias=False)
+        self.proj_norm = nn.BatchNorm2d(cout, track_running_stats=False)
+
+    def forward(self, x):
+        y = x
+        for i, (conv, norm) in enumerate(zip(self.convs, self.norms)):
+            y = norm(conv(y))
+            if i < 2:
+                y = F.leaky_relu(y, 0.1)
+        return F.max_pool2d(F.leaky_relu(y + self.proj_norm(self.proj(x)), 0.1), 2)
+
+
+class ResNet12(nn.Module):
+    """The few-shot ResNet-12 shape of BASELINE.json cfg 3 (4 residual blocks of 3 convs; widths
+    64-128-256-512 = 8.0 M parameters in 50 tensors) — full-size GPU parity only, no golden file."""
+
+    def __init__(self, ways=5, widths=(64, 128, 256, 512)):
+        super().__init__()
+        chans = [3] + list(widths)
+        self.blocks = nn.ModuleList([_Res12Block(a, b) for a, b in zip(chans[:-1], chans[1:])])
+        self.fc = nn.Linear(widths[-1], ways)
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return self.fc(x.mean(dim=(2, 3)))
+
+
+class TokenClassifier(nn.Module):
+    """RoBERTa-base-shaped encoder (BASELINE.json cfg 4): vocab 50265, 514 positions, 12 pre-norm layers
+    of width 768 / 12 heads / FFN 3072, 2-way head = 124.1 M parameters.  Synthetic tokens, no dropout."""
+
+    def __init__(self, vocab=50265, width=768, layers=12, heads=12, ffn=3072, positions=514, classes=2):
+        super().__init__()
+        self.tok = nn.Embedding(vocab, width)
+        self.pos = nn.Embedding(positions, width)
+        self.norm = nn.LayerNorm(width)
+        layer = nn.TransformerEncoderLayer(width, heads, ffn, dropout=0.0, activation="gelu", batch_first=True, norm_first=True)
+        self.encoder = nn.TransformerEncoder(layer, layers, enable_nested_tensor=False)
+        self.head = nn.Linear(width, classes)
+
+    def forward(self, tokens):
+        pos = torch.arange(tokens.shape[1], device=tokens.device)
+        h = self.norm(self.tok(tokens) + self.pos(pos)[None])
+        return self.head(self.encoder(h)[:, 0])
+
+
+class _MixedOp(nn.Module):
+    """Softmax(alpha)-weighted sum of candidate ops (DARTS search space, reduced)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.ops = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, c, 3, padding=1, bias=False), nn.BatchNorm2d(c, track_running_stats=False)),
+            nn.Sequential(nn.Conv2d(c, c, 3, padding=1, groups=c, bias=False), nn.Conv2d(c, c, 1, bias=False),
+                          nn.BatchNorm2d(c, track_running_stats=False)),
+            nn.Sequential(nn.Conv2d(c, c, 5, padding=2, groups=c, bias=False), nn.Conv2d(c, c, 1, bias=False),
+                          nn.BatchNorm2d(c, track_running_stats=False)),
+            nn.AvgPool2d(3, stride=1, padding=1),
+            nn.Identity(),
+        ])
+
+    def forward(self, x, w):
+        return sum(w[i] * op(x) for i, op in enumerate(self.ops))
+
+
+class Supernet(nn.Module):
+    """Mixed-op supernet (BASELINE.json cfg 5 shape): `cells` cells of 4 nodes, every node sums mixed ops
+    over all earlier nodes (14 edges x 5 candidate ops per cell).  forward(x, alphas[cells][14][5])."""
+
+    N_OPS, N_EDGES = 5, 14
+
+    def __init__(self, c=32, cells=4, classes=10):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, c, 3, padding=1, bias=False), nn.BatchNorm2d(c, track_running_stats=False))
+        self.cells = nn.ModuleList([nn.ModuleList([_MixedOp(c) for _ in range(self.N_EDGES)]) for _ in range(cells)])
+        self.fc = nn.Linear(c, classes)
+
+    def forward(self, x, alphas):
+        s0 = s1 = self.stem(x)
+        for cell, a in zip(self.cells, alphas):
+            w = torch.softmax(a, dim=-1)
+            states, e = [s0, s1], 0
+            for _ in range(4):
+                nxt = 0
+                for h in states:
+                    nxt = nxt + cell[e](h, w[e])
+                    e += 1
+                states.append(nxt)
+            s0, s1 = s1, sum(states[2:]) / 4.0
+        return self.fc(s1.mean(dim=(2, 3)))
+
+
+class ArchParams(nn.Module):
+    def __init__(self, cells=4):
+        super().__init__()
+        self.alpha = nn.Parameter(1e-3 * torch.randn(cells, Supernet.N_EDGES, Supernet.N_OPS))
+
+    def forward(self):
+        return self.alpha * 1.0
+
+
 # ---------------------------------------------------------------------------------------------
 # inner losses (what the user writes in ``training_step``)
 # ---------------------------------------------------------------------------------------------
@@ -160,6 +270,16 @@ def make_imaml_loss(upper, reg):
         out = F.cross_entropy(self.module(x), y)
         prox = sum(((p - q) ** 2).sum() for p, q in zip(self.module.parameters(), upper.module.parameters()))
         return out + reg * prox
+
+    return loss
+
+
+def make_supernet_loss(upper, ridge):
+    # examples/neural_architecture_search: the inner loss is the supernet's CE at the current architecture
+    def loss(self, batch):
+        x, y = batch
+        out = F.cross_entropy(self.module(x, upper.fwd()), y)
+        return out + ridge * sum((p * p).sum() for p in self.module.parameters())
 
     return loss
 
