@@ -14,6 +14,9 @@ for p in (ROOT, HERE):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU cases are tiny: intra-op threads only add OpenMP barrier spinning (6x slower on a busy
+    # 8-vCPU container), and one thread fixes torch's CPU reduction order.  BHG_TEST_THREADS overrides.
+    torch.set_num_threads(int(os.environ.get("BHG_TEST_THREADS", "1")))
 
 
 def pytest_collection_modifyitems(config, items):
