@@ -450,19 +450,33 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = 0.f;
     if (m < B) {
-      for (int s = 0; s < splits; ++s) {
-        const float* p = part + (int64_t)s * slab + i * VEC;
-        if (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(p);
-          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        } else {
-          v[0] += p[0];
-        }
-      }
+      if (VEC == 4) {
+        // Batches of 8 slabs: all 8 loads (plus bias and mask) are issued before the first add, so a
+        // reduce costs one or two L2 round trips instead of `splits` dependent ones.  Lanes past the
+        // last slab re-read it (an L1 hit) and are not added; the summation order stays s = 0, 1, ...
+        constexpr int NB = 8;
+        const float* p0 = part + i * VEC;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+        if (mask) mv = *reinterpret_cast<const float4*>(mask + i * VEC);
+        for (int s0 = 0; s0 < splits; s0 += NB) {
+          float4 t[NB];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (bias) v[j] += bias[n + j];
-        if (mask) v[j] *= mask[i * VEC + j];
+          for (int u = 0; u < NB; ++u) {
+            const int s = s0 + u < splits ? s0 + u : splits - 1;
+            t[u] = *reinterpret_cast<const float4*>(p0 + (int64_t)s * slab);
+          }
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            if (s0 + u < splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+          }
+        }
+        v[0] = (v[0] + bv.x) * mv.x; v[1] = (v[1] + bv.y) * mv.y;
+        v[2] = (v[2] + bv.z) * mv.z; v[3] = (v[3] + bv.w) * mv.w;
+      } else {
+        for (int s = 0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
+        if (bias) v[0] += bias[n];
+        if (mask) v[0] *= mask[i];
       }
     }
     if (relu_mask_out) {
@@ -562,7 +576,11 @@ constexpr int kSmallC = 32;
 enum : int { HEAD_JVP = 0, HEAD_COEFF = 1, HEAD_LOGITS = 2 };
 
 // Rz[b][c] = Rh[b].W[c] + h[b].V[c] + cb[c], then Rd_L[b] = sd[b] * (p*Rz - p (p.Rz)).
-// One workgroup per sample row; wave w handles classes w, w+4, ...; lanes stride K (coalesced rows).
+// One workgroup per sample row; wave w handles classes w, w+4, ... (JMAX slots); lanes stride K (coalesced rows).
+// Every load address is clamped instead of guarded and HAS_RH / JMAX are compile-time, so a trip's
+// 2 + 2*JMAX 16-B loads are all in flight together (a runtime `if (c < C)` / `if (Rh)` around a load makes
+// hipcc wait vmcnt(0) after each one: 30 dependent L2 round trips on the critical path of every HVP).
+template <bool HAS_RH, int JMAX>
 __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ Rh, const float* __restrict__ h,
                                                       const float* __restrict__ W, const float* __restrict__ V,
                                                       const float* __restrict__ cb, const float* __restrict__ prob,
@@ -576,86 +594,112 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
   // mode HEAD_COEFF:  aux[b]   = (p - onehot(y)).Rz / B                         (mixed-derivative coefficient)
   // mode HEAD_LOGITS: rd[b][:] = softmax(z), aux[b] = -log softmax(z)[y]        (forward pass; V = W, cb = bias)
-  __shared__ float rz[kSmallC];
+  __shared__ float rz[kSmallC], rdl[kSmallC], dtl[kSmallC], pz[kSmallC];
   const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
   if (b >= B) {
-    if (mode != HEAD_COEFF && threadIdx.x < C) rd[(int64_t)b * C + threadIdx.x] = 0.f;
-    if (mode != HEAD_JVP && threadIdx.x == 0) aux[b] = 0.f;
+    if (mode != HEAD_COEFF && t < C) rd[(int64_t)b * C + t] = 0.f;
+    if (mode != HEAD_JVP && t == 0) aux[b] = 0.f;
     if (mode == HEAD_JVP && rd_prev)
-      for (int k = 4 * threadIdx.x; k < K; k += 1024) *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  const float* rhb = Rh ? Rh + (int64_t)b * K : nullptr;
+  const float* rhb = HAS_RH ? Rh + (int64_t)b * K : nullptr;
   const float* hb = h + (int64_t)b * K;
-  // every wave owns up to 8 classes (w, w+4, ...); lanes take float4 slices of K (K % 4 == 0), so a
-  // 384-wide feature row is covered in two trips with 2 + 2*classes independent 16-B loads each
-  float acc[kSmallC / 4];
+  float acc[JMAX], cbv[JMAX];
+  const float* vrow[JMAX];
+  const float* wrow[JMAX];
 #pragma unroll
-  for (int j = 0; j < kSmallC / 4; ++j) acc[j] = 0.f;
+  for (int j = 0; j < JMAX; ++j) {
+    const int cc = min(wave + 4 * j, C - 1);
+    acc[j] = 0.f;
+    vrow[j] = V + (int64_t)cc * K;
+    wrow[j] = W + (int64_t)cc * K;
+    cbv[j] = cb[cc];
+  }
   for (int k = 4 * lane; k < K; k += 256) {
     const float4 hv = *reinterpret_cast<const float4*>(hb + k);
-    const float4 rv = rhb ? *reinterpret_cast<const float4*>(rhb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_RH) rv = *reinterpret_cast<const float4*>(rhb + k);
+    float4 vv[JMAX], ww[JMAX];
 #pragma unroll
-    for (int j = 0; j < kSmallC / 4; ++j) {
-      const int c = wave + 4 * j;
-      if (c < C) {
-        const float4 vv = *reinterpret_cast<const float4*>(V + (int64_t)c * K + k);
-        float t = acc[j];
-        t = fmaf(hv.x, vv.x, t); t = fmaf(hv.y, vv.y, t); t = fmaf(hv.z, vv.z, t); t = fmaf(hv.w, vv.w, t);
-        if (rhb) {
-          const float4 ww = *reinterpret_cast<const float4*>(W + (int64_t)c * K + k);
-          t = fmaf(rv.x, ww.x, t); t = fmaf(rv.y, ww.y, t); t = fmaf(rv.z, ww.z, t); t = fmaf(rv.w, ww.w, t);
-        }
-        acc[j] = t;
+    for (int j = 0; j < JMAX; ++j) {
+      vv[j] = *reinterpret_cast<const float4*>(vrow[j] + k);
+      if (HAS_RH) ww[j] = *reinterpret_cast<const float4*>(wrow[j] + k);
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      float a = acc[j];
+      a = fmaf(hv.x, vv[j].x, a); a = fmaf(hv.y, vv[j].y, a); a = fmaf(hv.z, vv[j].z, a); a = fmaf(hv.w, vv[j].w, a);
+      if (HAS_RH) {
+        a = fmaf(rv.x, ww[j].x, a); a = fmaf(rv.y, ww[j].y, a); a = fmaf(rv.z, ww[j].z, a); a = fmaf(rv.w, ww[j].w, a);
       }
+      acc[j] = a;
     }
   }
 #pragma unroll
-  for (int j = 0; j < kSmallC / 4; ++j) {
+  for (int j = 0; j < JMAX; ++j) {
     const int c = wave + 4 * j;
     float a = acc[j];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    if (lane == 0 && c < C) rz[c] = a + cb[c];
+    if (lane == 0 && c < C) rz[c] = a + cbv[j];
   }
   __syncthreads();
   if (mode == HEAD_JVP) {
-    __shared__ float rdl[kSmallC], dtl[kSmallC];
-    if (threadIdx.x < C) {
+    float p = 0.f, sdv = 0.f, dt = 0.f;
+    if (t < C) {
+      p = prob[(int64_t)b * C + t];
+      sdv = sd[b];
+      if (rd_prev) dt = delta_top[(int64_t)b * C + t];
+      pz[t] = p * rz[t];
+    }
+    __syncthreads();
+    if (t < C) {
       float dot = 0.f;
-      for (int c = 0; c < C; ++c) dot += prob[(int64_t)b * C + c] * rz[c];
-      const float p = prob[(int64_t)b * C + threadIdx.x];
-      const float v = sd[b] * (p * rz[threadIdx.x] - p * dot);
-      rd[(int64_t)b * C + threadIdx.x] = v;
-      rdl[threadIdx.x] = v;
-      if (rd_prev) dtl[threadIdx.x] = delta_top[(int64_t)b * C + threadIdx.x];
+      for (int c = 0; c < C; ++c) dot += pz[c];
+      const float v = sdv * (p * rz[t] - p * dot);
+      rd[(int64_t)b * C + t] = v;
+      rdl[t] = v;
+      dtl[t] = dt;
     }
     if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
       __syncthreads();
-      for (int k = 4 * threadIdx.x; k < K; k += 1024) {
-        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = 0; c < C; ++c) {
-          const float r = rdl[c], d = dtl[c];
-          const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)c * K + k);
-          const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * K + k);
-          acc2.x += d * v.x + r * w.x; acc2.y += d * v.y + r * w.y;
-          acc2.z += d * v.z + r * w.z; acc2.w += d * v.w + r * w.w;
-        }
+      for (int k = 4 * t; k < K; k += 1024) {
         const float4 mk = *reinterpret_cast<const float4*>(mask_prev + (int64_t)b * K + k);
+        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < C; c0 += 4) {  // 8 independent 16-B loads per batch of 4 classes
+          float4 w[4], v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int cc = min(c0 + u, C - 1);
+            w[u] = *reinterpret_cast<const float4*>(W + (int64_t)cc * K + k);
+            v[u] = *reinterpret_cast<const float4*>(V + (int64_t)cc * K + k);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (c0 + u < C) {
+              const float r = rdl[c0 + u], d = dtl[c0 + u];
+              acc2.x += d * v[u].x + r * w[u].x; acc2.y += d * v[u].y + r * w[u].y;
+              acc2.z += d * v[u].z + r * w[u].z; acc2.w += d * v[u].w + r * w[u].w;
+            }
+          }
+        }
         acc2.x *= mk.x; acc2.y *= mk.y; acc2.z *= mk.z; acc2.w *= mk.w;
         *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
       }
     }
   } else if (mode == HEAD_COEFF) {
-    if (threadIdx.x == 0) {
-      const int y = (int)labels[b];
+    if (t < C) pz[t] = (prob[(int64_t)b * C + t] - (t == (int)labels[b] ? 1.f : 0.f)) * rz[t];
+    __syncthreads();
+    if (t == 0) {
       float acc2 = 0.f;
-      for (int c = 0; c < C; ++c) acc2 += (prob[(int64_t)b * C + c] - (c == y ? 1.f : 0.f)) * rz[c];
+      for (int c = 0; c < C; ++c) acc2 += pz[c];
       aux[b] = acc2 / (float)B;
     }
   } else {  // HEAD_LOGITS: numerically stable log-softmax, one thread per row (C <= 32)
-    if (threadIdx.x == 0) {
+    if (t == 0) {
       float mx = rz[0];
       for (int c = 1; c < C; ++c) mx = fmaxf(mx, rz[c]);
       float sum = 0.f;
@@ -665,6 +709,19 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
       aux[b] = lse - rz[(int)labels[b]];
     }
   }
+}
+
+void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float* h, const float* W, const float* V,
+                         const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
+                         const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
+                         float* rd_prev) {
+  // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
+#define BHG_HEAD(RH, J)                                                                                              \
+  hipLaunchKernelGGL((k_head_forward<RH, J>), dim3(rows), dim3(256), 0, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
+                     mode, labels, aux, delta_top, mask_prev, rd_prev)
+  if (Rh) { if (C <= 12) BHG_HEAD(true, 3); else BHG_HEAD(true, 8); }
+  else    { if (C <= 12) BHG_HEAD(false, 3); else BHG_HEAD(false, 8); }
+#undef BHG_HEAD
 }
 
 // Rd_prev[b][n] = mask[b][n] * sum_c (delta[b][c] V[c][n] + Rd[b][c] W[c][n]);  thread per (b, 4 n).
@@ -830,10 +887,9 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
     if (head && l == L - 1) {
-      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
-                         m->h[l], m->W[l], V, c, m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP,
-                         (const int64_t*)nullptr, (float*)nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
-                         l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr);
+      launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, m->sd,
+                          m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
+                          l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr);
       continue;
     }
     GemmArgs a{};
@@ -973,10 +1029,8 @@ int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* la
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* b = static_cast<const float*>(bias[l]);
     if (l == L - 1) {
-      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, (const float*)nullptr, (const float*)m->h[l],
-                         (const float*)nullptr, m->W[l], b, (const float*)nullptr, (const float*)nullptr,
-                         const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce, (const float*)nullptr,
-                         (const float*)nullptr, (float*)nullptr);
+      launch_head_forward(st, Bp, nullptr, m->h[l], m->W[l] /* unused: no Rh */, m->W[l], b, nullptr, nullptr,
+                          const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce, nullptr, nullptr, nullptr);
       break;
     }
     GemmArgs a{};
@@ -1038,9 +1092,8 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
     if (l == L - 1) {
-      hipLaunchKernelGGL(k_head_forward, dim3(Bp), dim3(256), 0, st, l > 0 ? (const float*)m->Rh[l - 1] : nullptr,
-                         (const float*)m->h[l], m->W[l], V, c, m->prob, (const float*)nullptr, (float*)nullptr, K, N, B,
-                         HEAD_COEFF, labels, coeff, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+      launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, nullptr,
+                          nullptr, K, N, B, HEAD_COEFF, labels, coeff, nullptr, nullptr, nullptr);
       break;
     }
     GemmArgs a{};
