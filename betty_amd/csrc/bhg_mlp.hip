@@ -58,6 +58,13 @@ struct GemmArgs {
 // operand, leading dimension a multiple of 4 -> unconditional 16-B loads, no control flow, so all
 // loads of a step are in flight together) and a branch-free edge form (clamped addresses + selects,
 // scalar loads) for ragged tiles and odd leading dimensions.
+// 16-B load through a native vector type: `regs[i] = *(const float4*)p` on the HIP struct type becomes a
+// memcpy into a private ARRAY that SROA then leaves in scratch memory when nothing else touches the array.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ float4 ld16(const float* __restrict__ p) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float ld_guard(const float* __restrict__ g, int64_t idx, bool ok) {
   const float v = g[ok ? idx : 0];
   return ok ? v : 0.f;
@@ -70,7 +77,7 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ g, int ld, int
   if (fast) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i)
-      regs[i] = *reinterpret_cast<const float4*>(g + (int64_t)(row0 + (t >> 3) + 32 * i) * ld + k0 + 4 * (t & 7));
+      regs[i] = ld16(g + (int64_t)(row0 + (t >> 3) + 32 * i) * ld + k0 + 4 * (t & 7));
   } else {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -103,8 +110,7 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ g, int ld, int
   if (fast) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i)
-      regs[i] = *reinterpret_cast<const float4*>(g + (int64_t)(k0 + (t / F4_PER_K) + K_PER_PASS * i) * ld + row0 +
-                                                 4 * (t % F4_PER_K));
+      regs[i] = ld16(g + (int64_t)(k0 + (t / F4_PER_K) + K_PER_PASS * i) * ld + row0 + 4 * (t % F4_PER_K));
   } else {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -139,8 +145,12 @@ __device__ __forceinline__ float frag(const float* __restrict__ lds, int row, in
 
 // C[M][N] (+)= sum over pairs  A_pair (M x K) * B_pair (K x N), operands in layouts LA / LB.
 // grid = (ceil(N/64), ceil(M/128), splits), block = 256 (4 waves: 2 along M x 2 along N).
-template <int LA, int LB, int TN>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+// FAST: every tile is interior (M % 128 == 0, N % TN == 0, K % 32 == 0, leading dimensions % 4 == 0; checked by
+// launch_gemm).  The instance then has NO edge path: with the ragged-tile branches in the loop hipcc puts an
+// `s_waitcnt vmcnt(0)` at the top of every step (the control-flow join), which serialises the two-stage
+// register prefetch — step s+1's loads had to land BEFORE step s's MFMAs instead of behind them.
+template <int LA, int LB, int TN, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 3 : 2, TN == 32 ? 3 : 2))) void k_gemm(GemmArgs a) {
   static_assert(TN == 64 || TN == 32, "tile width");
   constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
   constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
@@ -174,27 +184,35 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   // Two register stages: the global loads of step s+2 are issued before the MFMAs of step s, so every
-  // load has two compute phases (plus the other resident workgroups) to land.
+  // load has two compute phases (plus the other resident workgroups) to land.  The loop body is kept free
+  // of control flow (a step index past the end re-loads the last tile, which is never used): with branches
+  // in the body hipcc shuttles all 32 accumulator registers AGPR -> VGPR -> AGPR around every step and
+  // drains the load queue at each join.
   float4 ra0[kTM / 32], rb0[TN / 32], ra1[kTM / 32], rb1[TN / 32];
+  const GemmPair pr0 = a.pr[0];
+  const GemmPair pr1 = a.pr[a.pairs > 1 ? 1 : 0];   // operand bases live in SGPRs, not re-fetched per step
   auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32]) {
-    const int pi = step / nsteps_pair;
-    const int k0 = kbeg + (step - pi * nsteps_pair) * kTK;
-    const GemmPair& pr = a.pr[pi];
-    const bool kfull = k0 + kTK <= kend;  // workgroup-uniform
-    const bool fa = kfull && m0 + kTM <= a.M && (pr.lda & 3) == 0;
-    const bool fb = kfull && n0 + TN <= a.N && (pr.ldb & 3) == 0;
-    if (LA == LAYOUT_KC) load_kc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
-    else load_rc<kTM>(pr.A, pr.lda, m0, a.M, k0, kend, fa, ra);
-    if (LB == LAYOUT_KC) load_kc<TN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
-    else load_rc<TN>(pr.B, pr.ldb, n0, a.N, k0, kend, fb, rb);
+    step = min(step, nsteps - 1);
+    const bool second = step >= nsteps_pair;          // workgroup-uniform
+    const int k0 = kbeg + (step - (second ? nsteps_pair : 0)) * kTK;
+    const float* gA = second ? pr1.A : pr0.A;
+    const float* gB = second ? pr1.B : pr0.B;
+    const int lda = second ? pr1.lda : pr0.lda, ldb = second ? pr1.ldb : pr0.ldb;
+    const bool kfull = FAST || k0 + kTK <= kend;
+    const bool fa = FAST || (kfull && m0 + kTM <= a.M && (lda & 3) == 0);
+    const bool fb = FAST || (kfull && n0 + TN <= a.N && (ldb & 3) == 0);
+    if (LA == LAYOUT_KC) load_kc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
+    else load_rc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
+    if (LB == LAYOUT_KC) load_kc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
+    else load_rc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
   };
   auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], const float4 (&rb)[TN / 32]) {
     if (LA == LAYOUT_KC) store_kc<kTM>(sA[buf], ra); else store_rc<kTM>(sA[buf], ra);
     if (LB == LAYOUT_KC) store_kc<TN>(sB[buf], rb); else store_rc<TN>(sB[buf], rb);
   };
-  auto compute = [&](int step) {
-    const float* A = sA[step & 1];
-    const float* B = sB[step & 1];
+  auto compute = [&](int buf) {
+    const float* A = sA[buf];
+    const float* B = sB[buf];
     // Lane l works on k = 8*k8 + 4*(l>>5) + t, t = 0..3, in the t-th MFMA of each group of four: any
     // assignment is valid as long as the A and the B fragment of a lane refer to the same k.  K-contiguous
     // tiles therefore deliver four k per lane with ONE ds_read_b128.  (The tail of a K range is zero-filled
@@ -229,25 +247,32 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
           acc[i * KI + (t & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i * KI + (t & 1)], 0, 0, 0);
     }
   };
-  // body for one step whose NEXT step's data sits in (ran, rbn) and whose step+2 loads go to (raf, rbf)
-  auto body = [&](int step, float4 (&raf)[kTM / 32], float4 (&rbf)[TN / 32], const float4 (&ran)[kTM / 32],
-                  const float4 (&rbn)[TN / 32]) {
-    if (step + 2 < nsteps) gload(step + 2, raf, rbf);
-    compute(step);
-    if (step + 1 < nsteps) lstore((step + 1) & 1, ran, rbn);
-    __syncthreads();
-  };
 
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
   if (nsteps > 0) {
     gload(0, ra0, rb0);
-    if (nsteps > 1) gload(1, ra1, rb1);
+    gload(1, ra1, rb1);
     lstore(0, ra0, rb0);
+    __syncthreads();
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+      // Per step: issue the loads of tile s+2, hand tile s+1 (loaded a step ago) to the OTHER LDS buffer, then
+      // run this tile's MFMAs — the LDS stores complete in the shadow of the MFMAs, so the barrier at the end
+      // of the step finds them done.  (The buffer being written was last read before the previous barrier.)
+      gload(step + 2, ra0, rb0);   // even step: tile in buffer 0, next tile parked in stage 1
+      lstore(1, ra1, rb1);
+      SCHED_FENCE();
+      compute(0);
+      __syncthreads();
+      gload(step + 3, ra1, rb1);   // odd step: tile in buffer 1, next tile parked in stage 0
+      lstore(0, ra0, rb0);
+      SCHED_FENCE();
+      compute(1);
+      __syncthreads();
+    }
+    if (step < nsteps) compute(0);  // odd count: the last tile was stored to buffer 0 by the loop's second half
   }
-  __syncthreads();
-  for (int step = 0; step < nsteps; step += 2) {
-    body(step, ra0, rb0, ra1, rb1);      // step even: next (odd) data in stage 1, step+2 loads into stage 0
-    if (step + 1 < nsteps) body(step + 1, ra1, rb1, ra0, rb0);
-  }
+#undef SCHED_FENCE
 
   // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)split * a.out_rows * a.ldo : 0);
@@ -809,8 +834,17 @@ __global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ pro
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a, int tn, hipStream_t st) {
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
-  if (tn == 64) hipLaunchKernelGGL((k_gemm<LA, LB, 64>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_gemm<LA, LB, 32>), grid, dim3(256), 0, st, a);
+  bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
+  for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+  static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;   // A/B switch (debug)
+  if (no_fast) fast = false;
+  if (tn == 64) {
+    if (fast) hipLaunchKernelGGL((k_gemm<LA, LB, 64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm<LA, LB, 64, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_gemm<LA, LB, 32, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm<LA, LB, 32, false>), grid, dim3(256), 0, st, a);
+  }
 }
 inline int skinny_tile_n() {
   static const int tn = getenv("BHG_MLP_TN") ? atoi(getenv("BHG_MLP_TN")) : 32;  // 32 measured +2 % over 64
