@@ -304,6 +304,9 @@ constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging
 // Each operand pair is cut in two K halves => up to 4 pipeline stages; a stage is ONE round of global
 // loads (all in flight together) parked in registers while the previous stage's MFMAs run from the
 // single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
+// FAST: all tiles interior and 16-B aligned (checked by the launcher): no ragged path, loads unconditional with
+// clamped row index and a 0/1 multiplier (same reasons as k_gemm's FAST instance).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = a.K;
@@ -326,11 +329,15 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
 
   float4 ra[kOA], rb[kOB];
   // stage s: pair s / nsp, K rows [ (s % nsp)*Kh, min(K, (s % nsp)*Kh + Kh) )
+  const GemmPair pr0 = a.pr[0];
+  const GemmPair pr1 = a.pr[a.pairs > 1 ? 1 : 0];
   auto gload = [&](int stage) {
-    const GemmPair& pr = a.pr[stage / nsp];
-    const int kb = (stage % nsp) * Kh;
-    const bool fa = m0 + kTM <= a.M && (pr.lda & 3) == 0;  // workgroup-uniform
-    const bool fb = n0 + kTN <= a.N && (pr.ldb & 3) == 0;
+    const bool second = stage >= nsp;             // workgroup-uniform
+    const GemmPair pr = {second ? pr1.A : pr0.A, second ? pr1.B : pr0.B, second ? pr1.lda : pr0.lda,
+                         second ? pr1.ldb : pr0.ldb};
+    const int kb = (stage - (second ? nsp : 0)) * Kh;
+    const bool fa = FAST || (m0 + kTM <= a.M && (pr.lda & 3) == 0);  // workgroup-uniform
+    const bool fb = FAST || (n0 + kTN <= a.N && (pr.ldb & 3) == 0);
 #pragma unroll
     for (int i = 0; i < kOA; ++i) {   // A stage: 32 float4 per k-row, 8 k-rows per pass
       const int kl = (t >> 5) + 8 * i;
@@ -339,8 +346,9 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
       const bool kok = kl < Kh && k < K;
       const int64_t base = (int64_t)(kok ? k : 0) * pr.lda + r;
       if (fa) {
-        const float4 v = *reinterpret_cast<const float4*>(pr.A + base);
-        ra[i] = kok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = ld16(pr.A + base);
+        const float mz = kok ? 1.f : 0.f;   // multiplier, not a select: hipcc turns the select into a branch around the load
+        ra[i] = make_float4(v.x * mz, v.y * mz, v.z * mz, v.w * mz);
       } else {
         ra[i].x = ld_guard(pr.A, base, kok && r < a.M);
         ra[i].y = ld_guard(pr.A, base + 1, kok && r + 1 < a.M);
@@ -356,8 +364,9 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
       const bool kok = kl < Kh && k < K;
       const int64_t base = (int64_t)(kok ? k : 0) * pr.ldb + r;
       if (fb) {
-        const float4 v = *reinterpret_cast<const float4*>(pr.B + base);
-        rb[i] = kok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = ld16(pr.B + base);
+        const float mz = kok ? 1.f : 0.f;
+        rb[i] = make_float4(v.x * mz, v.y * mz, v.z * mz, v.w * mz);
       } else {
         rb[i].x = ld_guard(pr.B, base, kok && r < a.N);
         rb[i].y = ld_guard(pr.B, base + 1, kok && r + 1 < a.N);
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     }
   };
   auto compute = [&](int stage) {
-    const int kb = (stage % nsp) * Kh;
+    const int kb = (stage >= nsp ? stage - nsp : stage) * Kh;
     const int kvalid = min(Kh, K - kb);           // rows of this stage that carry data (rest is zero)
     const int nkp = kvalid > 0 ? (kvalid + 1) / 2 : 0;
     int kp = 0;
@@ -412,11 +421,11 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
   gload(0);
   lstore();
   for (int stage = 0; stage < nstages; ++stage) {
-    if (stage + 1 < nstages) gload(stage + 1);  // in flight during this stage's MFMAs
+    gload(min(stage + 1, nstages - 1));         // in flight during this stage's MFMAs (the last one re-loads itself: unused)
     __syncthreads();                            // this stage's tile is complete in LDS
     compute(stage);
     __syncthreads();                            // everyone is done reading it
-    if (stage + 1 < nstages) lstore();
+    lstore();                                   // (after the last stage: a dead store, overwritten by the C staging below)
   }
   __syncthreads();  // LDS is reused as the C staging tile below
 
@@ -436,10 +445,10 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     const int row = (t >> 4) + 16 * i;
     const int c4 = 4 * (t & 15);
     const int grow = m0 + row, gcol = n0 + c4;
-    if (grow >= a.M || gcol >= a.N) continue;
+    if (!FAST && (grow >= a.M || gcol >= a.N)) continue;
     float4 v = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
     float* dst = a.out + (int64_t)grow * a.ldo + gcol;
-    if (vec_ok && gcol + 4 <= a.N) {
+    if (FAST || (vec_ok && gcol + 4 <= a.N)) {
       if (a.addend) {
         const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)grow * a.ldo + gcol);
         v.x += a.addend_scale * ad.x; v.y += a.addend_scale * ad.y;
@@ -953,8 +962,10 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     BHG_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming | hipEventDisableSystemFence));
     BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
-    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer),
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // > 64 KiB dynamic LDS
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   auto launch_outer = [&](int l, hipStream_t s) {
     const int Mo = m->dims[l + 1], No = m->dims[l];
@@ -979,7 +990,11 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
     if (lds < lds_c) lds = lds_c;
     dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
-    hipLaunchKernelGGL(k_outer, grid, dim3(256), lds, s, a);
+    bool fast = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
+    for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
+    if (fast && !no_fast) hipLaunchKernelGGL(k_outer<true>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_outer<false>, grid, dim3(256), lds, s, a);
   };
   for (int l = L - 1; l >= 1; --l) {
     // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
