@@ -586,14 +586,20 @@ __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
   const int col = ((int)blockIdx.x - a.blk0[l]) * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   const float* __restrict__ rd = a.rd[l];
+  const int colc = col < N ? col : N - 1;   // clamped, not guarded: all loads of a batch are in flight together
   float s0 = 0.f, s1 = 0.f;
-  if (col < N) {
-    int b = rg;
-    for (; b + 4 < a.B; b += 8) {  // two independent accumulators for load ILP
-      s0 += rd[(int64_t)b * N + col];
-      s1 += rd[(int64_t)(b + 4) * N + col];
+  for (int b0 = rg; b0 < a.B; b0 += 32) {   // 8 batch rows per trip: b0, b0+4, ..., b0+28
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = b0 + 4 * u;
+      v[u] = rd[(int64_t)(bb < a.B ? bb : a.B - 1) * N + colc];
     }
-    if (b < a.B) s0 += rd[(int64_t)b * N + col];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      if (b0 + 4 * u < a.B) s0 += v[u];
+      if (b0 + 4 * (u + 1) < a.B) s1 += v[u + 1];
+    }
   }
   red[rg][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
@@ -788,6 +794,7 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
 
 // G[c][n] = sum_b (Rd[b][c] h[b][n] + delta[b][c] Rh[b][n]) + rho2 V[c][n];  block = 64 n x 4 batch groups,
 // fixed-order combine through LDS (deterministic).
+template <bool HAS_RH>
 __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd, const float* __restrict__ h,
                                                     const float* __restrict__ delta, const float* __restrict__ Rh,
                                                     const float* __restrict__ V, float rho2, float* __restrict__ out,
@@ -795,29 +802,27 @@ __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd
   __shared__ float red[4][64];
   const int c = blockIdx.y;
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int nc = n < N ? n : N - 1;   // clamped, not guarded (see k_head_forward)
   const int g = threadIdx.x >> 6;
   float acc = 0.f;
-  if (n < N) {
-    int b = g;
-    for (; b + 28 < B; b += 32) {  // 8 batch rows per trip: 32 independent loads before the fma chain
-      float r[8], hh[8], d[8], rr[8];
+  for (int b = g; b < B; b += 32) {  // 8 batch rows per trip: 16 / 32 independent loads before the fma chain
+    float r[8], hh[8], d[8], rr[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int bb = b + 4 * u;
-        r[u] = rd[(int64_t)bb * C + c];
-        hh[u] = h[(int64_t)bb * N + n];
-        d[u] = Rh ? delta[(int64_t)bb * C + c] : 0.f;
-        rr[u] = Rh ? Rh[(int64_t)bb * N + n] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc = fmaf(r[u], hh[u], acc);
-        acc = fmaf(d[u], rr[u], acc);
+    for (int u = 0; u < 8; ++u) {
+      const int bb = b + 4 * u < B ? b + 4 * u : B - 1;
+      r[u] = rd[(int64_t)bb * C + c];
+      hh[u] = h[(int64_t)bb * N + nc];
+      if (HAS_RH) {
+        d[u] = delta[(int64_t)bb * C + c];
+        rr[u] = Rh[(int64_t)bb * N + nc];
       }
     }
-    for (; b < B; b += 4) {
-      acc = fmaf(rd[(int64_t)b * C + c], h[(int64_t)b * N + n], acc);
-      if (Rh) acc = fmaf(delta[(int64_t)b * C + c], Rh[(int64_t)b * N + n], acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b + 4 * u < B) {
+        acc = fmaf(r[u], hh[u], acc);
+        if (HAS_RH) acc = fmaf(d[u], rr[u], acc);
+      }
     }
   }
   red[g][threadIdx.x & 63] = acc;
@@ -971,9 +976,14 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     const int Mo = m->dims[l + 1], No = m->dims[l];
     const float* V = static_cast<const float*>(dir[2 * l]);
     if (head && l == L - 1) {
-      hipLaunchKernelGGL(k_head_outer, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l], m->h[l],
-                         m->delta[l], l > 0 ? (const float*)m->Rh[l - 1] : nullptr, V, rho2,
-                         static_cast<float*>(out[2 * l]), No, Mo, B);
+      if (l > 0)
+        hipLaunchKernelGGL(k_head_outer<true>, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l],
+                           m->h[l], m->delta[l], (const float*)m->Rh[l - 1], V, rho2, static_cast<float*>(out[2 * l]), No,
+                           Mo, B);
+      else
+        hipLaunchKernelGGL(k_head_outer<false>, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l],
+                           m->h[l], m->delta[l], (const float*)nullptr, V, rho2, static_cast<float*>(out[2 * l]), No, Mo,
+                           B);
       return;
     }
     GemmArgs a{};
