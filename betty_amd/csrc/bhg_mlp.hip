@@ -968,8 +968,16 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   // H(W_l) only needs Rd_l and Rh_{l-1}; the R-backward chain that produces Rd_{l-1} is independent of
   // it.  The many-workgroup outer products therefore run on a library-owned side stream and fill the
   // CUs the short, latency-bound split-K kernels of the backward chain leave idle.
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS], ev_join = nullptr;
+  // one side stream + event set per device (streams and events belong to the device they were created on)
+  struct SideState { hipStream_t side; hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS]; hipEvent_t ev_join; };
+  static SideState per_device[64];
+  int dev = 0;
+  BHG_HIP_CHECK(hipGetDevice(&dev));
+  BHG_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+  SideState& ss = per_device[dev];
+  hipStream_t& side = ss.side;
+  hipEvent_t* ev_rd = ss.ev_rd;
+  hipEvent_t& ev_join = ss.ev_join;
   if (!side) {
     BHG_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming | hipEventDisableSystemFence));

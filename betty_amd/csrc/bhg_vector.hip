@@ -637,18 +637,26 @@ __global__ __launch_bounds__(kThreads) void k_sama_adam(PtrTab tv, PtrTab tg, Pt
 
 inline int grid_for(int n_chunks) { return n_chunks < kMaxBlocks ? (n_chunks > 0 ? n_chunks : 1) : kMaxBlocks; }
 
-int g_num_cus = -1;
-int num_cus() {
-  if (g_num_cus >= 0) return g_num_cus;
+// Per-device caches (a process may drive several GPUs): index = current HIP device, -1 = not probed yet.
+constexpr int kMaxDevices = 64;
+int current_device() {
   int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return dev >= 0 && dev < kMaxDevices ? dev : -1;
+}
+int num_cus() {
+  static int cus[kMaxDevices];
+  static bool init = false;
+  if (!init) { for (int i = 0; i < kMaxDevices; ++i) cus[i] = -1; init = true; }
+  const int dev = current_device();
+  if (dev < 0) return 0;
+  if (cus[dev] >= 0) return cus[dev];
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     (void)hipGetLastError();
-    g_num_cus = 0;
-  } else {
-    g_num_cus = prop.multiProcessorCount;
+    return cus[dev] = 0;
   }
-  return g_num_cus;
+  return cus[dev] = prop.multiProcessorCount;
 }
 
 }  // namespace
@@ -822,7 +830,12 @@ int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMax; }
 // `num_cus()` workgroups are not co-resident (CU masking, a shared GPU, a partitioned device) the barrier
 // times out, the flag is read back and BHG_CG_AUTO never picks the resident variant in this process.
 int bhg_cg_resident_ok(void) {
-  static int cached = -1;
+  static int per_device[kMaxDevices];
+  static bool init = false;
+  if (!init) { for (int i = 0; i < kMaxDevices; ++i) per_device[i] = -1; init = true; }
+  const int dev = current_device();
+  if (dev < 0) return 0;
+  int& cached = per_device[dev];
   if (cached >= 0) return cached;
   const int G = num_cus();
   if (G <= 0) return cached = 0;
