@@ -754,3 +754,28 @@ def test_cfg5_supernet_neumann20(be):
     print(f"supernet neumann20: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
     tol = max(1e-4, 20 * noise)
     assert rel <= tol and mx <= 10 * tol, (rel, mx, noise)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's metric workload at full size, end to end: the product path (analytic MFMA HVP + fused
+# recurrence) against the reference's algorithm on the same device tensors (oracle restatement: opaque
+# double backward + per-tensor ATen recurrence)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo,K", [("cg", 20), ("neumann", 10)])
+def test_cfg2_metric_workload_end_to_end(algo, K, be):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    import bench
+
+    curr, prev, vector = bench.build(torch.device(DEV), seed=0, K=K, algo=algo)
+    assert sum(p.numel() for p in curr.parameters()) == 10_034_826
+    want = getattr(horc, algo)(vector, curr, prev, False)
+    again = getattr(horc, algo)(vector, curr, prev, False)
+    noise, _ = rel_err(_np(again), _np(want))
+    bench.declare_structure(curr, "hip")
+    got = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
+    rel, mx = rel_err(_np(got), _np(want))
+    print(f"cfg2 full size {algo} K={K}: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
+    tol = max(1e-4, 20 * noise)     # rtol 1e-4 (north_star)
+    assert rel <= tol and mx <= 10 * tol, (algo, rel, mx, noise)
