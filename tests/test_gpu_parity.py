@@ -344,6 +344,42 @@ def test_neumann_full_size_closed_form(be):
         assert (pv - want).abs().max().item() <= 2e-6 * want.abs().max().item()
 
 
+def test_recurrences_at_roberta_scale_closed_form(be):
+    """Maximum size on the list (BASELINE cfg 4: 124 M elements in 12 x 16 + 5 tensors, far beyond the resident
+    kernel's capacity): streaming CG on a 4-eigenvalue diagonal Hessian is exact after 4 iterations, Neumann
+    matches the geometric-series closed form."""
+    layer = [768 * 768, 768] * 4 + [3072 * 768, 3072, 768 * 3072, 768] + [768] * 4
+    sizes = [50265 * 768, 514 * 768, 768, 768] + layer * 12 + [768 * 2, 2]
+    assert sum(sizes) > 120_000_000
+    gen = torch.Generator().manual_seed(8)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    lay = be.layout(vec)
+    assert lay.n_chunks > be.lib.bhg_cg_resident_capacity_chunks()
+    dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
+    diag = [dvals[torch.arange(n, device=DEV) % 4] for n in sizes]
+    x, r, p = lay.state(3)
+    be.cg_init(lay, vec, x, r, p)
+    for k in range(4):
+        hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
+        be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == 3 else 0.0))   # AUTO -> stream
+        del hv
+    for xv, v, d in zip(lay.views(x, vec), vec, diag):
+        want = -(v / d)
+        assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    v_, p_ = lay.state(2)
+    be.neumann_init(lay, vec, v_, p_)
+    K, alpha = 6, 0.1
+    for k in range(K):
+        hv = [d * t for d, t in zip(diag, lay.views(v_, vec))]
+        be.neumann_step(lay, hv, v_, p_, alpha, out_scale=(-alpha if k == K - 1 else 0.0))
+        del hv
+    for pv, vv, d in zip(lay.views(p_, vec), vec, diag):
+        q = 1.0 - alpha * d.double()
+        geo = sum(q**j for j in range(K + 1))
+        want = (-alpha * geo * vv.double()).float()
+        assert (pv - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
 def test_product_refuses_cpu_tensors(be):
     t = [torch.randn(10)]
     lay = be.layout([torch.randn(10, device=DEV)])
