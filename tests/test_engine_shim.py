@@ -5,10 +5,14 @@
     regression HPO, 2000 iterations, unroll 100, final outer loss < 0.48) passes with cg / neumann /
     darts — on CPU through the test-only checker backend, on the GPU through the HIP kernels.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 from betty_amd import Config
 from betty_amd.engine import Engine, EngineConfig
@@ -207,3 +211,48 @@ def test_autocast_precision_runs_on_gpu(algo):
     assert outer.count == 5
     lam = outer.module.w.detach()
     assert torch.isfinite(lam).all() and (lam - 1.0).abs().max() > 1e-4
+
+
+_RCCL_WORLD1 = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # RCCL
+import zoo
+from conftest import load_golden, golden_list, rel_err
+from torch.nn.parallel import DistributedDataParallel as DDP
+from betty_amd import Config, hypergradient as hg
+from betty_amd.distributed import exchange_async
+case = zoo.CASE_BY_NAME["reweight_cg20"]
+inputs, outputs = load_golden(case.family)
+curr, prev, vector = zoo.build_case(case, inputs, Config, device="cuda:0")
+prev.fwd = DDP(prev.module, device_ids=[0], gradient_as_bucket_view=True, find_unused_parameters=True)  # problem.py:220-224
+assert hg.cg(vector, curr, prev, True) is None          # sync=True: backward -> DDP reducer -> RCCL all-reduce
+got = [p.grad.detach().cpu().numpy() for p in prev.trainable_parameters()]
+rel, _ = rel_err(got, golden_list(outputs, case.name, "sync32"))
+local = hg.cg(vector, curr, prev, False)
+h = exchange_async(local)                               # one flat asynchronous all-reduce on the comm stream
+avg = h.wait()
+rel2, _ = rel_err([t.cpu().numpy() for t in avg], [t.cpu().numpy() for t in local])
+torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", rel, rel2)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_backend_world_size_1():
+    """The N > 1 code path on the real collective library: process group "nccl" (= RCCL on ROCm), DDP-wrapped upper
+    module, sync=True hop and the flat asynchronous exchange — with one rank, which is all a 1-GPU box can hold."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_WORLD1.format(root=root, tests=HERE)], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RCCL_OK")][-1].split()
+    assert float(line[1]) <= 1e-4, line       # vs the reference's sync=True golden
+    assert float(line[2]) <= 1e-7, line       # mean over one rank = the local result
