@@ -799,19 +799,32 @@ def test_cfg5_supernet_neumann20(be):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("algo,K", [("cg", 20), ("neumann", 10)])
 def test_cfg2_metric_workload_end_to_end(algo, K, be):
+    """Three runs of the same algorithm on the same inputs: fp64 on the device (the truth), the reference's
+    algorithm in fp32 on the device (oracle restatement on ATen), and the product path.  Twenty fp32 CG iterations
+    on this 10 M-parameter problem sit ~9e-5 from the truth whoever runs them, and ATen's double backward is not
+    reproducible between calls of one process (the reference-fp32 run measured 7e-5 ... 2.7e-4 from the truth),
+    so the product is held to the truth, not to one draw of the reference: within rtol 1e-4 (north_star) or no
+    more than twice as far from it as the reference's own fp32 run."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hypergrad_oracle as horc
 
     import bench
 
-    curr, prev, vector = bench.build(torch.device(DEV), seed=0, K=K, algo=algo)
+    dev = torch.device(DEV)
+    curr64, prev64, vec64 = bench.build(dev, seed=0, dtype=torch.float64, K=K, algo=algo)
+    truth = [t.detach().clone() for t in getattr(horc, algo)(vec64, curr64, prev64, False)]
+    del curr64, prev64, vec64
+    curr, prev, vector = bench.build(dev, seed=0, K=K, algo=algo)
     assert sum(p.numel() for p in curr.parameters()) == 10_034_826
     want = getattr(horc, algo)(vector, curr, prev, False)
-    again = getattr(horc, algo)(vector, curr, prev, False)
-    noise, _ = rel_err(_np(again), _np(want))
     bench.declare_structure(curr, "hip")
     got = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
-    rel, mx = rel_err(_np(got), _np(want))
-    print(f"cfg2 full size {algo} K={K}: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
-    tol = max(1e-4, 20 * noise)     # rtol 1e-4 (north_star)
-    assert rel <= tol and mx <= 10 * tol, (algo, rel, mx, noise)
+    again = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b), "the product path must be bit-reproducible"
+    e_ref, _ = rel_err(_np(want), _np(truth))
+    e_got, _ = rel_err(_np(got), _np(truth))
+    rel, _ = rel_err(_np(got), _np(want))
+    print(f"cfg2 full size {algo} K={K}: vs fp64 truth: reference-fp32 {e_ref:.2e}, hip {e_got:.2e}; hip vs reference-fp32 {rel:.2e}")
+    assert e_got <= max(1e-4, 2.0 * e_ref), (algo, e_got, e_ref)
+    assert rel <= max(1e-4, 2.0 * (e_ref + e_got)), (algo, rel, e_ref, e_got)
