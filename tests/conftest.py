@@ -28,6 +28,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _poison_the_gpu_allocator():
+    """Fill ~6 GB of PyTorch's caching allocator with NaN and free it before the first GPU test, so every
+    `torch.empty` the suite (or the package) does afterwards starts as NaN instead of the zeros a fresh process
+    gets from the driver: a kernel that reads a buffer it was supposed to fill first shows up as a failure here
+    instead of passing by luck."""
+    if torch.cuda.is_available():
+        junk = [torch.full((256 << 20,), float("nan"), device="cuda:0") for _ in range(6)]
+        junk += [torch.full((n,), float("nan"), device="cuda:0") for n in (1 << 10, 1 << 14, 1 << 18, 1 << 22) for _ in range(8)]
+        del junk
+    yield
+
+
 _GOLDEN_CACHE = {}
 
 
