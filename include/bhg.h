@@ -2,7 +2,7 @@
  * bhg.h — C ABI of the MI355X-native hypergradient backend (libbhg.so).
  *
  * This is the drop-in boundary for the implicit-differentiation hot path of
- * leopard-ai/betty (`betty/hypergradient/{cg,neumann,darts}.py`).  The reference
+ * leopard-ai/betty (`betty/hypergradient/{cg,neumann,darts,sama}.py`).  The reference
  * has no FFI of its own (it is pure Python on torch); the entry points below are
  * what a binding for this path has to call: each one replaces a run of per-tensor
  * ATen launches in the reference and cites the lines it replaces.
