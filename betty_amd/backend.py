@@ -146,7 +146,7 @@ class HipBackend:
 
     # -- DARTS ---------------------------------------------------------------------------------------
     def darts_eps(self, layout, vector, R: float):
-        """Returns (eps_f32, eps_f64) as 0-dim device tensors; no host synchronisation."""
+        """Returns (eps_f32, eps_f64, sum_of_squares_f64) as 0-dim device tensors; no host synchronisation."""
         ts = self._prep(vector, layout)
         tab, _keep = self._table(ts)
         out = torch.empty(2, dtype=torch.float64, device=layout.device)
@@ -156,7 +156,7 @@ class HipBackend:
                                    out.data_ptr(), eps32.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
             "bhg_darts_eps",
         )
-        return eps32[0], out[1]
+        return eps32[0], out[1], out[0]
 
     def sama_adam_precondition(self, layout, vector, last_grad, exp_avg, exp_avg_sq, out_flat, beta1, beta2, eps, lr) -> None:
         tabs, keep = [], []

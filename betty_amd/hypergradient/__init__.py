@@ -23,10 +23,9 @@ def get_grads(loss, path, retain_graph, do_sync):
     """Hypergradient of ``loss`` along ``path`` = [upper, lower_1, ..., upper]
     (__init__.py:22-39): direct gradient w.r.t. the first lower problem's parameters, then one
     best-response-Jacobian product per hop, right to left; only the last hop may sync."""
-    if getattr(path[0], "_strategy", "default") == "fsdp":
-        raise NotImplementedError("betty_amd: the FSDP strategy is out of scope")
+    is_fsdp = getattr(path[0], "_strategy", "default") == "fsdp"   # __init__.py:23
     lower = path[1].meta_trainable_parameters()
-    jvp = grad(loss, lower, retain_graph=retain_graph, allow_unused=True)
+    jvp = grad(loss, lower, retain_graph=retain_graph, allow_unused=True, is_fsdp=is_fsdp)
     jvp = replace_none_with_zero(jvp, lower)
     for i in range(1, len(path) - 1):
         jvp_fn_type = path[i].config.type

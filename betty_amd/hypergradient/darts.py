@@ -15,8 +15,7 @@ from .utils import grad, replace_none_with_zero
 
 def darts(vector, curr, prev, sync):
     config = curr.config
-    if getattr(curr, "_strategy", "default") == "fsdp":
-        raise NotImplementedError("betty_amd: the FSDP strategy (darts.py:31-34) is out of scope")
+    is_fsdp = getattr(curr, "_strategy", "default") == "fsdp"
     be = get_backend()
     vector = list(vector)
     weights = [w.data for w in curr.meta_trainable_parameters()]
@@ -24,7 +23,17 @@ def darts(vector, curr, prev, sync):
 
     layout = be.layout(vector)
     # eps = R / (||v|| + 1e-15)   (darts.py:29-35), 0-dim device tensors
-    eps32, eps64 = be.darts_eps(layout, vector, float(config.darts_alpha))
+    eps32, eps64, sumsq = be.darts_eps(layout, vector, float(config.darts_alpha))
+    if is_fsdp:
+        # darts.py:31-34: every rank holds a shard of v; eps uses the norm of the whole vector.  Same fp32
+        # steps as the reference: local norm -> square -> all-reduce(SUM) -> sqrt -> + 1e-15 -> R / .
+        import torch.distributed as dist
+
+        sq = sumsq.sqrt().to(torch.float32).pow(2)
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM)
+        norm = sq.sqrt().add_(1e-15)
+        eps64 = float(config.darts_alpha) / norm.to(torch.float64)
+        eps32 = eps64.to(torch.float32)
     two_eps = (2.0 * eps64).to(torch.float32)  # the reference divides fp32 tensors by the Python float 2*eps
 
     # w <- w + eps*v   (darts.py:37-38)

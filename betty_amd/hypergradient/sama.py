@@ -86,7 +86,7 @@ def sama(vector, curr, prev, sync):
     upper = prev.trainable_parameters()
 
     layout, pv = precondition(vector, curr, be)  # sama.py:25
-    eps32, eps64 = be.darts_eps(layout, pv, float(config.sama_adam_alpha))  # sama.py:26-27
+    eps32, eps64, _ = be.darts_eps(layout, pv, float(config.sama_adam_alpha))  # sama.py:26-27
     two_eps = (2.0 * eps64).to(torch.float32)
 
     be.axpy_multi(layout, weights, pv, eps32, 1.0)  # sama.py:29-30

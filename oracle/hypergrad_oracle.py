@@ -51,7 +51,20 @@ def zeros_for_missing(tensors, reference):
 
 
 # -- betty/hypergradient/utils.py:5-21 (non-FSDP branch, 18-21) -----------------------------------
-def first_order_grad(loss, parameters, retain_graph=False, allow_unused=False):
+def first_order_grad(loss, parameters, retain_graph=False, allow_unused=False, through_grad_field=False):
+    """hypergradient/utils.py:5-21.  ``through_grad_field`` is the FSDP branch (9-17): the gradient is read
+    off ``.grad`` around a ``backward`` and the previous ``.grad`` is put back."""
+    if through_grad_field:
+        def current(p):
+            return p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+
+        saved = [current(p) for p in parameters]
+        torch.autograd.backward(loss, retain_graph=retain_graph, inputs=parameters)
+        deltas = []
+        for p, old in zip(parameters, saved):
+            deltas.append(current(p) - old)
+            p.grad.copy_(old.data)
+        return deltas
     return torch.autograd.grad(loss, parameters, retain_graph=retain_graph, allow_unused=allow_unused)
 
 
@@ -130,6 +143,12 @@ def darts(vector, curr, prev, sync):
     cfg = curr.config
     radius = cfg.darts_alpha  # 29
     norm = flat_scaled(vector).norm()  # 30
+    if getattr(curr, "_strategy", "default") == "fsdp":  # 31-34: the vector is sharded over the ranks
+        import torch.distributed as dist
+
+        total = norm.pow(2)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        norm = total.sqrt()
     eps = radius / norm.add_(1e-15).item()  # 35
 
     for w, v in zip(curr.meta_trainable_parameters(), vector):  # 37-38
@@ -244,7 +263,8 @@ JVP_FNS = {"cg": cg, "neumann": neumann, "darts": darts, "sama": sama}
 # -- betty/hypergradient/__init__.py:22-39 ------------------------------------------------------------------
 def get_grads(loss, path, retain_graph, do_sync):
     lower = path[1].meta_trainable_parameters()
-    jvp = first_order_grad(loss, lower, retain_graph=retain_graph, allow_unused=True)  # 24-30
+    sharded = getattr(path[0], "_strategy", "default") == "fsdp"  # 23
+    jvp = first_order_grad(loss, lower, retain_graph=retain_graph, allow_unused=True, through_grad_field=sharded)  # 24-30
     jvp = zeros_for_missing(jvp, lower)  # 31
     hops = len(path) - 1
     for i in range(1, hops):  # 32

@@ -114,7 +114,8 @@ class CpuCheckerBackend:
     def darts_eps(self, layout, vector, R):
         ss = sum(self.orc.orc_sqnorm(t.data_ptr(), t.numel()) for t in self._prep(vector))
         eps = self.orc.orc_darts_eps(ss, R)
-        return torch.tensor(eps, dtype=torch.float64).to(torch.float32), torch.tensor(eps, dtype=torch.float64)
+        return (torch.tensor(eps, dtype=torch.float64).to(torch.float32), torch.tensor(eps, dtype=torch.float64),
+                torch.tensor(ss, dtype=torch.float64))
 
     def axpy_multi(self, layout, dst, src, coef, mul):
         a = _f32(mul * float(coef)) if coef is not None else _f32(mul)

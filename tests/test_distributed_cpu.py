@@ -240,3 +240,83 @@ def test_engine_distributed_strategy_keeps_upper_parameters_in_sync():
         assert upper_steps == 5
         assert diff < 1e-6, "ranks diverged: the hypergradient was not averaged"
         assert moved > 1e-3, "lambda did not move at all"
+
+
+def _fsdp_darts_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hypergrad_oracle as horc
+        import zoo
+        from _cpu_checker_backend import CpuCheckerBackend
+        from conftest import load_golden
+
+        from betty_amd import Config
+        from betty_amd import hypergradient as hg
+        from betty_amd.backend import use_backend
+
+        case = zoo.CASE_BY_NAME["reweight_darts"]
+        inputs, _ = load_golden(case.family)
+
+        def build(cfg_cls):
+            curr, prev, vector = zoo.build_case(case, inputs, cfg_cls)
+            curr._strategy = "fsdp"
+            # each rank holds a different "shard" of the direction: scale it per rank so the norms differ
+            vector = [(rank + 1.0) * v for v in vector]
+            return curr, prev, vector
+
+        # what eps must be: R / sqrt(sum over ranks of the local squared norms)
+        _, _, vec = build(Config)
+        local_sq = sum(float((v.double() ** 2).sum()) for v in vec)
+        all_sq = torch.tensor([local_sq], dtype=torch.float64)
+        dist.all_reduce(all_sq)
+
+        curr, prev, vector = build(Config)
+        want = horc.darts(vector, curr, prev, False)            # oracle restatement of darts.py incl. 31-34
+        with use_backend(CpuCheckerBackend()):
+            curr, prev, vector = build(Config)
+            w0 = [p.data.clone() for p in curr.trainable_parameters()]
+            got = hg.darts(vector, curr, prev, False)
+            drift = max(float((p.data - w).abs().max()) for p, w in zip(curr.trainable_parameters(), w0))
+        err = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(got, want))
+        ref_err = -1.0
+        if os.path.isdir("/root/reference/betty"):              # the live reference, same two ranks
+            sys.path.insert(0, "/root/reference")
+            import betty.hypergradient  # noqa: F401
+            from betty.configs import Config as RefConfig
+
+            ref_darts = sys.modules["betty.hypergradient.darts"].darts
+            curr, prev, vector = build(RefConfig)
+            ref = ref_darts(vector, curr, prev, False)
+            ref_err = max(float((a - b).abs().max()) for a, b in zip(want, ref))   # oracle == reference, bitwise
+        q.put((rank, err, drift, ref_err, local_sq, float(all_sq)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_darts_fsdp_branch_uses_the_norm_of_the_whole_sharded_vector():
+    """darts.py:31-34: under FSDP every rank holds a shard of the direction, eps = R / ||whole vector||.
+    Two gloo ranks with different shards: the product (checker backend) matches the oracle's restatement, the
+    oracle matches the live reference bit for bit (when the checkout is present), weights are restored."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fsdp_darts_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    results = sorted(q.get(timeout=5) for _ in range(world))
+    assert results[0][4] != results[1][4], "ranks must hold different shards"
+    for rank, err, drift, ref_err, local_sq, all_sq in results:
+        assert all_sq > local_sq
+        assert err < 2e-3, (rank, err)          # finite differences: the darts tolerance of the golden cases
+        assert drift < 2e-7, (rank, drift)
+        assert ref_err in (-1.0, 0.0), (rank, ref_err)

@@ -279,7 +279,7 @@ def test_darts_eps_matches_oracle(be, orc):
     gen = torch.Generator().manual_seed(3)
     vec = _rand_list([1000, 33, 5000], gen, scale=0.01)
     lay = be.layout(vec)
-    e32, e64 = be.darts_eps(lay, vec, 0.01)
+    e32, e64, _ = be.darts_eps(lay, vec, 0.01)
     flat = np.concatenate([t.cpu().numpy() for t in vec])
     want = orc.orc_darts_eps(orc.orc_sqnorm(_ptr(flat), len(flat)), 0.01)
     assert abs(float(e64) - want) <= 1e-12 * want
@@ -289,7 +289,7 @@ def test_darts_eps_matches_oracle(be, orc):
     assert abs(float(e64) - ref) <= 1e-6 * ref
     # all-zero vector: eps = R / 1e-15, finite
     z = [torch.zeros(10, device=DEV)]
-    e32, e64 = be.darts_eps(be.layout(z), z, 0.01)
+    e32, e64, _ = be.darts_eps(be.layout(z), z, 0.01)
     assert np.isfinite(float(e64)) and float(e64) > 1e12
 
 

@@ -120,3 +120,39 @@ def test_oracle_matches_live_reference_on_fresh_seed():
         b = orc.JVP_FNS[case.algo](v2, c2, p2, False)
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x.detach().numpy(), y.detach().numpy())
+
+
+def _fsdp_grad_case():
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(6, 4)
+    x = torch.randn(5, 6)
+    params = list(lin.parameters())
+    # a pre-existing .grad that must survive untouched (utils.py:10,16)
+    for p in params:
+        p.grad = torch.randn_like(p)
+    keep = [p.grad.clone() for p in params]
+    loss = (lin(x) ** 2).sum()
+    return params, keep, loss
+
+
+def test_oracle_fsdp_grad_branch():
+    """hypergradient/utils.py:9-17 (gradient read off `.grad` around a backward, `.grad` restored): the oracle's
+    restatement equals the plain autograd gradient, leaves `.grad` as it was — and equals the live reference's
+    `grad(..., is_fsdp=True)` bit for bit when the checkout is present."""
+    params, keep, loss = _fsdp_grad_case()
+    plain = torch.autograd.grad(loss, params, retain_graph=True)
+    got = orc.first_order_grad(loss, params, retain_graph=True, through_grad_field=True)
+    for g, w in zip(got, plain):
+        np.testing.assert_allclose(g.numpy(), w.numpy(), rtol=1e-6, atol=1e-7)   # (grad + g) - grad rounds once
+    for p, k in zip(params, keep):
+        np.testing.assert_array_equal(p.grad.numpy(), k.numpy())
+    if os.path.isdir("/root/reference/betty"):
+        sys.path.insert(0, "/root/reference")
+        try:
+            from betty.hypergradient.utils import grad as ref_grad
+        finally:
+            sys.path.remove("/root/reference")
+        params2, _, loss2 = _fsdp_grad_case()
+        want = ref_grad(loss2, params2, retain_graph=True, is_fsdp=True)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.numpy(), w.numpy())
