@@ -20,17 +20,21 @@ jvp_fn_mapping = {
 
 
 def get_grads(loss, path, retain_graph, do_sync):
-    """Hypergradient of ``loss`` along ``path`` = [upper, lower_1, ..., upper]
-    (__init__.py:22-39): direct gradient w.r.t. the first lower problem's parameters, then one
-    best-response-Jacobian product per hop, right to left; only the last hop may sync."""
-    is_fsdp = getattr(path[0], "_strategy", "default") == "fsdp"   # __init__.py:23
-    lower = path[1].meta_trainable_parameters()
-    jvp = grad(loss, lower, retain_graph=retain_graph, allow_unused=True, is_fsdp=is_fsdp)
-    jvp = replace_none_with_zero(jvp, lower)
-    for i in range(1, len(path) - 1):
-        jvp_fn_type = path[i].config.type
-        assert jvp_fn_type in jvp_fn_mapping
-        jvp_fn = jvp_fn_mapping[jvp_fn_type]
-        sync = bool(do_sync and i == len(path) - 2)
-        jvp = jvp_fn(jvp, path[i], path[i + 1], sync)
-    return jvp
+    """Hypergradient of ``loss`` along ``path`` = [upper, lower_1, ..., upper] (__init__.py:22-39).
+
+    The direct gradient w.r.t. the first lower problem's parameters is pushed through the path one hop at a
+    time: hop ``(lower, nxt)`` multiplies it with the best-response Jacobian of ``lower`` w.r.t. ``nxt`` using
+    the approximation named by ``lower.config.type``.  Only the LAST hop may synchronise (``do_sync``): it then
+    accumulates into ``nxt``'s ``.grad`` through ``backward`` (DDP reducer) and the function returns None."""
+    upper, first_lower = path[0], path[1]
+    targets = first_lower.meta_trainable_parameters()
+    vector = grad(loss, targets, retain_graph=retain_graph, allow_unused=True,
+                  is_fsdp=getattr(upper, "_strategy", "default") == "fsdp")
+    vector = replace_none_with_zero(vector, targets)
+    hops = list(zip(path[1:-1], path[2:]))          # (lower, next-on-the-way-up)
+    for n, (lower, nxt) in enumerate(hops):
+        kind = lower.config.type
+        assert kind in jvp_fn_mapping
+        last = n == len(hops) - 1
+        vector = jvp_fn_mapping[kind](vector, lower, nxt, bool(do_sync and last))
+    return vector
