@@ -160,8 +160,15 @@ class HipMLPState:
         return tab, (dirs, keep)
 
     def hvp(self, direction_views):
-        tab, _keep = self._dir_table(direction_views)
-        _native.check(self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), tab, self._out_tab, _stream()), "bhg_mlp_hvp")
+        # CG / Neumann pass the SAME view tensors every iteration (views of the persistent flat direction):
+        # validate and build the pointer table once per distinct tensor set (the cache holds the tensors, so
+        # their ids cannot be recycled while it is alive).
+        key = tuple(map(id, direction_views))
+        cached = getattr(self, "_dir_cache", None)
+        if cached is None or cached[0] != key:
+            tab, keep = self._dir_table(direction_views)
+            cached = self._dir_cache = (key, tab, keep, list(direction_views))
+        _native.check(self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), cached[1], self._out_tab, _stream()), "bhg_mlp_hvp")
         return self.out
 
     def mixed_coeff(self, dir_views):
