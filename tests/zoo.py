@@ -310,6 +310,8 @@ CASES: List[Case] = [
     Case("reweight_darts", "reweight", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
     # cfg 3 shape (reduced): conv net inner, prox-regularised to the upper copy (M = N)
     Case("imaml_cg10", "imaml", "cg", dict(type="cg", cg_iterations=10, cg_alpha=1.0)),
+    Case("imaml_neumann6", "imaml", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.3)),
+    Case("imaml_darts", "imaml", "darts", dict(type="darts", darts_alpha=0.05), rtol=2e-3),
     # SAMA: Adam-preconditioned finite difference; SGD = identity preconditioner
     Case("reweight_sama_adam", "reweight", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
     Case("logreg_sama_sgd", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01), rtol=2e-3),
@@ -320,6 +322,7 @@ CASES: List[Case] = [
     Case("deep_neumann6", "deep", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.2)),
     Case("deep_cg6", "deep", "cg", dict(type="cg", cg_iterations=6, cg_alpha=1.0)),
     Case("deep_darts", "deep", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
+    Case("deep_sama_adam", "deep", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 
