@@ -620,7 +620,17 @@ enum : int { HEAD_JVP = 0, HEAD_COEFF = 1, HEAD_LOGITS = 2 };
 // Every load address is clamped instead of guarded and HAS_RH / JMAX are compile-time, so a trip's
 // 2 + 2*JMAX 16-B loads are all in flight together (a runtime `if (c < C)` / `if (Rh)` around a load makes
 // hipcc wait vmcnt(0) after each one: 30 dependent L2 round trips on the critical path of every HVP).
-template <bool HAS_RH, int JMAX>
+// FUSED: the split-K combine of the PREVIOUS layer's R-forward GEMM (sum of slabs + bias, times ReLU mask) is done
+// here, by the workgroup that owns the sample row, instead of by a k_reduce_mask launch in front of this kernel:
+// the row lands in LDS for the dot products and is written out once (the outer products need it).
+struct HeadFuse {
+  const float* part;   // [splits][rows][K] partial slabs of Ra_{L-2}
+  int splits, slab;
+  const float* bias;   // c_{L-2}[K]
+  const float* mask;   // m_{L-2}[rows][K]
+  float* rh_out;       // Rh_{L-2}[rows][K]
+};
+template <bool HAS_RH, int JMAX, bool FUSED>
 __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ Rh, const float* __restrict__ h,
                                                       const float* __restrict__ W, const float* __restrict__ V,
                                                       const float* __restrict__ cb, const float* __restrict__ prob,
@@ -628,7 +638,8 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       int C, int B, int mode, const int64_t* __restrict__ labels,
                                                       float* __restrict__ aux, const float* __restrict__ delta_top,
                                                       const float* __restrict__ mask_prev,
-                                                      float* __restrict__ rd_prev) {
+                                                      float* __restrict__ rd_prev, HeadFuse fz) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];   // FUSED: the row of Rh_{L-2}, K floats
   // HEAD_JVP with rd_prev != NULL also performs the R-backward step through the head for this sample row
   // (it only needs the row's own Rd_L):  rd_prev[b][k] = mask_prev[b][k] * sum_c (delta_top[b][c] V[c][k] + Rd_L[b][c] W[c][k])
   // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
@@ -643,9 +654,31 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
     if (mode != HEAD_JVP && t == 0) aux[b] = 0.f;
     if (mode == HEAD_JVP && rd_prev)
       for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FUSED)
+      for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  const float* rhb = HAS_RH ? Rh + (int64_t)b * K : nullptr;
+  if (FUSED) {
+    for (int k = 4 * t; k < K; k += 1024) {
+      const float* p0 = fz.part + (int64_t)b * K + k;
+      const float4 bv = ld16(fz.bias + k);
+      const float4 mv = ld16(fz.mask + (int64_t)b * K + k);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < fz.splits; s0 += 8) {     // same batching and summation order as k_reduce_mask
+        float4 tt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < fz.splits ? s0 + u : fz.splits - 1) * fz.slab);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < fz.splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
+      }
+      v.x = (v.x + bv.x) * mv.x; v.y = (v.y + bv.y) * mv.y; v.z = (v.z + bv.z) * mv.z; v.w = (v.w + bv.w) * mv.w;
+      *reinterpret_cast<float4*>(srow + k) = v;
+      *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = v;
+    }
+    __syncthreads();
+  }
+  const float* rhb = HAS_RH ? (FUSED ? srow : Rh + (int64_t)b * K) : nullptr;
   const float* hb = h + (int64_t)b * K;
   float acc[JMAX], cbv[JMAX];
   const float* vrow[JMAX];
@@ -754,13 +787,17 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
 void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float* h, const float* W, const float* V,
                          const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
                          const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
-                         float* rd_prev) {
+                         float* rd_prev, const HeadFuse* fuse = nullptr) {
   // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
-#define BHG_HEAD(RH, J)                                                                                              \
-  hipLaunchKernelGGL((k_head_forward<RH, J>), dim3(rows), dim3(256), 0, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
-                     mode, labels, aux, delta_top, mask_prev, rd_prev)
-  if (Rh) { if (C <= 12) BHG_HEAD(true, 3); else BHG_HEAD(true, 8); }
-  else    { if (C <= 12) BHG_HEAD(false, 3); else BHG_HEAD(false, 8); }
+  HeadFuse fz{};
+  if (fuse) fz = *fuse;
+  const size_t lds = fuse ? (size_t)K * sizeof(float) : 0;
+#define BHG_HEAD(RH, J, F)                                                                                              \
+  hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
+                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz)
+  if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
+  else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
+  else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
 #undef BHG_HEAD
 }
 
@@ -937,6 +974,9 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;
   const bool head = !no_head && L >= 1 && m->dims[L] <= kSmallC && (m->dims[L - 1] & 3) == 0;
   // ---- R-forward ------------------------------------------------------------------------------------
+  static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;   // A/B switch (debug)
+  HeadFuse head_fuse{};
+  bool fuse_head = false;
   for (int l = 0; l < L; ++l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* V = static_cast<const float*>(dir[2 * l]);
@@ -944,7 +984,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     if (head && l == L - 1) {
       launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, m->sd,
                           m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
-                          l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr);
+                          l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
+                          fuse_head ? &head_fuse : nullptr);
       continue;
     }
     GemmArgs a{};
@@ -957,7 +998,11 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
     launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
     const int slab = Bp * N;
-    if (l + 1 < L) {
+    if (head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024) {
+      // the head kernel of the next layer combines these slabs itself (one launch less on the chain)
+      head_fuse = {m->partial, a.splits, slab, c, m->mask[l], m->Rh[l]};
+      fuse_head = true;
+    } else if (l + 1 < L) {
       launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
     } else {
       hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
