@@ -62,6 +62,7 @@ class _Buffers:
         self.partial = torch.empty(max(n_part, 1), dtype=torch.float32, device=device)
         d.partial, d.partial_floats = self.partial.data_ptr(), n_part
         self.desc = d
+        self.out = None   # HVP output tensors, allocated with the first problem that uses these buffers
         self.native_prepare = bool(lib.bhg_mlp_supports_native_prepare(ctypes.byref(d)))
 
 
@@ -116,12 +117,16 @@ class HipMLPState:
             _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
         else:
             self._aten_backward(Ws, y)
-        # HVP outputs are consumed by the recurrence kernel on the same stream before the next
-        # HVP is launched, so one set of output tensors serves all K iterations.
-        self.out = []
-        for lin in spec.layers:
-            self.out += [torch.empty_like(lin.weight), torch.empty_like(lin.bias)]
-        self._out_tab, self._out_keep = _native.ptr_array([t.data_ptr() for t in self.out])
+        # HVP outputs are consumed by the recurrence kernel on the same stream before the next HVP is
+        # launched, so ONE set of output tensors serves all K iterations — and all steps (no allocator
+        # traffic per step, stable addresses for the recurrence kernel's pointer-table cache).
+        if buf.out is None:
+            buf.out = []
+            for lin in spec.layers:
+                buf.out += [torch.empty_like(lin.weight), torch.empty_like(lin.bias)]
+            buf.out_tab, buf.out_keep = _native.ptr_array([t.data_ptr() for t in buf.out])
+        self.out = buf.out
+        self._out_tab = buf.out_tab
 
     # ---- ATen path of the once-per-step passes for wide output layers ------------------------------------------
     def _aten_forward(self, Ws, bs, y):
