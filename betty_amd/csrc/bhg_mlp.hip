@@ -12,10 +12,10 @@
 //   outputs     H(W_l) = Rd_l^T h_{l-1} + delta_l^T Rh_{l-1} + 2 rho V_l                (TN GEMMs)
 //               H(b_l) = colsum(Rd_l) + 2 rho c_l
 // All GEMMs have one skinny dimension (the batch, padded to 128 rows) and stream a large weight
-// or produce a large weight-shaped output, so they are tiled 128 x 64 per workgroup (4 waves of
-// 64 x 32 on v_mfma_f32_32x32x2_f32, exact fp32), staged through LDS with coalesced 16-B global
-// loads, split along K across workgroups to fill the 256 CUs (deterministic: partial slabs are
-// summed in fixed order by the epilogue, no atomics).
+// or produce a large weight-shaped output: k_gemm tiles 128 x 32 per workgroup (4 waves of 32 x 32;
+// 128 x 64 selectable), k_outer 128 x 64, both on v_mfma_f32_32x32x2_f32 (exact fp32), staged through
+// LDS with coalesced 16-B global loads; the skinny GEMMs are split along K across ~768 workgroups to
+// fill the 256 CUs (deterministic: partial slabs are summed in fixed order, no atomics).
 #include <stdlib.h>
 
 #include "bhg_common.hpp"
