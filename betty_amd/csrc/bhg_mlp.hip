@@ -144,7 +144,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ lds, int row, in
 }
 
 // C[M][N] (+)= sum over pairs  A_pair (M x K) * B_pair (K x N), operands in layouts LA / LB.
-// grid = (ceil(N/64), ceil(M/128), splits), block = 256 (4 waves: 2 along M x 2 along N).
+// grid = (ceil(N/TN), ceil(M/128), splits), block = 256: TN = 32 -> 4 waves of 32 x 32 stacked along M; TN = 64 -> 2 x 2 waves of 64 x 32.
 // FAST: every tile is interior (M % 128 == 0, N % TN == 0, K % 32 == 0, leading dimensions % 4 == 0; checked by
 // launch_gemm).  The instance then has NO edge path: with the ragged-tile branches in the loop hipcc puts an
 // `s_waitcnt vmcnt(0)` at the top of every step (the control-flow join), which serialises the two-stage
