@@ -87,12 +87,13 @@ class Problem:
                 p.grad = g if p.grad is None else p.grad + g
 
 
-def declare_structure(curr, impl):
+def declare_structure(curr, impl, fused=True):
     """Opt the inner problem into the analytic MFMA HVP (betty_amd/hypergradient/structured.py)."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
     curr.hypergradient_structure = lambda prev: WeightedCEMLP(
-        curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=RIDGE, impl=impl
+        curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=RIDGE, impl=impl,
+        fused=fused,
     )
 
 
@@ -133,19 +134,49 @@ def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg"):
     return curr, prev, vector
 
 
-def pmc_traffic(resident, N):
-    """HBM bytes per launch of the recurrence kernel from the committed PMC passes
-    (profiles/pmc_k_cg_resident.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this
-    very command, corrected per MI355X_MICROARCH.md §HBM).  PMC collection needs rocprofv3 around the
-    process, so bench.py reports the committed measurement for the matching kernel + size, else null."""
-    path = os.path.join(ROOT, "profiles", "pmc_k_cg_resident.json")
+def lib_sha256():
+    import hashlib
+
+    from betty_amd import _native
+
+    with open(_native.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_traffic(key, N):
+    """Fabric-side bytes per iteration from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, corrected per MI355X_MICROARCH.md §HBM; written
+    by scripts/gpu_pmc.sh).  PMC collection needs rocprofv3 around the process, so bench.py can only replay a
+    committed measurement — and does so ONLY when that file is stamped with the sha256 of the very libbhg.so
+    that is loaded now (same kernels); otherwise the field is null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("lib_sha256") != lib_sha256() or d.get("workload_N") != N:
+        return None
+    return d.get("traffic_bytes", {}).get(key)
+
+
+def host_info():
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
     except OSError:
-        return None
-    if not resident or d.get("workload_N") != N:
-        return None
-    return d["traffic_bytes_per_launch"]
+        pass
+    return model, (len(phys) or None), os.cpu_count()
 
 
 def cpu_baseline(steps, K):
@@ -180,10 +211,14 @@ def cpu_baseline(steps, K):
     med, used_threads, times = best
     steps = len(times)
     torch.set_num_threads(used_threads)
+    model, phys, logical = host_info()
     return {
         "value": 1.0 / med,
         "unit": "hypergradient-steps/sec",
         "cores": used_threads,
+        "host_model": model,
+        "physical_cores": phys,
+        "logical_cpus": logical,
         "kind": "port",
         "sample": f"{steps} steps of the same workload (cg K={K}, N=10,034,826, batch {BATCH}), median, at the best of "
         f"8/16/32 torch threads ({used_threads}); oracle/hypergrad_oracle.py on torch CPU fp32, "
@@ -194,14 +229,16 @@ def cpu_baseline(steps, K):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # ~1 s of GPU work: visible to coarse (SMI) utilisation sampling
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cg-iters", type=int, default=20, help="K: CG / Neumann iterations")
     ap.add_argument("--algo", choices=["cg", "neumann", "darts"], default="cg",
                     help="cg = the BASELINE metric; neumann / darts = secondary lines (BASELINE cfg 2 uses neumann K=10)")
     ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
     ap.add_argument("--hvp", choices=["analytic", "analytic-aten", "autograd"], default="analytic",
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="analytic HVP only: K x (HVP kernels + recurrence kernel) instead of the one-pass fused solver (A/B)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
@@ -235,16 +272,19 @@ def main():
     curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
     jvp_fn = hg.jvp_fn_mapping[args.algo]
     if args.hvp == "analytic":
-        declare_structure(curr, "hip")
+        declare_structure(curr, "hip", fused=not args.no_fuse)
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
     layout = be.layout(vector)
-    resident = args.variant == "resident" or (args.variant == "auto" and layout.n_chunks <= be.lib.bhg_cg_resident_capacity_chunks())
+    fused = args.hvp == "analytic" and not args.no_fuse and args.algo in ("cg", "neumann")
+    # the predicate bhg_cg_step itself uses (capacity AND the residency census)
+    resident = (not fused) and (args.variant == "resident" or (
+        args.variant == "auto" and layout.n_chunks <= be.lib.bhg_cg_resident_capacity_chunks() and bool(be.lib.bhg_cg_resident_ok())))
 
-    # per-launch timing of the CG recurrence: HIP events attached to the kernels themselves on the
-    # launch stream (hipExtLaunchKernelGGL inside libbhg; bhg_timing_enable/read in include/bhg.h)
+    # per-launch timing: HIP events attached to the kernels / launch groups themselves on the launch stream
+    # (hipExtLaunchKernelGGL / hipEventRecord inside libbhg; bhg_timing_enable/read in include/bhg.h)
     timing_on = not args.no_kernel_timing
 
     def step():
@@ -269,65 +309,83 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_total_ms, kern_launches = 0.0, 0
-    hvp_total_ms, hvp_calls = 0.0, 0
+    spans = {}
     if timing_on:
         import ctypes
 
-        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
-        _native.check(be.lib.bhg_timing_read(0 if args.algo == "cg" else 1, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
-        kern_total_ms, kern_launches = tot.value, cnt.value
-        _native.check(be.lib.bhg_timing_read(2, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
-        hvp_total_ms, hvp_calls = tot.value, cnt.value
+        for name, kind in (("cg_step", 0), ("neumann_step", 1), ("hvp", 2), ("cg_iter", 3)):
+            tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+            _native.check(be.lib.bhg_timing_read(kind, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
+            if cnt.value:
+                spans[name] = (1e3 * tot.value / cnt.value, cnt.value)   # (average us, launches)
         be.lib.bhg_timing_enable(0)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    be.check_health()
 
     finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
+    if not finite:
+        raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
     out = None
     if rank == 0:
         value = world * args.steps / elapsed
+        # CG iteration 28*N B (read Hp,p,r,x; write x,r,p), Neumann iteration 20*N B; analytic HVP:
+        # >= 20*N B of weight traffic (read W, V twice, write the HVP once) — with the fused solver the HVP output is
+        # not written and the recurrence does not read it, but the algorithmic figure is kept (it is the yardstick).
+        rec_bytes = (28.0 if args.algo == "cg" else 20.0) * N
         roof = None
-        if kern_launches:
-            avg_us = 1e3 * kern_total_ms / kern_launches
-            # CG iteration 28*N B (read Hp,p,r,x; write x,r,p), Neumann iteration 20*N B
-            alg_bytes = (28.0 if args.algo == "cg" else 20.0) * N
-            achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+        mall_note = ("working set (x, r, p, W, activations = %.0f MB) is smaller than the 256 MiB Infinity Cache: this is "
+                     "fabric-side bandwidth on cache-resident data, quoted against the 8 TB/s HBM peak as north_star asks; "
+                     "cache-defeated figures: profiles/r02_cache_defeated.json" % ((3 * 4 * N + 4 * N + 8e6) / 1e6))
+        if fused and args.algo == "cg" and "cg_iter" in spans:
+            us, n = spans["cg_iter"]
+            alg = rec_bytes + 20.0 * N
+            roof = {"bound": "hbm", "kernel": "bhg_mlp_cg_solve: one fused CG-HVP iteration (HVP chain with r/x update in its "
+                    "output kernels + k_cg_pdir)", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": pmc_traffic("cg_iter_fused", N),
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n, "note": mall_note}
+        elif fused and args.algo == "neumann" and "hvp" in spans:
+            us, n = spans["hvp"]
+            alg = rec_bytes + 20.0 * N
+            roof = {"bound": "hbm", "kernel": "bhg_mlp_neumann_solve: one fused Neumann-HVP iteration", "achieved": alg / (us * 1e-6) / 1e9,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": pmc_traffic("neumann_iter_fused", N), "algorithmic_bytes_per_launch": alg, "avg_launch_us": us,
+                    "launches_timed": n, "note": mall_note}
+        elif ("cg_step" if args.algo == "cg" else "neumann_step") in spans:
+            us, n = spans["cg_step" if args.algo == "cg" else "neumann_step"]
             roof = {
                 "bound": "hbm",
                 "kernel": ("k_neumann_step (1 launch/iter)" if args.algo == "neumann" else
                            "k_cg_resident (1 launch/iter)" if resident else "k_cg_dot+k_cg_resid+k_cg_dir (3 launches/iter)"),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(resident, N) if args.algo == "cg" else None,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_us": avg_us,
-                "launches_timed": kern_launches,
+                "achieved": rec_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": rec_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": pmc_traffic("k_cg_resident" if resident else "cg_stream", N) if args.algo == "cg" else None,
+                "algorithmic_bytes_per_launch": rec_bytes, "avg_launch_us": us, "launches_timed": n, "note": mall_note,
             }
         hvp_roof = None
-        if hvp_calls:
+        if "hvp" in spans:
             # useful flops of one analytic HVP (B valid rows, no padding): R-forward + R-backward + weight-shaped outputs
             d = SIZES
             fwd = sum(2.0 * BATCH * d[l] * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 1))
             bwd = sum(2.0 * BATCH * d[l] * d[l + 1] * 2 for l in range(1, len(d) - 1))
             outer = sum(2.0 * BATCH * d[l] * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 1))
             flops = fwd + bwd + outer
-            us = 1e3 * hvp_total_ms / hvp_calls
+            us, n = spans["hvp"]
             hvp_roof = {
                 "bound": "mfma",
-                "kernel": "bhg_mlp_hvp (k_gemm<NT>, k_gemm<NN>, k_outer, head kernels, split-K reduces)",
-                "achieved": flops / (us * 1e-6) / 1e12,
-                "peak": 157.3,
-                "unit": "TFLOP/s",
-                "frac": flops / (us * 1e-6) / 1e12 / 157.3,
-                "flops_per_call": flops,
-                "avg_call_us": us,
-                "calls_timed": hvp_calls,
+                "kernel": "MLP HVP chain (k_gemm<NT>, k_gemm<NN>, k_outer, head kernels, split-K reduces)" +
+                          ("; fused: its output kernels also carry the recurrence's r/x (or v/p) update" if fused else ""),
+                "achieved": flops / (us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": flops / (us * 1e-6) / 1e12 / 157.3, "flops_per_call": flops, "avg_call_us": us, "calls_timed": n,
             }
+        K_eff = 0 if args.algo == "darts" else K
+        per_iter_us = None
+        if fused and args.algo == "cg" and "cg_iter" in spans:
+            per_iter_us = spans["cg_iter"][0]
+        elif "hvp" in spans:
+            per_iter_us = spans["hvp"][0] + (spans.get("cg_step") or spans.get("neumann_step") or (0.0, 0))[0]
         out = {
             "metric": "hypergradient-steps/sec (CG K=20, 10M inner params)" if (args.algo == "cg" and K == 20)
             else f"hypergradient-steps/sec ({args.algo} K={K}, 10M inner params)",
@@ -345,13 +403,18 @@ def main():
             "config": {
                 "workload": "BASELINE cfg2/metric: MLP 3072-2048-1536-384-10 inner (N=%d, 8 tensors), MWN 1-100-1 upper (M=%d), "
                 "batch %d, %s K=%d, sync=True" % (N, M, BATCH, args.algo, K),
-                "hvp": "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp)" if args.hvp == "analytic" else "pytorch-rocm autograd double backward",
-                "cg_variant": "resident" if resident else "stream",
+                "hvp": ("analytic R-op HVP on fp32 MFMA, recurrence fused into its output kernels (one pass)" if fused else
+                        "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp) + recurrence kernel" if args.hvp == "analytic" else
+                        "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else "pytorch-rocm autograd double backward"),
+                "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "parallelism": "replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU",
                 "finite": finite,
+                "lib_sha256": lib_sha256()[:16],
             },
             "roofline": roof,
             "hvp_roofline": hvp_roof,
+            "per_iteration_us": per_iter_us,
+            "outside_k_loop_ms": (1e3 * elapsed / args.steps - K_eff * per_iter_us * 1e-3) if per_iter_us else None,
             "cpu_baseline": None,
         }
         if world == 1 and args.cpu_steps > 0:

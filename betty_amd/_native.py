@@ -107,6 +107,17 @@ SYMBOLS = {
     "bhg_mlp_forward": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_void_p]),
     "bhg_mlp_backward": (c_int, [POINTER(Mlp), c_void_p, c_void_p]),
     "bhg_mlp_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_void_p]),
+    "bhg_mlp_supports_fused_solve": (c_int, [POINTER(Mlp)]),
+    "bhg_mlp_fused_ws_bytes": (c_size_t, [POINTER(Mlp)]),
+    "bhg_mlp_cg_solve": (
+        c_int,
+        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_float, c_float, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
+    "bhg_mlp_neumann_solve": (
+        c_int,
+        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, c_void_p],
+    ),
 }
 
 _lib = None

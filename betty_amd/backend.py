@@ -36,6 +36,11 @@ class HipBackend:
                 "there is no CPU fallback."
             )
         self.cg_variant = _native.BHG_CG_AUTO
+        # collectives this process has in flight on a communication stream (betty_amd.distributed): while > 0 the
+        # resident CG kernel is not eligible — it needs every CU for its grid barrier and RCCL's channel kernels
+        # hold some (the barrier would spin until the collective ends, or time out)
+        self.collectives_in_flight = 0
+        self._health = []  # (event, pinned flag copy): non-blocking time-out checks of finished resident solves
 
     # -- helpers ---------------------------------------------------------------------------
     def layout(self, tensors: Sequence[torch.Tensor]) -> FlatLayout:
@@ -134,16 +139,62 @@ class HipBackend:
             self._tab_cache = (key, tab, keep, [weakref.ref(t) for t in tensors])   # `keep` owns the host pointer array
         return tab, keep
 
+    def _pick_variant(self, layout, it: int, variant: Optional[int]) -> int:
+        """The variant is chosen ONCE per solve (iteration 0) and kept: the resident kernel's barrier targets count
+        two arrivals per workgroup and completed iteration, so the two variants must not alternate inside a solve."""
+        if it > 0 and getattr(layout, "_cg_variant", None) is not None:
+            return layout._cg_variant
+        v = self.cg_variant if variant is None else variant
+        if v == _native.BHG_CG_AUTO:
+            cap = int(self.lib.bhg_cg_resident_capacity_chunks())
+            resident = 0 < layout.n_chunks <= cap and self.collectives_in_flight == 0 and bool(self.lib.bhg_cg_resident_ok())
+            v = _native.BHG_CG_RESIDENT if resident else _native.BHG_CG_STREAM
+        layout._cg_variant = v
+        return v
+
     def cg_step(self, layout, hvp, x, r, p, cg_alpha: float, it: int, out_scale: float = 0.0,
                 variant: Optional[int] = None, hvp_shift: float = 0.0) -> None:
         tab, _keep = self._cached_table(hvp, layout)
         _native.check(
             self.lib.bhg_cg_step(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
                                  r.data_ptr(), p.data_ptr(), cg_alpha, it, out_scale, hvp_shift,
-                                 self.cg_variant if variant is None else variant,
+                                 self._pick_variant(layout, it, variant),
                                  layout.workspace.data_ptr(), _stream_ptr()),
             "bhg_cg_step",
         )
+
+    def after_cg(self, layout) -> None:
+        """Health check of the resident kernel's grid barrier WITHOUT stalling the host: the time-out word of the
+        solve that was just enqueued is copied to pinned memory behind it, and the copies of EARLIER solves that
+        have completed by now are inspected.  A barrier that gave up (the GPU became shared mid-run) has already
+        NaN-poisoned that solve's result; here the cause is raised instead of leaving a silent NaN hypergradient."""
+        self.check_health(block=False)
+        if getattr(layout, "_cg_variant", None) != _native.BHG_CG_RESIDENT:
+            return
+        ws = layout.workspace
+        off = int(self.lib.bhg_cg_timeout_flag_dev(ws.data_ptr())) - ws.data_ptr()
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._health.append((ev, host))
+
+    def check_health(self, block: bool = True) -> None:
+        """Raise if a resident-CG grid barrier timed out in a solve that has finished (block=True: wait for all)."""
+        keep = []
+        for ev, host in self._health:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if int(host.item()) != 0:
+                    self._health = []
+                    raise _native.NativeLibraryError(
+                        "k_cg_resident: a grid barrier timed out (the GPU is shared, partitioned, or another stream held "
+                        "CUs during the solve); the hypergradient of that call is NaN. Set HipBackend.cg_variant = "
+                        "BHG_CG_STREAM on shared devices.")
+            else:
+                keep.append((ev, host))
+        self._health = keep
 
     def cg_barrier_timed_out(self, layout) -> bool:
         """True if a grid barrier of the resident CG kernel gave up polling since the last cg_init

@@ -293,6 +293,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
   }
 }
 
+// ---- fused recurrence epilogues ("one pass": the weight-shaped HVP output never round-trips through HBM) ------
+// Instead of storing H*direction, the kernels that produce it (k_outer, k_head_outer, k_bias_hvp) apply the
+// CG / Neumann recurrence to the matching slices of the flat state vectors while the tile is still on chip:
+//   FUSE_CG       Hp = raw + shift*p ; r <- r - alpha*Hp ; x <- x + alpha*p [x <- out_scale*x] ; partial r'.r'
+//                 (cg.py:47-51; alpha = rr / (cg_alpha * p.Hp) was computed BEFORE these kernels from the batch-sized
+//                 factors of the R-chain — see k_cg_alpha — so there is no N-sized H*p vector at all)
+//   FUSE_NEUMANN  Hv = raw + shift*v ; v' <- v - alpha*Hv (written to the OTHER direction buffer: the R-backward
+//                 GEMMs of this HVP still read v) ; p <- p + v' [p <- out_scale*p]          (neumann.py:62-64,66)
+// Same rounding sequence as bhg_vector.hip's recurrence kernels (products rounded before add/sub, never contracted).
+enum : int { FUSE_NONE = 0, FUSE_CG = 1, FUSE_NEUMANN = 2 };
+struct FuseArgs {
+  float* a;          // CG: r (in/out)          Neumann: v_out (out)
+  float* b;          // CG: x (in/out)          Neumann: p (in/out)
+  const float* d;    // the direction slice:    CG: p    Neumann: v_in
+  const double* scal;  // CG: device scalars, alpha = scal[S_ALPHA]
+  double* part;        // CG: per-workgroup partial of r'.r' -> part[part_base + linear block id]
+  int part_base;
+  float alpha;       // Neumann: step length (host constant)
+  float shift;       // operator = raw HVP + shift * I
+  float out_scale;   // applied to x (CG) / p (Neumann) when apply_out != 0: the final scaling + negation of the solve
+  int apply_out;
+};
+__device__ __forceinline__ float fz_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fz_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fz_sub(float a, float b) { return __fsub_rn(a, b); }
+// one element: hv = raw HVP value, dv = direction, av / bv = the two state values; results back in av / bv.
+template <int MODE>
+__device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float hv, float dv, float& av, float& bv,
+                                          double& racc) {
+  if (f.shift != 0.f) hv = fz_add(hv, fz_mul(f.shift, dv));
+  if (MODE == FUSE_CG) {
+    const float nr = fz_sub(av, fz_mul(alpha, hv));
+    float nx = fz_add(bv, fz_mul(alpha, dv));
+    if (f.apply_out) nx = fz_mul(f.out_scale, nx);
+    racc += (double)nr * nr;
+    av = nr; bv = nx;
+  } else {
+    const float nv = fz_sub(dv, fz_mul(alpha, hv));
+    float np = fz_add(nv, bv);
+    if (f.apply_out) np = fz_mul(f.out_scale, np);
+    av = nv; bv = np;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ float fuse_alpha(const FuseArgs& f) {
+  return MODE == FUSE_CG ? (float)f.scal[S_ALPHA] : f.alpha;
+}
+
 // ---- weight-shaped outputs: C[M][N] = sum_pairs A_pair^T B_pair (+ addend), K = batch (<= 128) -----------
 // The accumulators are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
 constexpr int kOK = 128;                      // max K of the outer-product kernel
@@ -306,9 +354,10 @@ constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging
 // single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
 // FAST: all tiles interior and 16-B aligned (checked by the launcher): no ragged path, loads unconditional with
 // clamped row index and a 0/1 multiplier (same reasons as k_gemm's FAST instance).
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
+template <bool FAST, int MODE>
+__global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ double red_rr[kWaves];
   const int K = a.K;
   const int nsp = a.kstages;                          // stages per pair
   const int Kh = (((K + nsp - 1) / nsp) + 1) & ~1;    // rows per stage, even, <= kOH
@@ -440,6 +489,59 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
     }
   __syncthreads();
   const bool vec_ok = ((a.ldo & 3) == 0);
+  if (MODE != FUSE_NONE) {
+    // fused recurrence: the tile's slices of the state vectors are read/written at the SAME element offsets as C
+    // (the weight tensor W_l occupies flat[start_l + row*ldo + col]); two half-tiles of 4 float4 per thread so the
+    // 8-12 state loads of a half are all in flight before the first use.
+    const float alpha = fuse_alpha<MODE>(fz);
+    double racc = 0.0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      float4 dv[4], av[4], bv[4];
+      bool ok[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 4) + 16 * (4 * hb + i);
+        const int c4 = 4 * (t & 15);
+        const int grow = m0 + row, gcol = n0 + c4;
+        ok[i] = FAST || (grow < a.M && vec_ok && gcol + 4 <= a.N);
+        const int64_t off = ok[i] ? (int64_t)grow * a.ldo + gcol : 0;
+        dv[i] = ld16(fz.d + off);
+        if (MODE == FUSE_CG) av[i] = ld16(fz.a + off);
+        bv[i] = ld16(fz.b + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 4) + 16 * (4 * hb + i);
+        const int c4 = 4 * (t & 15);
+        const int grow = m0 + row, gcol = n0 + c4;
+        const float4 hv = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
+        const int64_t off = (int64_t)grow * a.ldo + gcol;
+        if (ok[i]) {
+          float4 na = MODE == FUSE_CG ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), nb = bv[i];
+          fuse_elem<MODE>(fz, alpha, hv.x, dv[i].x, na.x, nb.x, racc);
+          fuse_elem<MODE>(fz, alpha, hv.y, dv[i].y, na.y, nb.y, racc);
+          fuse_elem<MODE>(fz, alpha, hv.z, dv[i].z, na.z, nb.z, racc);
+          fuse_elem<MODE>(fz, alpha, hv.w, dv[i].w, na.w, nb.w, racc);
+          *reinterpret_cast<float4*>(fz.a + off) = na;
+          *reinterpret_cast<float4*>(fz.b + off) = nb;
+        } else if (!FAST && grow < a.M) {   // ragged right edge / odd leading dimension: element by element
+          const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+          for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
+            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = fz.b[off + j];
+            fuse_elem<MODE>(fz, alpha, hh[j], fz.d[off + j], na, nb, racc);
+            fz.a[off + j] = na;
+            fz.b[off + j] = nb;
+          }
+        }
+      }
+    }
+    if (MODE == FUSE_CG) {
+      const double s = block_sum(racc, red_rr);
+      if (t == 0) fz.part[fz.part_base + (int)(blockIdx.y * gridDim.x + blockIdx.x)] = s;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < kTM * kTN / (256 * 4); ++i) {  // 8 float4 per thread
     const int row = (t >> 4) + 16 * i;
@@ -467,15 +569,17 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a) {
 }
 
 // ---- split-K epilogues ---------------------------------------------------------------------------------
-// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + bias[n]);  rows >= B are written as zero.
+// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + addend[m][n] + bias[n]);  rows >= B are written as zero.
 // One float4 per thread when N % 4 == 0 (all split loads independent => in flight together);
 // fixed summation order over splits => deterministic.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ part, int splits, int slab,
                                                      const float* __restrict__ bias, const float* __restrict__ mask,
                                                      float* __restrict__ out, int rows, int N, int B,
-                                                     float* __restrict__ relu_mask_out) {
+                                                     float* __restrict__ relu_mask_out,
+                                                     const float* __restrict__ addend) {
   // relu_mask_out != NULL: forward-pass mode — out = relu(sum + bias), relu_mask_out = (sum + bias > 0)
+  // addend != NULL: a chain-independent term computed earlier (delta_l V_l of the fused solver's G pass)
   const int64_t total = (int64_t)rows * N / VEC;
   const int nv = N / VEC;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -491,8 +595,10 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
         constexpr int NB = 8;
         const float* p0 = part + i * VEC;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 adv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
         if (mask) mv = *reinterpret_cast<const float4*>(mask + i * VEC);
+        if (addend) adv = *reinterpret_cast<const float4*>(addend + i * VEC);
         for (int s0 = 0; s0 < splits; s0 += NB) {
           float4 t[NB];
 #pragma unroll
@@ -505,10 +611,12 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
             if (s0 + u < splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
           }
         }
+        if (addend) { v[0] += adv.x; v[1] += adv.y; v[2] += adv.z; v[3] += adv.w; }
         v[0] = (v[0] + bv.x) * mv.x; v[1] = (v[1] + bv.y) * mv.y;
         v[2] = (v[2] + bv.z) * mv.z; v[3] = (v[3] + bv.w) * mv.w;
       } else {
         for (int s = 0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
+        if (addend) v[0] += addend[i];
         if (bias) v[0] += bias[n];
         if (mask) v[0] *= mask[i];
       }
@@ -526,6 +634,44 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
     if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
     else out[i] = v[0];
   }
+}
+
+// Fused solver, G pass: gsum[m][n] = sum_s part[s][m][n]  (= (delta_l V_l)[m][n], chain-independent) and the partial
+// of T2_l = 2 <delta_l V_l, Rh_{l-1}> (the second-order part of p.Hp, see k_cg_alpha) over this block's elements.
+// Up to 2 layers per launch; one float4 per thread; fixed summation order.
+struct GsumArgs {
+  const float* part[2]; int splits[2]; int slab[2];   // slab = rows * N floats
+  const float* rh[2];                                  // Rh_{l-1} [rows][N]
+  float* gsum[2];
+  int blk0[3];                                         // first block of each problem
+  int n;
+};
+__global__ __launch_bounds__(256) void k_gsum_dot(GsumArgs g, double* __restrict__ partT2) {
+  __shared__ double red[kWaves];
+  const int q = (g.n > 1 && (int)blockIdx.x >= g.blk0[1]) ? 1 : 0;
+  const int64_t total4 = g.slab[q] / 4;
+  const int64_t i = (int64_t)((int)blockIdx.x - g.blk0[q]) * 256 + threadIdx.x;
+  const int64_t ic = i < total4 ? i : total4 - 1;   // clamped: all loads in flight, contribution masked below
+  constexpr int NB = 8;
+  const float* p0 = g.part[q] + ic * 4;
+  const float4 rh = ld16(g.rh[q] + ic * 4);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int splits = g.splits[q];
+  for (int s0 = 0; s0 < splits; s0 += NB) {
+    float4 tt[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < splits ? s0 + u : splits - 1) * g.slab[q]);
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (s0 + u < splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
+  }
+  double acc = 0.0;
+  if (i < total4) {
+    *reinterpret_cast<float4*>(g.gsum[q] + i * 4) = v;
+    acc = (double)v.x * rh.x + (double)v.y * rh.y + (double)v.z * rh.z + (double)v.w * rh.w;
+  }
+  const double sblk = block_sum(acc, red);
+  if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
 }
 
 // Top of the network: Rz = sum_s part + c ; Rd_L = sd * (p*Rz - p (p.Rz)).
@@ -577,9 +723,12 @@ struct BiasArgs {
   int blk0[BHG_MLP_MAX_LAYERS + 1];  // first block of each layer
   int L, B;
   float rho2;
+  int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
 };
-__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
   __shared__ float red[4][64];
+  __shared__ double red_rr[kWaves];
   int l = 0;
   while (l + 1 < a.L && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
   const int N = a.n[l];
@@ -603,9 +752,23 @@ __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a) {
   }
   red[rg][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
+  double racc = 0.0;
   if (rg == 0 && col < N) {
     const int t = threadIdx.x;
-    a.out[l][col] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.rho2 * a.c[l][col];
+    if (MODE == FUSE_NONE) {
+      a.out[l][col] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.rho2 * a.c[l][col];
+    } else {
+      const float hv = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      const int64_t off = a.foff[l] + col;
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off];
+      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), hv, fz.d[off], na, nb, racc);
+      fz.a[off] = na;
+      fz.b[off] = nb;
+    }
+  }
+  if (MODE == FUSE_CG) {
+    const double sblk = block_sum(racc, red_rr);
+    if (threadIdx.x == 0) fz.part[fz.part_base + (int)blockIdx.x] = sblk;
   }
 }
 
@@ -638,8 +801,14 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       int C, int B, int mode, const int64_t* __restrict__ labels,
                                                       float* __restrict__ aux, const float* __restrict__ delta_top,
                                                       const float* __restrict__ mask_prev,
-                                                      float* __restrict__ rd_prev, HeadFuse fz) {
+                                                      float* __restrict__ rd_prev, HeadFuse fz,
+                                                      double* __restrict__ partT1, double* __restrict__ partT2h) {
   extern __shared__ __attribute__((aligned(16))) float srow[];   // FUSED: the row of Rh_{L-2}, K floats
+  // partT1 / partT2h != NULL (HEAD_JVP, fused CG solver): this sample row's share of p.Hp (see k_cg_alpha):
+  //   partT1[b]  = sum_c Rz[b][c] * Rd_L[b][c]                          (the Gauss-Newton part)
+  //   partT2h[b] = 2 * sum_k (delta_L V_L)[b][k] * Rh_{L-2}[b][k]       (the head layer's second-order part)
+  __shared__ float t1s[kSmallC];
+  __shared__ double red_t[kWaves];
   // HEAD_JVP with rd_prev != NULL also performs the R-backward step through the head for this sample row
   // (it only needs the row's own Rd_L):  rd_prev[b][k] = mask_prev[b][k] * sum_c (delta_top[b][c] V[c][k] + Rd_L[b][c] W[c][k])
   // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
@@ -736,12 +905,20 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
       rd[(int64_t)b * C + t] = v;
       rdl[t] = v;
       dtl[t] = dt;
+      t1s[t] = rz[t] * v;
     }
+    if (rd_prev || partT1) __syncthreads();
+    if (partT1 && t == 0) {
+      double s1 = 0.0;
+      for (int c = 0; c < C; ++c) s1 += (double)t1s[c];
+      partT1[b] = s1;
+    }
+    double dacc = 0.0;
     if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
-      __syncthreads();
       for (int k = 4 * t; k < K; k += 1024) {
         const float4 mk = *reinterpret_cast<const float4*>(mask_prev + (int64_t)b * K + k);
         float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f);   // (delta_L V_L)[b][k..k+3] alone, for partT2h
         for (int c0 = 0; c0 < C; c0 += 4) {  // 8 independent 16-B loads per batch of 4 classes
           float4 w[4], v[4];
 #pragma unroll
@@ -756,12 +933,21 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
               const float r = rdl[c0 + u], d = dtl[c0 + u];
               acc2.x += d * v[u].x + r * w[u].x; acc2.y += d * v[u].y + r * w[u].y;
               acc2.z += d * v[u].z + r * w[u].z; acc2.w += d * v[u].w + r * w[u].w;
+              accd.x += d * v[u].x; accd.y += d * v[u].y; accd.z += d * v[u].z; accd.w += d * v[u].w;
             }
           }
         }
         acc2.x *= mk.x; acc2.y *= mk.y; acc2.z *= mk.z; acc2.w *= mk.w;
         *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
+        if (HAS_RH && partT2h) {
+          const float4 rh4 = *reinterpret_cast<const float4*>(rhb + k);
+          dacc += (double)accd.x * rh4.x + (double)accd.y * rh4.y + (double)accd.z * rh4.z + (double)accd.w * rh4.w;
+        }
       }
+    }
+    if (partT2h) {
+      const double s2 = block_sum(dacc, red_t);
+      if (t == 0) partT2h[b] = 2.0 * s2;
     }
   } else if (mode == HEAD_COEFF) {
     if (t < C) pz[t] = (prob[(int64_t)b * C + t] - (t == (int)labels[b] ? 1.f : 0.f)) * rz[t];
@@ -787,14 +973,15 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
 void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float* h, const float* W, const float* V,
                          const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
                          const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
-                         float* rd_prev, const HeadFuse* fuse = nullptr) {
+                         float* rd_prev, const HeadFuse* fuse = nullptr, double* partT1 = nullptr,
+                         double* partT2h = nullptr) {
   // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
   HeadFuse fz{};
   if (fuse) fz = *fuse;
   const size_t lds = fuse ? (size_t)K * sizeof(float) : 0;
 #define BHG_HEAD(RH, J, F)                                                                                              \
   hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
-                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz)
+                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h)
   if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
   else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
   else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
@@ -831,12 +1018,14 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
 
 // G[c][n] = sum_b (Rd[b][c] h[b][n] + delta[b][c] Rh[b][n]) + rho2 V[c][n];  block = 64 n x 4 batch groups,
 // fixed-order combine through LDS (deterministic).
-template <bool HAS_RH>
+template <bool HAS_RH, int MODE>
 __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd, const float* __restrict__ h,
                                                     const float* __restrict__ delta, const float* __restrict__ Rh,
                                                     const float* __restrict__ V, float rho2, float* __restrict__ out,
-                                                    int N, int C, int B) {
+                                                    int N, int C, int B, FuseArgs fz) {
+  // fused modes: fz.a / fz.b / fz.d already point at the head weight's slice of the flat state vectors
   __shared__ float red[4][64];
+  __shared__ double red_rr[kWaves];
   const int c = blockIdx.y;
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int nc = n < N ? n : N - 1;   // clamped, not guarded (see k_head_forward)
@@ -864,11 +1053,24 @@ __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd
   }
   red[g][threadIdx.x & 63] = acc;
   __syncthreads();
+  double racc = 0.0;
   if (g == 0 && n < N) {
     const int t = threadIdx.x;
     float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    if (rho2 != 0.f) v += rho2 * V[(int64_t)c * N + n];
-    out[(int64_t)c * N + n] = v;
+    const int64_t off = (int64_t)c * N + n;
+    if (MODE == FUSE_NONE) {
+      if (rho2 != 0.f) v += rho2 * V[off];
+      out[off] = v;
+    } else {
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off];
+      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), v, fz.d[off], na, nb, racc);
+      fz.a[off] = na;
+      fz.b[off] = nb;
+    }
+  }
+  if (MODE == FUSE_CG) {
+    const double sblk = block_sum(racc, red_rr);
+    if (threadIdx.x == 0) fz.part[fz.part_base + (int)(blockIdx.y * gridDim.x + blockIdx.x)] = sblk;
   }
 }
 
@@ -903,17 +1105,18 @@ inline int skinny_tile_n() {
 }
 
 void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
-                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr) {
+                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr,
+                        const float* addend = nullptr) {
   if ((N & 3) == 0) {
     int blocks = (slab / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out);
+                       relu_mask_out, addend);
   } else {
     int blocks = (slab + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out);
+                       relu_mask_out, addend);
   }
 }
 
@@ -934,6 +1137,445 @@ int pick_splits(int tiles, int K, int pairs) {
     }
   }
   return s;
+}
+
+// ---- fused CG solver: step length BEFORE the weight-shaped outputs, direction update after them -------------------
+// p.(H p) from batch-sized factors of the R-chain (no N-sized H p exists in the fused solver):
+//   p.Hp = sum_b Rz_b . Rd_L,b  +  2 sum_{l>=1} <delta_l V_l, Rh_{l-1}>  +  shift * p.p
+// (second directional derivative of the loss: the Gauss-Newton term through the softmax-CE Hessian plus the
+//  layer-bilinear terms; the identity is checked in fp64 by tests/test_host_logic.py against p . autograd-HVP).
+// den = cg_alpha * p.Hp, alpha = rr / den with fp32 division of the fp32-rounded dots, as the reference does
+// (cg.py:42-47).  One workgroup; every partial array is summed in a fixed order.
+struct AlphaArgs {
+  const double* partT1; const double* partT2h; int B;
+  const double* partT2; int nT2;
+  const double* partPP; int nPP;
+  const double* partRR; int nRR;
+  float cg_alpha, shift;
+  double* scal;
+};
+__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
+  __shared__ double red[kWaves];
+  const double t1 = sum_partials(a.partT1, a.B, red);
+  const double t2h = a.partT2h ? sum_partials(a.partT2h, a.B, red) : 0.0;
+  const double t2 = sum_partials(a.partT2, a.nT2, red);
+  const double pp = a.shift != 0.f ? sum_partials(a.partPP, a.nPP, red) : 0.0;
+  const double rr = sum_partials(a.partRR, a.nRR, red);
+  if (threadIdx.x == 0) {
+    const double php = (t1 + t2h + t2) + (double)a.shift * pp;
+    const double den = (double)a.cg_alpha * php;
+    const float alpha = (float)rr / (float)den;
+    a.scal[S_RR_OLD] = rr;
+    a.scal[S_PHP] = den;
+    a.scal[S_ALPHA] = (double)alpha;
+  }
+}
+
+// cg.py:52-53 after the fused outputs: beta = r'.r' / r.r ; p <- r' + beta * p ; partial p'.p' (next iteration's
+// shift term).  12*N bytes (read r', p; write p).  x and r were already updated by the fused epilogues.
+__global__ __launch_bounds__(kThreads) void k_cg_pdir(const bhg_chunk* __restrict__ chunks, int n_chunks,
+                                                      const float* __restrict__ r, float* __restrict__ p,
+                                                      const double* __restrict__ partRR_new, int nRR,
+                                                      double* __restrict__ partPP, double* __restrict__ scal) {
+  __shared__ double red[kWaves];
+  const double rr_new = sum_partials(partRR_new, nRR, red);
+  const double rr_old = scal[S_RR_OLD];
+  const float beta = (float)rr_new / (float)rr_old;
+  double acc = 0.0;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    float4 a[kVecPerThread], q[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      a[i] = ld4(r + ck.flat_off, e, ck.len);
+      q[i] = ld4(p + ck.flat_off, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      float4 np;
+      np.x = fz_add(a[i].x, fz_mul(beta, q[i].x)); np.y = fz_add(a[i].y, fz_mul(beta, q[i].y));
+      np.z = fz_add(a[i].z, fz_mul(beta, q[i].z)); np.w = fz_add(a[i].w, fz_mul(beta, q[i].w));
+      st4(p + ck.flat_off, e, ck.len, np);
+      acc += (double)np.x * np.x + (double)np.y * np.y + (double)np.z * np.z + (double)np.w * np.w;
+    }
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    partPP[blockIdx.x] = s;
+    if (blockIdx.x == 0) {
+      scal[S_RR_NEW] = rr_new;
+      scal[S_BETA] = (double)beta;
+    }
+  }
+}
+
+// ---- per-device side stream + events -------------------------------------------------------------------------------
+struct SideState {
+  hipStream_t side;
+  hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS], ev_rh[BHG_MLP_MAX_LAYERS];
+  hipEvent_t ev_join, ev_head, ev_alpha, ev_dir, ev_gsum;
+};
+int side_state(SideState** out) {
+  static SideState per_device[64];
+  int dev = 0;
+  BHG_HIP_CHECK(hipGetDevice(&dev));
+  BHG_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+  SideState& ss = per_device[dev];
+  if (!ss.side) {
+    // the side stream carries work that is OFF the critical path (weight-shaped outputs, the G pass): lowest priority,
+    // so the dependent chain on the caller's stream is dispatched first whenever both have workgroups waiting
+    int least = 0, greatest = 0;
+    static const bool flat_prio = getenv("BHG_SIDE_PRIO_DEFAULT") != nullptr;   // A/B switch (debug)
+    if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+    BHG_HIP_CHECK(hipStreamCreateWithPriority(&ss.side, hipStreamNonBlocking, least));
+    const unsigned fl = hipEventDisableTiming | hipEventDisableSystemFence;
+    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) {
+      BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_rd[i], fl));
+      BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_rh[i], fl));
+    }
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_join, fl));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_head, fl));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_alpha, fl));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_dir, fl));
+    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_gsum, fl));
+#define BHG_OUTER_LDS(F, M) \
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer<F, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    BHG_OUTER_LDS(true, FUSE_NONE); BHG_OUTER_LDS(false, FUSE_NONE);      // > 64 KiB dynamic LDS
+    BHG_OUTER_LDS(true, FUSE_CG); BHG_OUTER_LDS(false, FUSE_CG);
+    BHG_OUTER_LDS(true, FUSE_NEUMANN); BHG_OUTER_LDS(false, FUSE_NEUMANN);
+#undef BHG_OUTER_LDS
+  }
+  *out = &ss;
+  return BHG_OK;
+}
+
+bool use_head(const bhg_mlp* m) {
+  static const bool no_head = getenv("BHG_MLP_NO_HEAD") != nullptr;    // A/B switch (debug)
+  return !no_head && m->L >= 1 && m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0;
+}
+
+// Blocks of the weight-shaped output of layer l (fused CG: one r'.r' partial per block)
+int outer_blocks(const bhg_mlp* m, int l, bool head) {
+  const int Mo = m->dims[l + 1], No = m->dims[l];
+  if (head && l == m->L - 1) return ((No + 63) / 64) * Mo;
+  return ((No + kTN - 1) / kTN) * ((Mo + kTM - 1) / kTM);
+}
+int bias_blocks(const bhg_mlp* m) {
+  int blk = 0;
+  for (int l = 0; l < m->L; ++l) blk += (m->dims[l + 1] + 63) / 64;
+  return blk;
+}
+
+// Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve / _neumann_solve.
+struct FusedWs {
+  double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
+  float* gsum[BHG_MLP_MAX_LAYERS];       // [Bp][dims[l]], l = 1 .. L-2
+  float* gpartial[BHG_MLP_MAX_LAYERS];   // split-K slabs of the G pass
+  int gsplits[BHG_MLP_MAX_LAYERS];
+  int nRR, nT2;
+  size_t bytes;
+};
+void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
+  memset(w, 0, sizeof(*w));
+  const bool head = use_head(m);
+  int nrr = bias_blocks(m);
+  for (int l = 0; l < m->L; ++l) nrr += outer_blocks(m, l, head);
+  w->nRR = nrr;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base ? static_cast<char*>(base) + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+  w->partT1 = static_cast<double*>(take(sizeof(double) * m->Bp));
+  w->partT2h = static_cast<double*>(take(sizeof(double) * m->Bp));
+  w->partPP = static_cast<double*>(take(sizeof(double) * kMaxBlocks));
+  w->partRR[0] = static_cast<double*>(take(sizeof(double) * nrr));
+  w->partRR[1] = static_cast<double*>(take(sizeof(double) * nrr));
+  int nt2 = 0;
+  for (int l = 1; l + 1 < m->L; ++l) nt2 += (m->Bp * m->dims[l] / 4 + 255) / 256;
+  w->nT2 = nt2;
+  w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
+  for (int l = 1; l + 1 < m->L; ++l) {
+    const int N = m->dims[l], K = m->dims[l + 1];
+    const int tn = skinny_tile_n();
+    w->gsplits[l] = pick_splits((N + tn - 1) / tn, K, 1);
+    w->gsum[l] = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * N));
+    w->gpartial[l] = static_cast<float*>(take(sizeof(float) * (size_t)w->gsplits[l] * m->Bp * N));
+  }
+  w->bytes = off;
+}
+
+// What one pass of the HVP chain does with its weight-shaped outputs.
+struct ChainMode {
+  int mode;                     // FUSE_NONE: store H*dir into out[] | FUSE_CG | FUSE_NEUMANN
+  void* const* out;             // FUSE_NONE
+  float* fa; float* fb; const float* fd;   // fused: flat bases of FuseArgs a / b / d
+  const int64_t* starts;        // fused: element offsets of the 2L tensors inside the flat vectors
+  float alpha, shift, out_scale;
+  int apply_out;
+  // FUSE_CG
+  FusedWs* ws;
+  const double* partRR_old; int nRR_old;
+  const double* partPP; int nPP;
+  double* partRR_new;
+  double* scal;
+  float cg_alpha;
+};
+
+// One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
+// by the CG / Neumann recurrence while still on chip (fused modes).  On return everything is ordered on `st`.
+int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hipStream_t st) {
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  const float rho2 = cm.mode == FUSE_NONE ? m->ridge2 : 0.f;
+  const bool cg = cm.mode == FUSE_CG;
+  static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;    // A/B switches (debug)
+  static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;
+  const bool head = use_head(m);
+  BHG_REQUIRE(!cg || (head && !no_side), "the fused CG solver needs the narrow-head kernels and the side stream");
+  SideState* ssp = nullptr;
+  if (int rc = side_state(&ssp)) return rc;
+  SideState& ss = *ssp;
+  hipStream_t side = ss.side;
+  const int tn = skinny_tile_n();
+
+  FuseArgs fbase{};
+  fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
+  fbase.out_scale = cm.out_scale; fbase.apply_out = cm.apply_out;
+  auto fuse_at = [&](int tensor, int part_base) {
+    FuseArgs f = fbase;
+    if (cm.mode != FUSE_NONE) {
+      const int64_t o = cm.starts[tensor];
+      f.a = cm.fa + o; f.b = cm.fb + o; f.d = cm.fd + o;
+    }
+    f.part_base = part_base;
+    return f;
+  };
+  // r'.r' partial slots of the fused CG epilogues: [W_0 tiles][W_1 tiles]...[bias blocks]
+  int part_base_w[BHG_MLP_MAX_LAYERS], part_base_bias = 0;
+  {
+    int base = 0;
+    for (int l = 0; l < L; ++l) { part_base_w[l] = base; base += outer_blocks(m, l, head); }
+    part_base_bias = base;
+  }
+
+  // ---- fused CG: the chain-independent G pass  G_l = delta_l V_l  (l = 1 .. L-2) on the side stream -------------------
+  if (cg) {
+    BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_dir, 0));   // the direction (and last iteration's scalars) are final
+    for (int l = L - 2; l >= 1; --l) {
+      const int K = m->dims[l + 1], N = m->dims[l];
+      GemmArgs a{};
+      a.pr[0] = {m->delta[l], static_cast<const float*>(dir[2 * l]), K, N};
+      a.pairs = 1;
+      a.M = Bp; a.N = N; a.K = K;
+      a.splits = cm.ws->gsplits[l];
+      a.out = cm.ws->gpartial[l]; a.ldo = N; a.out_rows = Bp;
+      launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, side);
+    }
+  }
+
+  // ---- R-forward ------------------------------------------------------------------------------------
+  HeadFuse head_fuse{};
+  bool fuse_head = false;
+  for (int l = 0; l < L; ++l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    const float* c = static_cast<const float*>(dir[2 * l + 1]);
+    if (head && l == L - 1) {
+      launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, m->sd,
+                          m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
+                          l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
+                          fuse_head ? &head_fuse : nullptr, cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr);
+      if (cg) BHG_HIP_CHECK(hipEventRecord(ss.ev_head, st));
+      continue;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->h[l], V, K, K};                       // h_{l-1} V_l^T
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
+    a.M = Bp; a.N = N; a.K = K;
+    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    const int slab = Bp * N;
+    if (head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024) {
+      // the head kernel of the next layer combines these slabs itself (one launch less on the chain)
+      head_fuse = {m->partial, a.splits, slab, c, m->mask[l], m->Rh[l]};
+      fuse_head = true;
+    } else if (l + 1 < L) {
+      launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
+      if (cg) BHG_HIP_CHECK(hipEventRecord(ss.ev_rh[l], st));
+    } else {
+      hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
+                         a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
+    }
+  }
+
+  // ---- fused CG: reduce the G slabs, T2, then the step length — all on the side stream, beside the R-backward chain --
+  if (cg) {
+    if (L >= 3) {
+      // G_l needs Rh_{l-1}: every Rh_j, j <= L-3, is written by an explicit reduce (only Rh_{L-2} can live inside the
+      // head kernel), the last of them by the reduce of layer L-3
+      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rh[L - 3], 0));
+      int done = 0;
+      for (int l0 = 1; l0 + 1 < L; l0 += 2) {
+        GsumArgs g{};
+        int blk = 0;
+        for (int q = 0; q < 2 && l0 + q + 1 < L; ++q) {
+          const int l = l0 + q;
+          g.part[q] = cm.ws->gpartial[l]; g.splits[q] = cm.ws->gsplits[l]; g.slab[q] = Bp * m->dims[l];
+          g.rh[q] = m->Rh[l - 1]; g.gsum[q] = cm.ws->gsum[l];
+          g.blk0[q] = blk;
+          blk += (Bp * m->dims[l] / 4 + 255) / 256;
+          g.n = q + 1;
+        }
+        g.blk0[g.n] = blk;
+        hipLaunchKernelGGL(k_gsum_dot, dim3(blk), dim3(256), 0, side, g, cm.ws->partT2 + done);
+        done += blk;
+      }
+      BHG_HIP_CHECK(hipEventRecord(ss.ev_gsum, side));
+    }
+    BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_head, 0));
+    AlphaArgs aa{};
+    aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
+    aa.partT2 = cm.ws->partT2; aa.nT2 = L >= 3 ? cm.ws->nT2 : 0;
+    aa.partPP = cm.partPP; aa.nPP = cm.nPP;
+    aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
+    aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
+    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, side, aa);
+    BHG_HIP_CHECK(hipEventRecord(ss.ev_alpha, side));
+  }
+
+  // ---- R-backward (main stream) overlapped with the weight-shaped outputs (side stream) ----------------
+  // H(W_l) only needs Rd_l and Rh_{l-1}; the R-backward chain that produces Rd_{l-1} is independent of
+  // it.  The many-workgroup outer products therefore run on a library-owned side stream and fill the
+  // CUs the short, latency-bound split-K kernels of the backward chain leave idle.
+  auto launch_outer = [&](int l, hipStream_t s) {
+    const int Mo = m->dims[l + 1], No = m->dims[l];
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    const FuseArgs fz = fuse_at(2 * l, part_base_w[l]);
+    float* outp = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l]) : nullptr;
+    if (head && l == L - 1) {
+      const dim3 grid((No + 63) / 64, Mo);
+#define BHG_HEAD_OUTER(RH, MODE)                                                                                       \
+  hipLaunchKernelGGL((k_head_outer<RH, MODE>), grid, dim3(256), 0, s, (const float*)m->Rd[l], m->h[l], m->delta[l],    \
+                     RH ? (const float*)m->Rh[l - 1] : (const float*)nullptr, V, rho2, outp, No, Mo, B, fz)
+      if (l > 0) {
+        if (cm.mode == FUSE_CG) BHG_HEAD_OUTER(true, FUSE_CG);
+        else if (cm.mode == FUSE_NEUMANN) BHG_HEAD_OUTER(true, FUSE_NEUMANN);
+        else BHG_HEAD_OUTER(true, FUSE_NONE);
+      } else {
+        if (cm.mode == FUSE_CG) BHG_HEAD_OUTER(false, FUSE_CG);
+        else if (cm.mode == FUSE_NEUMANN) BHG_HEAD_OUTER(false, FUSE_NEUMANN);
+        else BHG_HEAD_OUTER(false, FUSE_NONE);
+      }
+#undef BHG_HEAD_OUTER
+      return;
+    }
+    GemmArgs a{};
+    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
+    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
+    a.splits = 1;
+    a.out = outp; a.ldo = No; a.out_rows = 0;
+    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
+    a.kstages = (B + kOH - 1) / kOH < 2 ? 2 : (B + kOH - 1) / kOH;   // <= 64 K rows per pipeline stage
+    const int Kh = (((B + a.kstages - 1) / a.kstages) + 1) & ~1;      // (see k_outer)
+    size_t lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
+    const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
+    if (lds < lds_c) lds = lds_c;
+    dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
+    bool fast = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
+    for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+    if (cm.mode != FUSE_NONE) fast = fast && (cm.starts[2 * l] & 3) == 0;   // 16-B aligned state slices
+    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
+    if (no_fast) fast = false;
+#define BHG_OUTER(MODE)                                                                   \
+  do {                                                                                    \
+    if (fast) hipLaunchKernelGGL((k_outer<true, MODE>), grid, dim3(256), lds, s, a, fz);  \
+    else hipLaunchKernelGGL((k_outer<false, MODE>), grid, dim3(256), lds, s, a, fz);      \
+  } while (0)
+    if (cm.mode == FUSE_CG) BHG_OUTER(FUSE_CG);
+    else if (cm.mode == FUSE_NEUMANN) BHG_OUTER(FUSE_NEUMANN);
+    else BHG_OUTER(FUSE_NONE);
+#undef BHG_OUTER
+  };
+  for (int l = L - 1; l >= 1; --l) {
+    // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
+    if (no_side) {
+      launch_outer(l, st);
+    } else {
+      // (fused CG: ev_head / ev_rd[l] were waited for before k_cg_alpha or are recorded below; the side stream's
+      //  own order puts every fused epilogue behind k_cg_alpha)
+      if (!(cg && head && l == L - 1)) {   // that case: Rd_{L-1}, Rd_{L-2} come from the head kernel = ev_head, already waited
+        BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[l], st));
+        BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[l], 0));
+      }
+      launch_outer(l, side);
+    }
+    const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
+    GemmArgs a{};
+    if (cg) {   // delta_l V_l comes from the G pass (its sum is the reduce's addend): only Rd_l W_l is on the chain
+      a.pr[0] = {m->Rd[l], m->W[l], K, N};
+      a.pairs = 1;
+    } else {
+      a.pr[0] = {m->delta[l], V, K, N};
+      a.pr[1] = {m->Rd[l], m->W[l], K, N};
+      a.pairs = 2;
+    }
+    a.M = Bp; a.N = N; a.K = K;
+    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
+    const int slab = Bp * N;
+    if (cg && l == L - 2) BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_gsum, 0));   // first consumer of the G sums
+    launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B, nullptr,
+                       cg ? cm.ws->gsum[l] : nullptr);
+  }
+  {
+    BiasArgs ba{};
+    ba.L = L; ba.B = B; ba.rho2 = rho2;
+    int blk = 0;
+    for (int l = 0; l < L; ++l) {
+      ba.rd[l] = m->Rd[l];
+      ba.c[l] = static_cast<const float*>(dir[2 * l + 1]);
+      ba.out[l] = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l + 1]) : nullptr;
+      ba.foff[l] = cm.mode == FUSE_NONE ? 0 : cm.starts[2 * l + 1];
+      ba.n[l] = m->dims[l + 1];
+      ba.blk0[l] = blk;
+      blk += (m->dims[l + 1] + 63) / 64;
+    }
+    ba.blk0[L] = blk;
+    FuseArgs fz = fbase;
+    fz.a = cm.fa; fz.b = cm.fb; fz.d = cm.fd; fz.part_base = part_base_bias;   // offsets travel in ba.foff
+    hipStream_t bs = st;
+    if (L > 1 && !no_side) {  // needs every Rd_l (complete on the main stream now); runs beside H(W_0)
+      BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
+      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
+      bs = side;
+    } else if (cg) {
+      BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_alpha, 0));
+    }
+    if (cm.mode == FUSE_CG) hipLaunchKernelGGL(k_bias_hvp<FUSE_CG>, dim3(blk), dim3(256), 0, bs, ba, fz);
+    else if (cm.mode == FUSE_NEUMANN) hipLaunchKernelGGL(k_bias_hvp<FUSE_NEUMANN>, dim3(blk), dim3(256), 0, bs, ba, fz);
+    else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(blk), dim3(256), 0, bs, ba, fz);
+  }
+  if (cg) BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_alpha, 0));   // the step length (long done: it was due at the head)
+  launch_outer(0, st);  // needs Rd_0, the end of the chain
+  if (L > 1 && !no_side) {
+    BHG_HIP_CHECK(hipEventRecord(ss.ev_join, side));
+    BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_join, 0));
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int check_mlp(const bhg_mlp* m) {
+  BHG_REQUIRE(m, "NULL descriptor");
+  BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
+  BHG_REQUIRE(m->Bp > 0 && m->Bp % kTM == 0 && m->B >= 1 && m->B <= m->Bp, "Bp must be a multiple of 128 rows >= B");
+  return BHG_OK;
 }
 
 }  // namespace
@@ -958,166 +1600,115 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
 }
 
 int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream) {
-  BHG_REQUIRE(m && dir && out, "NULL argument");
-  BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
-  BHG_REQUIRE(m->Bp > 0 && m->Bp % kTM == 0 && m->B >= 1 && m->B <= m->Bp, "Bp must be a multiple of 128 rows >= B");
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(dir && out, "NULL argument");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int L = m->L, Bp = m->Bp, B = m->B;
-  const float rho2 = m->ridge2;
-
   hipEvent_t t_a, t_b;
   const bool timed = span_begin(BHG_TIMING_MLP_HVP, &t_a, &t_b);
   if (timed) BHG_HIP_CHECK(hipEventRecord(t_a, st));
-  // a narrow classifier head (<= 32 classes, feature width a multiple of 4) takes the dedicated kernels
-  static const bool no_head = getenv("BHG_MLP_NO_HEAD") != nullptr;    // A/B switches (debug)
-  static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;
-  const bool head = !no_head && L >= 1 && m->dims[L] <= kSmallC && (m->dims[L - 1] & 3) == 0;
-  // ---- R-forward ------------------------------------------------------------------------------------
-  static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;   // A/B switch (debug)
-  HeadFuse head_fuse{};
-  bool fuse_head = false;
-  for (int l = 0; l < L; ++l) {
-    const int K = m->dims[l], N = m->dims[l + 1];
-    const float* V = static_cast<const float*>(dir[2 * l]);
-    const float* c = static_cast<const float*>(dir[2 * l + 1]);
-    if (head && l == L - 1) {
-      launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, m->sd,
-                          m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
-                          l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
-                          fuse_head ? &head_fuse : nullptr);
-      continue;
-    }
-    GemmArgs a{};
-    a.pr[0] = {m->h[l], V, K, K};                       // h_{l-1} V_l^T
-    a.pairs = 1;
-    if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
-    a.M = Bp; a.N = N; a.K = K;
-    const int tn = skinny_tile_n();
-    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
-    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
-    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
-    const int slab = Bp * N;
-    if (head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024) {
-      // the head kernel of the next layer combines these slabs itself (one launch less on the chain)
-      head_fuse = {m->partial, a.splits, slab, c, m->mask[l], m->Rh[l]};
-      fuse_head = true;
-    } else if (l + 1 < L) {
-      launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
-    } else {
-      hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
-                         a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
-    }
-  }
-  // ---- R-backward (main stream) overlapped with the weight-shaped outputs (side stream) ----------------
-  // H(W_l) only needs Rd_l and Rh_{l-1}; the R-backward chain that produces Rd_{l-1} is independent of
-  // it.  The many-workgroup outer products therefore run on a library-owned side stream and fill the
-  // CUs the short, latency-bound split-K kernels of the backward chain leave idle.
-  // one side stream + event set per device (streams and events belong to the device they were created on)
-  struct SideState { hipStream_t side; hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS]; hipEvent_t ev_join; };
-  static SideState per_device[64];
-  int dev = 0;
-  BHG_HIP_CHECK(hipGetDevice(&dev));
-  BHG_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-  SideState& ss = per_device[dev];
-  hipStream_t& side = ss.side;
-  hipEvent_t* ev_rd = ss.ev_rd;
-  hipEvent_t& ev_join = ss.ev_join;
-  if (!side) {
-    BHG_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_rd[i], hipEventDisableTiming | hipEventDisableSystemFence));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
-    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // > 64 KiB dynamic LDS
-    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
-  auto launch_outer = [&](int l, hipStream_t s) {
-    const int Mo = m->dims[l + 1], No = m->dims[l];
-    const float* V = static_cast<const float*>(dir[2 * l]);
-    if (head && l == L - 1) {
-      if (l > 0)
-        hipLaunchKernelGGL(k_head_outer<true>, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l],
-                           m->h[l], m->delta[l], (const float*)m->Rh[l - 1], V, rho2, static_cast<float*>(out[2 * l]), No,
-                           Mo, B);
-      else
-        hipLaunchKernelGGL(k_head_outer<false>, dim3((No + 63) / 64, Mo), dim3(256), 0, s, (const float*)m->Rd[l],
-                           m->h[l], m->delta[l], (const float*)nullptr, V, rho2, static_cast<float*>(out[2 * l]), No, Mo,
-                           B);
-      return;
-    }
-    GemmArgs a{};
-    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
-    a.pairs = 1;
-    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
-    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
-    a.splits = 1;
-    a.out = static_cast<float*>(out[2 * l]); a.ldo = No; a.out_rows = 0;
-    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
-    a.kstages = (B + kOH - 1) / kOH < 2 ? 2 : (B + kOH - 1) / kOH;   // <= 64 K rows per pipeline stage
-    const int Kh = (((B + a.kstages - 1) / a.kstages) + 1) & ~1;      // (see k_outer)
-    size_t lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
-    const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
-    if (lds < lds_c) lds = lds_c;
-    dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
-    bool fast = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
-    for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
-    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
-    if (fast && !no_fast) hipLaunchKernelGGL(k_outer<true>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(k_outer<false>, grid, dim3(256), lds, s, a);
-  };
-  for (int l = L - 1; l >= 1; --l) {
-    // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
-    if (no_side) {
-      launch_outer(l, st);
-    } else {
-      BHG_HIP_CHECK(hipEventRecord(ev_rd[l], st));
-      BHG_HIP_CHECK(hipStreamWaitEvent(side, ev_rd[l], 0));
-      launch_outer(l, side);
-    }
-    const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
-    const float* V = static_cast<const float*>(dir[2 * l]);
-    if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
-    GemmArgs a{};
-    a.pr[0] = {m->delta[l], V, K, N};
-    a.pr[1] = {m->Rd[l], m->W[l], K, N};
-    a.pairs = 2;
-    a.M = Bp; a.N = N; a.K = K;
-    const int tn = skinny_tile_n();
-    a.splits = pick_splits((N + tn - 1) / tn, K, 2);
-    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
-    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
-    const int slab = Bp * N;
-    launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
-  }
-  {
-    BiasArgs ba{};
-    ba.L = L; ba.B = B; ba.rho2 = rho2;
-    int blk = 0;
-    for (int l = 0; l < L; ++l) {
-      ba.rd[l] = m->Rd[l];
-      ba.c[l] = static_cast<const float*>(dir[2 * l + 1]);
-      ba.out[l] = static_cast<float*>(out[2 * l + 1]);
-      ba.n[l] = m->dims[l + 1];
-      ba.blk0[l] = blk;
-      blk += (m->dims[l + 1] + 63) / 64;
-    }
-    ba.blk0[L] = blk;
-    if (L > 1 && !no_side) {  // needs every Rd_l (complete on the main stream now); runs beside H(W_0)
-      BHG_HIP_CHECK(hipEventRecord(ev_rd[0], st));
-      BHG_HIP_CHECK(hipStreamWaitEvent(side, ev_rd[0], 0));
-      hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, side, ba);
-    } else {
-      hipLaunchKernelGGL(k_bias_hvp, dim3(blk), dim3(256), 0, st, ba);
-    }
-  }
-  launch_outer(0, st);  // needs Rd_0, the end of the chain
-  if (L > 1 && !no_side) {
-    BHG_HIP_CHECK(hipEventRecord(ev_join, side));
-    BHG_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
-  }
+  ChainMode cm{};
+  cm.mode = FUSE_NONE;
+  cm.out = out;
+  if (int rc = run_chain(m, dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(t_b, st));
+  return BHG_OK;
+}
+
+// ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
+int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
+  static const bool off = getenv("BHG_MLP_NO_FUSED_SOLVE") != nullptr;   // A/B switch: callers fall back to HVP + recurrence kernel
+  return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m) &&
+         getenv("BHG_MLP_NO_SIDE") == nullptr;
+}
+
+size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m) {
+  if (!m || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS || m->Bp <= 0) return 0;
+  FusedWs w;
+  carve_fused_ws(m, nullptr, &w);
+  return w.bytes;
+}
+
+static int solve_common_checks(const bhg_mlp* m, const int64_t* starts, const void* fws, size_t fws_bytes) {
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(bhg_mlp_supports_fused_solve(m), "fused solve needs a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
+  BHG_REQUIRE(starts && fws, "NULL argument");
+  BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
+  BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  for (int l = 0; l < m->L; ++l) BHG_REQUIRE((starts[2 * l] & 3) == 0, "weight slices of the flat vectors must be 16-byte aligned");
+  return BHG_OK;
+}
+
+int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
+                     const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
+                     void* fws, size_t fws_bytes, void* stream) {
+  if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
+  BHG_REQUIRE(x && r && p && ws && chunks_dev, "NULL argument");
+  BHG_REQUIRE(K >= 0 && n_chunks > 0, "bad size");
+  if (K == 0) return BHG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  SideState* ss = nullptr;
+  if (int rc = side_state(&ss)) return rc;
+  char* wsb = static_cast<char*>(ws);
+  double* scal = reinterpret_cast<double*>(wsb + kWsScal);
+  const double* partR0 = reinterpret_cast<const double*>(wsb + kWsPartR);   // r.r partials of bhg_cg_init (r = p there)
+  const int n_init = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
+  const void* dir[2 * BHG_MLP_MAX_LAYERS];
+  for (int i = 0; i < 2 * m->L; ++i) dir[i] = p + starts[i];
+  const int pgrid = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
+  for (int k = 0; k < K; ++k) {
+    hipEvent_t ta, tb, tc, td;
+    const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
+    const bool timed_it = span_begin(BHG_TIMING_MLP_CG_ITER, &tc, &td);
+    if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
+    if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
+    BHG_HIP_CHECK(hipEventRecord(ss->ev_dir, st));   // p (and for k = 0: bhg_cg_init's state) is final here
+    ChainMode cm{};
+    cm.mode = FUSE_CG;
+    cm.fa = r; cm.fb = x; cm.fd = p; cm.starts = starts;
+    cm.shift = hvp_shift; cm.cg_alpha = cg_alpha;
+    cm.apply_out = k == K - 1; cm.out_scale = -cg_alpha;   // cg.py:56 and the negation of cg.py:59/68
+    cm.ws = &w; cm.scal = scal;
+    cm.partRR_old = k == 0 ? partR0 : w.partRR[k & 1];
+    cm.nRR_old = k == 0 ? n_init : w.nRR;
+    cm.partPP = k == 0 ? partR0 : w.partPP;   // p = r after the init, so p.p = r.r
+    cm.nPP = k == 0 ? n_init : pgrid;
+    cm.partRR_new = w.partRR[(k + 1) & 1];
+    if (int rc = run_chain(m, dir, cm, st)) return rc;
+    if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
+    if (k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
+      hipLaunchKernelGGL(k_cg_pdir, dim3(pgrid), dim3(kThreads), 0, st, chunks_dev, n_chunks, (const float*)r, p,
+                         (const double*)w.partRR[(k + 1) & 1], w.nRR, w.partPP, scal);
+    if (timed_it) BHG_HIP_CHECK(hipEventRecord(td, st));
+  }
   BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K, float alpha,
+                          float hvp_shift, void* fws, size_t fws_bytes, void* stream) {
+  if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
+  BHG_REQUIRE(v0 && v1 && p, "NULL argument");
+  BHG_REQUIRE(K >= 0, "bad size");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int k = 0; k < K; ++k) {
+    float* vin = (k & 1) ? v1 : v0;
+    float* vout = (k & 1) ? v0 : v1;
+    const void* dir[2 * BHG_MLP_MAX_LAYERS];
+    for (int i = 0; i < 2 * m->L; ++i) dir[i] = vin + starts[i];
+    hipEvent_t ta, tb;
+    const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
+    if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
+    ChainMode cm{};
+    cm.mode = FUSE_NEUMANN;
+    cm.fa = vout; cm.fb = p; cm.fd = vin; cm.starts = starts;
+    cm.alpha = alpha; cm.shift = hvp_shift;
+    cm.apply_out = k == K - 1; cm.out_scale = -alpha;   // neumann.py:66 and the negation of neumann.py:45/54
+    if (int rc = run_chain(m, dir, cm, st)) return rc;
+    if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
+  }
   return BHG_OK;
 }
 

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(kThreads) void k_cg_dir(const bhg_chunk* __restrict
                                                      float* __restrict__ x, const float* __restrict__ r,
                                                      float* __restrict__ p,
                                                      const double* __restrict__ partR_new, int n_part,
-                                                     float out_scale, double* __restrict__ scal) {
+                                                     float out_scale, double* __restrict__ scal,
+                                                     unsigned* __restrict__ barrier_words, unsigned resident_arrivals) {
   __shared__ double red[kWaves];
   const double rr_new = sum_partials(partR_new, n_part, red);
   const double rr_old = scal[S_RR_OLD];
@@ -312,6 +313,9 @@ __global__ __launch_bounds__(kThreads) void k_cg_dir(const bhg_chunk* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     scal[S_RR_NEW] = rr_new;
     scal[S_BETA] = (double)beta;
+    // the resident kernel's barrier targets count 2 arrivals per workgroup and COMPLETED iteration: credit this
+    // streamed iteration, so a later iteration of the same solve may use the resident kernel
+    barrier_words[0] += resident_arrivals;
   }
 }
 
@@ -670,7 +674,7 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 bool g_timing = false;
 std::vector<TimedSpan> g_spans;
 std::vector<hipEvent_t> g_free_events;
-constexpr size_t kMaxSpans = 8192;
+constexpr size_t kMaxSpans = 16384;
 hipEvent_t take_event() {
   if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -898,8 +902,9 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   // The producer of r.r for iteration `iter` wrote partR[iter & 1]; this iteration writes the other.
   double* partR_old = partR + (size_t)(iter & 1) * kMaxBlocks;
   double* partR_new = partR + (size_t)((iter + 1) & 1) * kMaxBlocks;
-  // How many partials the previous producer wrote travels in scal[S_NPART0 + parity], so the
-  // stream and resident variants may be mixed freely between iterations.
+  // How many partials the previous producer wrote travels in scal[S_NPART0 + parity], and a streamed
+  // iteration credits the resident kernel's arrival counter (k_cg_dir), so the stream and resident
+  // variants may be mixed between iterations of one solve.
   const int n_stream = grid_for(n_chunks);
   hipEvent_t ea, eb;
   const bool timed = span_begin(BHG_TIMING_CG_STEP, &ea, &eb);
@@ -912,7 +917,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
                        (const float*)p, hvp_shift, (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
     hipExtLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, nullptr, timed ? eb : nullptr, 0,
                           chunks_dev, n_chunks, x, (const float*)r, p, (const double*)partR_new, n_stream,
-                          out_scale, scal);
+                          out_scale, scal, reinterpret_cast<unsigned*>(w + kWsBarrier), 2u * (unsigned)num_cus());
   } else {
     const int G = num_cus();
     hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,

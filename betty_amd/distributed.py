@@ -25,14 +25,20 @@ from .backend import get_backend
 
 
 class ExchangeHandle:
-    def __init__(self, layout, flat, like, work, world):
+    def __init__(self, layout, flat, like, work, world, backend=None):
         self._layout, self._flat, self._like, self._work, self._world = layout, flat, like, work, world
+        self._be = backend
+        if work is not None and backend is not None:
+            backend.collectives_in_flight += 1   # resident CG kernel is not eligible while RCCL kernels hold CUs
 
     def wait(self) -> List[torch.Tensor]:
         """Block the CURRENT stream (not the host) on the collective and return the averaged tensors
         (views of the flat buffer)."""
         if self._work is not None:
             self._work.wait()
+            self._work = None
+            if self._be is not None:
+                self._be.collectives_in_flight -= 1
         return self._layout.views(self._flat, self._like)
 
 
@@ -47,4 +53,4 @@ def exchange_async(grads: Sequence[torch.Tensor], group: Optional[dist.ProcessGr
     work = None
     if world > 1:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    return ExchangeHandle(layout, flat, grads, work, world)
+    return ExchangeHandle(layout, flat, grads, work, world, be if hasattr(be, "collectives_in_flight") else None)

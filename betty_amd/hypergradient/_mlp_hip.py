@@ -172,9 +172,50 @@ class HipMLPState:
         cached = getattr(self, "_dir_cache", None)
         if cached is None or cached[0] != key:
             tab, keep = self._dir_table(direction_views)
-            cached = self._dir_cache = (key, tab, keep, list(direction_views))
+            cached = (key, tab, keep, list(direction_views))
+            # only a table that names the CALLER's tensors may be reused: a converted clone goes stale as soon as
+            # the caller changes the direction in place
+            self._dir_cache = cached if all(a is b for a, b in zip(keep[0], direction_views)) else None
         _native.check(self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), cached[1], self._out_tab, _stream()), "bhg_mlp_hvp")
         return self.out
+
+    # ---- fused solvers (csrc/bhg_mlp.hip: bhg_mlp_cg_solve / bhg_mlp_neumann_solve) -----------------------------------
+    def fused_supported(self, layout) -> bool:
+        """True when the whole K loop can run natively with the recurrence fused into the HVP's output kernels:
+        narrow classifier head, and ``layout`` is the flat layout of exactly [W1, b1, W2, b2, ...]."""
+        if not self.lib.bhg_mlp_supports_fused_solve(ctypes.byref(self.desc)):
+            return False
+        want = []
+        for W in self.Ws:
+            want += [W.numel(), W.shape[0]]
+        return tuple(want) == tuple(layout.numels) and str(layout.device) == str(self.Ws[0].device)
+
+    def _fused_args(self, layout):
+        buf = self.buf
+        if getattr(buf, "fws", None) is None:
+            n = int(self.lib.bhg_mlp_fused_ws_bytes(ctypes.byref(self.desc)))
+            buf.fws = torch.zeros(max(n, 256), dtype=torch.uint8, device=layout.device)
+        starts = (ctypes.c_int64 * len(layout.starts))(*layout.starts)
+        return buf.fws, starts
+
+    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float) -> None:
+        """cg.py:38-56 for this structure: K x (HVP chain with fused r/x update + direction update)."""
+        fws, starts = self._fused_args(layout)
+        _native.check(
+            self.lib.bhg_mlp_cg_solve(ctypes.byref(self.desc), x.data_ptr(), r.data_ptr(), p.data_ptr(), starts,
+                                      layout.chunks_dev.data_ptr(), layout.n_chunks, int(K), float(cg_alpha), float(shift),
+                                      layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
+            "bhg_mlp_cg_solve",
+        )
+
+    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float) -> None:
+        """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'."""
+        fws, starts = self._fused_args(layout)
+        _native.check(
+            self.lib.bhg_mlp_neumann_solve(ctypes.byref(self.desc), v0.data_ptr(), v1.data_ptr(), p.data_ptr(), starts, int(K),
+                                           float(alpha), float(shift), fws.data_ptr(), fws.numel(), _stream()),
+            "bhg_mlp_neumann_solve",
+        )
 
     def mixed_coeff(self, dir_views):
         """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step."""

@@ -41,10 +41,18 @@ def cg(vector, curr, prev, sync):
     # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.cg_alpha)
-    for k in range(K):
-        hvp = hvp_fn(p_views)  # H p   (cg.py:39-41)
-        # cg.py:42-55 in one launch group; the last one also applies cg.py:56 and the negation
-        be.cg_step(layout, hvp, x, r, p, alpha, k, out_scale=(-alpha if k == K - 1 else 0.0), hvp_shift=shift)
+    fused = getattr(provider, "fused_cg", None)
+    if fused is not None and alpha != 0.0 and fused(layout, x, r, p, K, alpha):
+        pass  # the provider's own kernels ran all K iterations (HVP outputs consumed on chip, no N-sized H p)
+    else:
+        for k in range(K):
+            hvp = hvp_fn(p_views)  # H p   (cg.py:39-41)
+            # cg.py:42-55 in one launch group; the last one also applies cg.py:56 and the negation
+            last = k == K - 1 and alpha != 0.0
+            be.cg_step(layout, hvp, x, r, p, alpha, k, out_scale=(-alpha if last else 0.0), hvp_shift=shift)
+        if K > 0 and alpha == 0.0:
+            be.scale_flat(x, -alpha)  # out_scale = 0 means "no final scaling" to the kernel: do cg.py:56 explicitly
+        be.after_cg(layout)
     # K == 0: x is identically zero, -alpha * 0 needs no pass.
 
     neg_x = layout.views(x, vector)

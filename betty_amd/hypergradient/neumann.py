@@ -35,11 +35,16 @@ def neumann(vector, curr, prev, sync):
     K = int(config.neumann_iterations)
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.neumann_alpha)
-    for k in range(K):
-        hvp = hvp_fn(v_views)  # neumann.py:62
-        be.neumann_step(layout, hvp, v, p, alpha, out_scale=(-alpha if k == K - 1 else 0.0), hvp_shift=shift)  # 63-64 (+66)
-    if K == 0:
-        be.scale_flat(p, -alpha)  # alpha * p with p = v   (neumann.py:66)
+    fused = getattr(provider, "fused_neumann", None)
+    if fused is not None and alpha != 0.0 and fused(layout, v, p, K, alpha):
+        pass  # the provider's own kernels ran all K iterations (v ping-pongs with a third flat vector of the layout)
+    else:
+        for k in range(K):
+            hvp = hvp_fn(v_views)  # neumann.py:62
+            last = k == K - 1 and alpha != 0.0
+            be.neumann_step(layout, hvp, v, p, alpha, out_scale=(-alpha if last else 0.0), hvp_shift=shift)  # 63-64 (+66)
+        if K == 0 or alpha == 0.0:
+            be.scale_flat(p, -alpha)  # alpha * p (with p = v when K == 0)   (neumann.py:66)
 
     neg_p = layout.views(p, vector)
     if provider is not None:

@@ -52,6 +52,11 @@ class WeightedCEMLP:
                     H(b_l) = sum_batch Rdelta_l + 2 ridge c_l
       mixed VJP to lam: c_i = (p_i - onehot_i).Rz_i(x) / B, then backward of sum_i c_i s_i(lam).
 
+    With the HIP implementation and a narrow classifier head the whole K loop runs natively and "one pass"
+    (``fused_cg`` / ``fused_neumann``, csrc/bhg_mlp.hip ``bhg_mlp_cg_solve`` / ``bhg_mlp_neumann_solve``): the
+    kernels that produce H(W_l), H(b_l) apply the CG / Neumann update to the flat state vectors while the tile is
+    on chip, so no N-sized H*direction vector exists.
+
     The HVP callable returns the Hessian WITHOUT its ``2*ridge*I`` part; ``hvp_shift = 2*ridge`` tells
     cg/neumann to add ``hvp_shift * direction`` inside the fused recurrence kernel.
 
@@ -62,7 +67,7 @@ class WeightedCEMLP:
     """
 
     def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
-                 batch=None, impl: Optional[str] = None):
+                 batch=None, impl: Optional[str] = None, fused: bool = True):
         self.curr, self.prev = curr, prev
         self.layers = list(layers)
         self.weight_fn = weight_fn
@@ -72,6 +77,9 @@ class WeightedCEMLP:
         self.hvp_shift = 2.0 * self.ridge
         self.batch = batch
         self.impl = impl
+        # fused=False keeps the K loop as K x (HVP kernels + recurrence kernel) — the A/B arm of the tests and of
+        # ``bench.py --no-fuse``; the product default lets the HVP's output kernels apply the recurrence themselves
+        self.fused = bool(fused)
         params = list(curr.parameters())
         expect = []
         for lin in self.layers:
@@ -92,6 +100,25 @@ class WeightedCEMLP:
         else:
             raise ValueError(f"unknown impl {impl!r}")
         return self._state.hvp
+
+    # Optional protocol extension: a provider whose HVP kernels can apply the recurrence themselves runs the whole K
+    # loop ("one pass": no N-sized H*direction vector).  Both return False when the fused path does not apply and the
+    # caller falls back to K x (hvp_fn + recurrence kernel).
+    def fused_cg(self, layout, x, r, p, K: int, cg_alpha: float) -> bool:
+        st = self._state
+        if K <= 0 or not self.fused or not hasattr(st, "cg_solve") or not st.fused_supported(layout):
+            return False
+        st.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift)
+        return True
+
+    def fused_neumann(self, layout, v, p, K: int, alpha: float) -> bool:
+        st = self._state
+        if K <= 0 or not self.fused or not hasattr(st, "neumann_solve") or not st.fused_supported(layout):
+            return False
+        # second direction buffer: the R-backward GEMMs of an HVP still read v while its epilogues write v'
+        v_alt = next(t for t in layout.state(3) if t is not v and t is not p)
+        st.neumann_solve(layout, v, v_alt, p, K, alpha, self.hvp_shift)
+        return True
 
     def mixed_vjp(self, neg_x_views, sync: bool):
         st = self._state

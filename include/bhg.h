@@ -159,7 +159,9 @@ int bhg_sama_adam_precondition(const void* const* vec, const void* const* last_g
  * the recorded spans of `kind` and returns their summed duration and count.           */
 #define BHG_TIMING_CG_STEP 0
 #define BHG_TIMING_NEUMANN_STEP 1
-#define BHG_TIMING_MLP_HVP 2      /* whole bhg_mlp_hvp call: event before the first / after the last launch */
+#define BHG_TIMING_MLP_HVP 2      /* whole bhg_mlp_hvp call (or one fused-solver iteration's HVP chain incl. its
+                                     fused recurrence epilogues): event before the first / after the last launch */
+#define BHG_TIMING_MLP_CG_ITER 3  /* one whole iteration of bhg_mlp_cg_solve: HVP chain + direction update      */
 int bhg_timing_enable(int on);
 int bhg_timing_read(int kind, double* total_ms, int* launches);
 
@@ -214,6 +216,28 @@ int bhg_mlp_supports_native_prepare(const bhg_mlp* m);
 int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* stream);
 int bhg_mlp_backward(const bhg_mlp* m, const int64_t* labels, void* stream);
 int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t* labels, float* coeff, void* stream);
+
+/* ---- fused solvers ("one pass"): K iterations of HVP + recurrence for the MLP structure above with NO N-sized
+ * H*direction vector.  The kernels that produce the weight-shaped HVP outputs apply the recurrence to the matching
+ * slices of the flat state vectors while the tile is on chip (r <- r - a*Hp, x <- x + a*p and the partial r'.r' for
+ * CG; v' <- v - a*Hv, p <- p + v' for Neumann).  For CG the step length a = rr / (cg_alpha * p.Hp) is known BEFORE
+ * those kernels run, from batch-sized factors of the R-chain:
+ *     p.Hp = sum_b Rz_b.Rd_L,b + 2 sum_{l>=1} <delta_l V_l, Rh_{l-1}> + hvp_shift * p.p .
+ * Replaces cg.py:38-56 / neumann.py:61-66 (the whole K loop) for this structure.
+ *   starts[2L]: element offsets of [W_0, b_0, W_1, b_1, ...] inside the flat vectors (bhg_layout_build's `starts`);
+ *   the direction handed to the HVP chain is the matching slice of p (CG) / v (Neumann).
+ *   fws: device scratch of bhg_mlp_fused_ws_bytes(m) bytes.
+ * bhg_mlp_cg_solve: call bhg_cg_init(vec, ..., x, r, p, ws, stream) first (x = 0, r = p = vec, r.r partials in ws);
+ *   on return x = -cg_alpha * x_K (cg.py:56 and the negation of cg.py:59/68 folded into the last iteration).
+ * bhg_mlp_neumann_solve: call bhg_neumann_init(vec, ..., v0, p, ...) first; v0 / v1 ping-pong as the direction (the
+ *   R-backward GEMMs of an HVP still read v while its epilogues write v'); on return p = -alpha * p_K.              */
+int bhg_mlp_supports_fused_solve(const bhg_mlp* m);
+size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m);
+int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
+                     const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
+                     void* fws, size_t fws_bytes, void* stream);
+int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K,
+                          float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

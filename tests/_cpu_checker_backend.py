@@ -75,6 +75,9 @@ class CpuCheckerBackend:
         for t, src in zip(tensors, self._slices(layout, flat)):
             self.orc.orc_scale_copy(t.data_ptr(), src.data_ptr(), t.numel(), scale)
 
+    def after_cg(self, layout):
+        pass
+
     def scale_flat(self, flat, scale):
         self.orc.orc_scale_copy(flat.data_ptr(), flat.data_ptr(), flat.numel(), scale)
 

@@ -435,14 +435,14 @@ def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cp
 RIDGE = {"reweight": 0.5, "deep": 0.5}
 
 
-def attach_mlp_structure(curr, family, impl=None):
+def attach_mlp_structure(curr, family, impl=None, fused=True):
     """Opt the inner problem into the analytic HVP (betty_amd.hypergradient.structured)."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
     def structure(prev):
         return WeightedCEMLP(
             curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)),
-            ridge=RIDGE[family], impl=impl,
+            ridge=RIDGE[family], impl=impl, fused=fused,
         )
 
     curr.hypergradient_structure = structure
