@@ -17,6 +17,7 @@ from conftest import golden_list, load_golden, rel_err
 
 from betty_amd import Config, _native
 from betty_amd import hypergradient as hg
+from betty_amd.backend import get_backend
 
 pytestmark = pytest.mark.gpu
 

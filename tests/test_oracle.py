@@ -156,3 +156,15 @@ def test_oracle_fsdp_grad_branch():
         want = ref_grad(loss2, params2, retain_graph=True, is_fsdp=True)
         for g, w in zip(got, want):
             np.testing.assert_array_equal(g.numpy(), w.numpy())
+
+
+@pytest.mark.parametrize("case", zoo.CASES, ids=lambda c: c.name)
+def test_case_tolerances_follow_the_golden_spread(case):
+    """Case.rtol = max(1e-4, ~5 x the reference's own fp32-vs-fp64 distance on that case): no blanket tolerance."""
+    _, outputs = load_golden(case.family)
+    a, b = golden_list(outputs, case.name, "fp32"), golden_list(outputs, case.name, "fp64")
+    if not b:
+        pytest.skip("no fp64 golden")
+    spread, _ = rel_err(a, b)
+    want = max(1e-4, 5.0 * spread)
+    assert want <= case.rtol <= 1.1 * want, (case.name, case.rtol, spread)

@@ -293,7 +293,10 @@ class Case:
     family: str  # logreg | reweight | imaml | deep
     algo: str  # cg | neumann | darts
     cfg: Dict  # Config kwargs
-    rtol: float = 1e-4  # parity tolerance of the HIP path against the fp32 reference golden
+    # parity tolerance of the HIP path against the fp32 reference golden: north_star's 1e-4, or — for the finite-difference
+    # algorithms (darts, sama), whose fp32 result is noise-limited — 5x the reference's OWN fp32-vs-fp64 spread on that case
+    # when that is larger (tests/test_oracle.py::test_case_tolerances_follow_the_golden_spread ties the numbers to the goldens)
+    rtol: float = 1e-4
 
 
 CASES: List[Case] = [
@@ -303,26 +306,26 @@ CASES: List[Case] = [
     Case("logreg_cg0", "logreg", "cg", dict(type="cg", cg_iterations=0, cg_alpha=1.0)),
     Case("logreg_neumann5", "logreg", "neumann", dict(type="neumann", neumann_iterations=5, neumann_alpha=0.5)),
     Case("logreg_neumann0", "logreg", "neumann", dict(type="neumann", neumann_iterations=0, neumann_alpha=0.5)),
-    Case("logreg_darts", "logreg", "darts", dict(type="darts", darts_alpha=0.01), rtol=2e-3),
+    Case("logreg_darts", "logreg", "darts", dict(type="darts", darts_alpha=0.01), rtol=1e-4),
     # cfg 2 shape (reduced): ReLU-MLP inner with MWN-weighted CE
     Case("reweight_neumann10", "reweight", "neumann", dict(type="neumann", neumann_iterations=10, neumann_alpha=0.1)),
     Case("reweight_cg20", "reweight", "cg", dict(type="cg", cg_iterations=20, cg_alpha=1.0)),
-    Case("reweight_darts", "reweight", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
+    Case("reweight_darts", "reweight", "darts", dict(type="darts", darts_alpha=0.1), rtol=4e-4),
     # cfg 3 shape (reduced): conv net inner, prox-regularised to the upper copy (M = N)
     Case("imaml_cg10", "imaml", "cg", dict(type="cg", cg_iterations=10, cg_alpha=1.0)),
     Case("imaml_neumann6", "imaml", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.3)),
-    Case("imaml_darts", "imaml", "darts", dict(type="darts", darts_alpha=0.05), rtol=2e-3),
+    Case("imaml_darts", "imaml", "darts", dict(type="darts", darts_alpha=0.05), rtol=1e-4),
     # SAMA: Adam-preconditioned finite difference; SGD = identity preconditioner
-    Case("reweight_sama_adam", "reweight", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
-    Case("logreg_sama_sgd", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01), rtol=2e-3),
+    Case("reweight_sama_adam", "reweight", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=1e-4),
+    Case("logreg_sama_sgd", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01), rtol=1e-4),
     # *_multitask=True: the perturbed inner weights are NOT restored (darts.py:61-63, sama.py:51-53)
-    Case("reweight_darts_multitask", "reweight", "darts", dict(type="darts", darts_alpha=0.1, darts_multitask=True), rtol=2e-3),
-    Case("logreg_sama_multitask", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01, sama_multitask=True), rtol=2e-3),
+    Case("reweight_darts_multitask", "reweight", "darts", dict(type="darts", darts_alpha=0.1, darts_multitask=True), rtol=4e-4),
+    Case("logreg_sama_multitask", "logreg", "sama", dict(type="sama", sama_adam_alpha=0.01, sama_multitask=True), rtol=1e-4),
     # many small tensors (T = 48 > 32): exercises the device pointer-table path (cfg 5 shape)
     Case("deep_neumann6", "deep", "neumann", dict(type="neumann", neumann_iterations=6, neumann_alpha=0.2)),
     Case("deep_cg6", "deep", "cg", dict(type="cg", cg_iterations=6, cg_alpha=1.0)),
-    Case("deep_darts", "deep", "darts", dict(type="darts", darts_alpha=0.1), rtol=2e-3),
-    Case("deep_sama_adam", "deep", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2e-3),
+    Case("deep_darts", "deep", "darts", dict(type="darts", darts_alpha=0.1), rtol=1.5e-3),
+    Case("deep_sama_adam", "deep", "sama", dict(type="sama", sama_adam_alpha=1.0), rtol=2.6e-4),
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 
