@@ -1404,7 +1404,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       fuse_head = true;
     } else if (l + 1 < L) {
       launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
-      if (cg) BHG_HIP_CHECK(hipEventRecord(ss.ev_rh[l], st));
+      // (an event record costs the stream a ~4 us bubble, a cross-stream wait ~8 us — measured, rocprofv3 timeline —
+      //  so only the one record the G sums need is made)
+      if (cg && l == L - 3) BHG_HIP_CHECK(hipEventRecord(ss.ev_rh[l], st));
     } else {
       hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
                          a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
@@ -1442,8 +1444,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     aa.partPP = cm.partPP; aa.nPP = cm.nPP;
     aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
     aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
-    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, side, aa);
-    BHG_HIP_CHECK(hipEventRecord(ss.ev_alpha, side));
+    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, side, aa);   // every fused epilogue is queued behind it on `side`
   }
 
   // ---- R-backward (main stream) overlapped with the weight-shaped outputs (side stream) ----------------
@@ -1508,7 +1509,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     } else {
       // (fused CG: ev_head / ev_rd[l] were waited for before k_cg_alpha or are recorded below; the side stream's
       //  own order puts every fused epilogue behind k_cg_alpha)
-      if (!(cg && head && l == L - 1)) {   // that case: Rd_{L-1}, Rd_{L-2} come from the head kernel = ev_head, already waited
+      if (!(cg && head && l >= L - 2)) {   // those: Rd_{L-1}, Rd_{L-2} come from the head kernel = ev_head, already waited
         BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[l], st));
         BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[l], 0));
       }
@@ -1556,16 +1557,20 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
       BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
       bs = side;
-    } else if (cg) {
-      BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_alpha, 0));
+    } else if (cg) {   // single-layer net: everything on the side stream (behind k_cg_alpha)
+      BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
+      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
+      bs = side;
     }
+    // fused CG: H(W_0) goes to the side stream as well — it is ordered behind k_cg_alpha there, so the caller's
+    // stream never has to wait for the step length (a cross-stream wait costs ~8 us even when the event is long done)
+    if (cg) launch_outer(0, side);
     if (cm.mode == FUSE_CG) hipLaunchKernelGGL(k_bias_hvp<FUSE_CG>, dim3(blk), dim3(256), 0, bs, ba, fz);
     else if (cm.mode == FUSE_NEUMANN) hipLaunchKernelGGL(k_bias_hvp<FUSE_NEUMANN>, dim3(blk), dim3(256), 0, bs, ba, fz);
     else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(blk), dim3(256), 0, bs, ba, fz);
   }
-  if (cg) BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_alpha, 0));   // the step length (long done: it was due at the head)
-  launch_outer(0, st);  // needs Rd_0, the end of the chain
-  if (L > 1 && !no_side) {
+  if (!cg) launch_outer(0, st);  // needs Rd_0, the end of the chain
+  if ((L > 1 && !no_side) || cg) {
     BHG_HIP_CHECK(hipEventRecord(ss.ev_join, side));
     BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_join, 0));
   }

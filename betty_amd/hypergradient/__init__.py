@@ -11,11 +11,20 @@ from .neumann import neumann
 from .sama import sama
 from .utils import grad, replace_none_with_zero
 
+def reinforce(vector, curr, prev, sync):
+    """The reference registers ``reinforce`` (__init__.py:18) but its function is a stub with the wrong arity
+    (reinforce.py:6 takes no ``sync``) and returns None: any run that selects it fails inside get_grads.  The key is
+    kept so that ``Config(type="reinforce")`` is accepted where the reference accepts it, and fails with a message."""
+    raise NotImplementedError("Config.type='reinforce' is an unimplemented stub in the reference "
+                              "(betty/hypergradient/reinforce.py:6-7); use darts | sama | neumann | cg")
+
+
 jvp_fn_mapping = {
     "darts": darts,
     "sama": sama,
     "neumann": neumann,
     "cg": cg,
+    "reinforce": reinforce,
 }
 
 

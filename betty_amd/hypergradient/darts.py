@@ -39,7 +39,8 @@ def darts(vector, curr, prev, sync):
     # w <- w + eps*v   (darts.py:37-38)
     be.axpy_multi(layout, weights, vector, eps32, 1.0)
     loss_p = curr.training_step_exec(curr.cur_batch)
-    grad_p = replace_none_with_zero(grad(loss_p, upper, allow_unused=True), upper)
+    # is_fsdp: the gradient of a flat shard only materialises through backward into .grad (darts.py:40-42, utils.py:9-17)
+    grad_p = replace_none_with_zero(grad(loss_p, upper, allow_unused=True, is_fsdp=is_fsdp), upper)
     if sync:
         # darts.py:44-46: -g+/(2 eps) goes straight into .grad
         prev.set_grads(upper, [-(g / two_eps) for g in grad_p])
@@ -51,7 +52,7 @@ def darts(vector, curr, prev, sync):
         torch.autograd.backward(loss_n / two_eps, inputs=upper)  # darts.py:52-53 (DDP hooks fire)
         grad_n = None
     else:
-        grad_n = replace_none_with_zero(grad(loss_n, upper, allow_unused=True), upper)
+        grad_n = replace_none_with_zero(grad(loss_n, upper, allow_unused=True, is_fsdp=is_fsdp), upper)  # darts.py:55-58
 
     # restore w   (darts.py:61-63)
     if not config.darts_multitask:

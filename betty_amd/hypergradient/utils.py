@@ -1,5 +1,5 @@
 """Small helpers of the hypergradient path (reference: betty/hypergradient/utils.py:5-21,
-betty/utils.py:125-137)."""
+betty/utils.py:132-137)."""
 from __future__ import annotations
 
 import torch
@@ -30,8 +30,3 @@ def grad(loss, parameters, retain_graph=False, allow_unused=False, is_fsdp=False
 def replace_none_with_zero(tensor_list, reference):
     """betty/utils.py:132-137."""
     return tuple(t if t is not None else torch.zeros_like(r) for t, r in zip(tensor_list, reference))
-
-
-def neg_with_none(a):
-    """betty/utils.py:125-129."""
-    return None if a is None else -a

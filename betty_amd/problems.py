@@ -54,6 +54,8 @@ class Problem:
         self._roll_back = False
         self._world_size = 1
         self._snapshot = None
+        # fp16 dynamic loss scaler (problem.py:165-174): created on first use so that a CPU-only import works
+        self.scaler = None
         # forward module seen by other problems (a DDP wrapper under strategy "distributed")
         self.fwd = module
 
@@ -154,9 +156,20 @@ class Problem:
     def gradient_accumulation_boundary(self):
         return bool(self._count % self.gas == 0)
 
+    def _ensure_scaler(self):
+        """problem.py:165-174: ``precision="fp16"`` trains under a dynamic loss scaler built from
+        ``Config.initial_dynamic_scale`` / ``Config.scale_factor``."""
+        if self._config.precision == "fp16" and self.scaler is None:
+            assert torch.cuda.is_available(), "fp16 training needs a GPU"
+            self.scaler = torch.amp.GradScaler("cuda", init_scale=self._config.initial_dynamic_scale,
+                                               growth_factor=self._config.scale_factor)
+        return self.scaler
+
     def get_loss(self, batch):
         out = self.training_step_exec(batch)
         loss = out["loss"] if isinstance(out, dict) else out
+        if self._ensure_scaler() is not None:   # problem.py:508-509: the SCALED loss is what gets differentiated
+            loss = self.scaler.scale(loss)
         return loss / self.gas
 
     def one_step_descent(self, batch=None):
@@ -178,6 +191,10 @@ class Problem:
             self.optimizer_step()
             if hasattr(self, "param_callback"):
                 self.param_callback()
+            # problem.py:363-364: replicas whose weights are perturbed in place per rank (darts / sama) are
+            # re-synchronised every 20 optimizer steps under the non-default strategies
+            if self._strategy != "default" and self._count % (self.gas * 20) == 0:
+                self.synchronize_params(self.trainable_parameters())
             self.zero_grad()
         return loss
 
@@ -392,12 +409,21 @@ class ImplicitProblem(Problem):
         return list(self.module.parameters())
 
     def optimizer_step(self):
+        """implicit_problem.py:40-65: [unscale] -> clip -> step -> record SAMA's last gradient -> [scaler update]."""
         clip = self._config.gradient_clipping
+        scaler = self._ensure_scaler()
+        if scaler is not None:
+            scaler.unscale_(self.optimizer)
         if clip > 0.0:
             torch.nn.utils.clip_grad_norm_(self.trainable_parameters(), max_norm=clip)
-        self.optimizer.step()
+        if scaler is not None:
+            scaler.step(self.optimizer)   # skipped by the scaler when a gradient overflowed
+        else:
+            self.optimizer.step()
         if self._config.type == "sama":  # implicit_problem.py:60-65: SAMA's preconditioner needs the last gradient
             for param in self.trainable_parameters():
                 state = self.optimizer.state[param]
                 if param.grad is not None and len(state) != 0:
                     state["last_grad"] = param.grad.detach().clone()
+        if scaler is not None:
+            scaler.update()

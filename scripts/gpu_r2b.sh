@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-2 run B: fused-solver tests, fused vs un-fused bench lines (+ side-stream priority A/B), timelines.
+set -u
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=10 -k "fused or structured or mlp or cfg2 or alternate" 2>&1 | tail -25 | tee gpurun_out/pytest_gpu_b.log
+run() { tag=$1; shift
+  timeout 300 python bench.py --steps 100 --cpu-steps 0 "$@" 2> gpurun_out/bench_$tag.err > gpurun_out/bench_$tag.json
+  python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/bench_$tag.json").read().strip().splitlines()[-1])
+    r=d["roofline"] or {}; h=d["hvp_roofline"] or {}
+    print("== %-16s value %.1f steps/s  ms/step %.3f  iter_us %.1f  roof_frac %.3f  hvp_us %.1f hvp_frac %.3f outside_ms %.3f" % ("$tag", d["value"], d["ms_per_step"], d.get("per_iteration_us") or 0, r.get("frac") or 0, h.get("avg_call_us") or 0, h.get("frac") or 0, d.get("outside_k_loop_ms") or 0))
+except Exception as e:
+    print("== $tag bench failed:", e); print(open("gpurun_out/bench_$tag.err").read()[-1500:])
+PY
+}
+run cg_fused --algo cg
+run cg_nofuse --algo cg --no-fuse
+BHG_SIDE_PRIO_DEFAULT=1 run cg_fused_flatprio --algo cg
+run neumann_fused --algo neumann --cg-iters 10
+BHG_SIDE_PRIO_DEFAULT=1 run neumann_fused_flatprio --algo neumann --cg-iters 10
+run cg_fused_notiming --algo cg --no-kernel-timing
+for arm in fused; do
+  cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$arm -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 2 cg $arm > /tmp/tr_$arm.log 2>&1; echo "trace $arm rc=$?"
+  cd $GRAFT_REPO_ROOT
+  f=$(ls /tmp/tr_$arm/*kernel_trace.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_cg_pdir | tee gpurun_out/timeline_$arm.txt; else tail -5 /tmp/tr_$arm.log; fi
+done

@@ -236,8 +236,44 @@ local = hg.cg(vector, curr, prev, False)
 h = exchange_async(local)                               # one flat asynchronous all-reduce on the comm stream
 avg = h.wait()
 rel2, _ = rel_err([t.cpu().numpy() for t in avg], [t.cpu().numpy() for t in local])
+# --- Problem.synchronize_params (problem.py:599-609) as ONE flat collective over RCCL; the early return at world
+# size 1 is bypassed by telling the problem it has 2 replicas: broadcast = identity, all-reduce(mean) = w / 2
+from betty_amd.problems import ImplicitProblem
+mod = zoo.MLP([33, 17, 5]).to("cuda:0")
+prob = ImplicitProblem("p", module=mod)
+prob._world_size = 2
+before = [p.detach().clone() for p in mod.parameters()]
+prob.synchronize_params(prob.trainable_parameters())
+same = all(torch.equal(a, b) for a, b in zip(before, mod.parameters()))
+prob.synchronize_params(prob.trainable_parameters(), all_reduce=True)
+half = all(torch.equal(a / 2, b) for a, b in zip(before, mod.parameters()))
+# --- a collective in flight makes BHG_CG_AUTO take the streaming CG kernels (the resident kernel's grid barrier needs
+# every CU; RCCL's channel kernels hold some): same result as with an idle device, no barrier time-out
+from betty_amd.backend import get_backend
+from betty_amd import _native
+be = get_backend()
+big = [torch.randn(30_000_000, device="cuda:0")]
+ref = [t.cpu().numpy() for t in hg.cg(vector, curr, prev, False)]
+h2 = exchange_async(big)
+assert be.collectives_in_flight == 1
+busy = [t.cpu().numpy() for t in hg.cg(vector, curr, prev, False)]
+lay = be.layout(vector)
+picked = lay._cg_variant
+h2.wait()
+assert be.collectives_in_flight == 0
+be.check_health()
+rel3, _ = rel_err(busy, ref)
+# the resident kernel forced WHILE a collective runs must still terminate with the right answer or poison it — never hang
+h3 = exchange_async(big)
+be.cg_variant = _native.BHG_CG_RESIDENT
+forced = [t.cpu().numpy() for t in hg.cg(vector, curr, prev, False)]
+be.cg_variant = _native.BHG_CG_AUTO
+h3.wait()
+import numpy as np
+forced_ok = all(np.isfinite(t).all() for t in forced)
+rel4 = rel_err(forced, ref)[0] if forced_ok else -1.0
 torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group()
-print("RCCL_OK", rel, rel2)
+print("RCCL_OK", rel, rel2, int(same), int(half), picked, rel3, rel4)
 """
 
 
@@ -256,3 +292,76 @@ def test_rccl_backend_world_size_1():
     line = [l for l in out.stdout.splitlines() if l.startswith("RCCL_OK")][-1].split()
     assert float(line[1]) <= 1e-4, line       # vs the reference's sync=True golden
     assert float(line[2]) <= 1e-7, line       # mean over one rank = the local result
+    assert line[3] == "1" and line[4] == "1", line   # synchronize_params: broadcast keeps, all-reduce(mean over "2") halves
+    assert int(line[5]) == 1, line            # BHG_CG_STREAM picked while the exchange was in flight
+    assert float(line[6]) <= 1e-5, line       # ... with the idle-device result
+    assert float(line[7]) <= 1e-5, line       # forced resident kernel beside a collective: right answer (or -1 = poisoned)
+
+
+@pytest.mark.gpu
+def test_roll_back_snapshot_and_flow_on_gpu():
+    """SURVEY §8 f.4 on the MI355X: cache_states / recover_states through ONE flat HBM snapshot written / restored by
+    the multi-tensor kernels (bhg_flatten / bhg_scatter), Adam state included, and the roll-back step flow
+    (problem.py:379-381,417-436; implicit_problem.py:67-78)."""
+    dev = torch.device("cuda:0")
+    engine, outer, inner = _scenario(Config(type="darts", unroll_steps=5), dev)
+    inner.optimizer = torch.optim.Adam(inner.module.parameters(), lr=0.05)
+    w0 = inner.module.w.data.clone()
+    inner.cache_states()
+    inner.training_step(inner.get_batch()).backward()
+    inner.optimizer.step()
+    assert not torch.equal(inner.module.w.data, w0) and len(inner.optimizer.state[inner.module.w]) > 0
+    inner.recover_states()
+    assert torch.equal(inner.module.w.data, w0)
+    assert len(inner.optimizer.state[inner.module.w]) == 0
+    inner.zero_grad()
+    inner.training_step(inner.get_batch()).backward()
+    inner.optimizer.step()
+    st = inner.optimizer.state[inner.module.w]
+    m0, v0, w1 = st["exp_avg"].clone(), st["exp_avg_sq"].clone(), inner.module.w.data.clone()
+    inner.cache_states()
+    for _ in range(3):
+        inner.zero_grad()
+        inner.training_step(inner.get_batch()).backward()
+        inner.optimizer.step()
+    assert not torch.equal(st["exp_avg"], m0)
+    inner.recover_states()
+    st = inner.optimizer.state[inner.module.w]
+    assert torch.equal(st["exp_avg"], m0) and torch.equal(st["exp_avg_sq"], v0) and torch.equal(inner.module.w.data, w1)
+    assert st["exp_avg"].is_cuda
+
+    # flow with plain SGD: w_end = w_start - lr * grad(w_start)
+    engine, outer, inner = _scenario(Config(type="darts", unroll_steps=5), dev)
+    engine.config.roll_back = True
+    engine._parse_dependency()
+    assert inner._roll_back and not outer._roll_back
+    w_start = torch.zeros(20, device=dev)
+    x, y = (t.to(dev) for t in inner.train_data_loader[0])
+    lam = outer.module.w.data.clone()
+    g = x.t() @ (torch.sigmoid(x @ w_start) - y) / x.shape[0] + lam * w_start
+    engine.config.train_iters = 5
+    engine.run()
+    assert inner.count == 5 and outer.count == 1
+    torch.testing.assert_close(inner.module.w.data, w_start - 0.1 * g, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_fp16_precision_uses_the_dynamic_loss_scaler_on_gpu():
+    """Config(precision="fp16"): autocast + GradScaler built from initial_dynamic_scale / scale_factor
+    (problem.py:165-174,508-509; implicit_problem.py:45-57): the loss handed to backward is scaled, the optimizer
+    step un-scales, and the scale grows by scale_factor after the growth interval."""
+    cfg = Config(type="darts", unroll_steps=10, precision="fp16", initial_dynamic_scale=1024.0, scale_factor=4.0)
+    engine, outer, inner = _scenario(cfg, torch.device("cuda:0"))
+    engine.config.train_iters = 40
+    batch = inner.get_batch()
+    raw = inner.training_step_exec(batch)
+    scaled = inner.get_loss(batch)
+    assert inner.scaler is not None and outer.scaler is None   # only the fp16 problem gets one
+    assert float(inner.scaler.get_scale()) == 1024.0
+    torch.testing.assert_close(scaled.float(), raw.float() * 1024.0, rtol=1e-3, atol=0.0)
+    inner.scaler.set_growth_interval(8)
+    engine.run()
+    assert inner.count == 40
+    assert float(inner.scaler.get_scale()) >= 4096.0            # grew by scale_factor = 4 at least once
+    w = inner.module.w.detach()
+    assert torch.isfinite(w).all() and w.abs().max() > 1e-3     # the un-scaled updates moved the weights sanely
