@@ -51,6 +51,8 @@ struct GemmArgs {
   const float* addend;  // optional: out = acc + addend_scale * addend[m][n] (same ld as out)
   float addend_scale;
   int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
+  int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
+                        // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
 };
 
 // LDS tile loaders -----------------------------------------------------------------------------------
@@ -160,7 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 
   const int n0 = blockIdx.x * TN;
   const int m0 = blockIdx.y * kTM;
-  const int split = blockIdx.z;
+  int split = blockIdx.z, nsplit = a.splits, npairs = a.pairs, first = 0;
+  if (a.pair_split > 0) {   // this workgroup's K range belongs to ONE of the two operand pairs (workgroup-uniform)
+    first = split >= a.pair_split ? 1 : 0;
+    nsplit = first ? a.splits - a.pair_split : a.pair_split;
+    split = first ? split - a.pair_split : split;
+    npairs = 1;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = TN == 64 ? (wave >> 1) * 64 : wave * 32;  // wave's row offset inside the tile
   const int wn = TN == 64 ? (wave & 1) * 32 : 0;           // wave's col offset
@@ -168,11 +176,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 
   // K range of this split (multiples of kTK except possibly the end)
   const int ksteps_total = (a.K + kTK - 1) / kTK;
-  const int per = (ksteps_total + a.splits - 1) / a.splits;
+  const int per = (ksteps_total + nsplit - 1) / nsplit;
   const int kbeg = split * per * kTK;
   const int kend = min(a.K, (split + 1) * per * kTK);
   const int nsteps_pair = kbeg < kend ? (kend - kbeg + kTK - 1) / kTK : 0;
-  const int nsteps = nsteps_pair * a.pairs;
+  const int nsteps = nsteps_pair * npairs;
 
   // Two K-interleaved accumulators per 32x32 output tile: consecutive MFMAs never depend on each other, so
   // the instructions hipcc schedules between them (LDS reads, waits) do not stretch a dependent chain.
@@ -189,8 +197,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
   // in the body hipcc shuttles all 32 accumulator registers AGPR -> VGPR -> AGPR around every step and
   // drains the load queue at each join.
   float4 ra0[kTM / 32], rb0[TN / 32], ra1[kTM / 32], rb1[TN / 32];
-  const GemmPair pr0 = a.pr[0];
-  const GemmPair pr1 = a.pr[a.pairs > 1 ? 1 : 0];   // operand bases live in SGPRs, not re-fetched per step
+  const GemmPair pr0 = a.pr[first];
+  const GemmPair pr1 = a.pr[npairs > 1 ? 1 : first];   // operand bases live in SGPRs, not re-fetched per step
   auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32]) {
     step = min(step, nsteps - 1);
     const bool second = step >= nsteps_pair;          // workgroup-uniform
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 #undef SCHED_FENCE
 
   // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)split * a.out_rows * a.ldo : 0);
+  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)blockIdx.z * a.out_rows * a.ldo : 0);
   const int col = n0 + wn + li;
   if (col < a.N) {
 #pragma unroll
@@ -355,7 +363,7 @@ constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging
 // FAST: all tiles interior and 16-B aligned (checked by the launcher): no ragged path, loads unconditional with
 // clamped row index and a 0/1 multiplier (same reasons as k_gemm's FAST instance).
 template <bool FAST, int MODE>
-__global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
+__device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz, const int bx, const int by, const int gx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ double red_rr[kWaves];
   const int K = a.K;
@@ -363,8 +371,8 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
   const int Kh = (((K + nsp - 1) / nsp) + 1) & ~1;    // rows per stage, even, <= kOH
   float* sA = smem;                       // [Kh][128]
   float* sB = smem + Kh * kTM;            // [Kh][64]
-  const int n0 = blockIdx.x * kTN;
-  const int m0 = blockIdx.y * kTM;
+  const int n0 = bx * kTN;
+  const int m0 = by * kTM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
   const int li = lane & 31, lk = lane >> 5;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
     }
     if (MODE == FUSE_CG) {
       const double s = block_sum(racc, red_rr);
-      if (t == 0) fz.part[fz.part_base + (int)(blockIdx.y * gridDim.x + blockIdx.x)] = s;
+      if (t == 0) fz.part[fz.part_base + by * gx + bx] = s;
     }
     return;
   }
@@ -566,6 +574,11 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
       }
     }
   }
+}
+
+template <bool FAST, int MODE>
+__global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
+  outer_body<FAST, MODE>(a, fz, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ---- split-K epilogues ---------------------------------------------------------------------------------
@@ -636,39 +649,53 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
   }
 }
 
-// Fused solver, G pass: gsum[m][n] = sum_s part[s][m][n]  (= (delta_l V_l)[m][n], chain-independent) and the partial
-// of T2_l = 2 <delta_l V_l, Rh_{l-1}> (the second-order part of p.Hp, see k_cg_alpha) over this block's elements.
-// Up to 2 layers per launch; one float4 per thread; fixed summation order.
-struct GsumArgs {
-  const float* part[2]; int splits[2]; int slab[2];   // slab = rows * N floats
-  const float* rh[2];                                  // Rh_{l-1} [rows][N]
-  float* gsum[2];
-  int blk0[3];                                         // first block of each problem
-  int n;
-};
-__global__ __launch_bounds__(256) void k_gsum_dot(GsumArgs g, double* __restrict__ partT2) {
+// R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
+// G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
+//   out[m][n] = mask[m][n] * (G + Rd_l W_l)[m][n]            (rows >= B written as zero)
+// every block emits its partial of T2_l = 2 <G, Rh_{l-1}>, the layer-bilinear part of p.Hp (see k_cg_alpha).
+// One float4 per thread and trip when VEC == 4; slabs are summed in fixed order s = 0, 1, ... => deterministic.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict__ part, int s0, int splits, int slab,
+                                                        const float* __restrict__ mask, const float* __restrict__ rh,
+                                                        float* __restrict__ out, int rows, int N, int B,
+                                                        double* __restrict__ partT2) {
   __shared__ double red[kWaves];
-  const int q = (g.n > 1 && (int)blockIdx.x >= g.blk0[1]) ? 1 : 0;
-  const int64_t total4 = g.slab[q] / 4;
-  const int64_t i = (int64_t)((int)blockIdx.x - g.blk0[q]) * 256 + threadIdx.x;
-  const int64_t ic = i < total4 ? i : total4 - 1;   // clamped: all loads in flight, contribution masked below
-  constexpr int NB = 8;
-  const float* p0 = g.part[q] + ic * 4;
-  const float4 rh = ld16(g.rh[q] + ic * 4);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int splits = g.splits[q];
-  for (int s0 = 0; s0 < splits; s0 += NB) {
-    float4 tt[NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < splits ? s0 + u : splits - 1) * g.slab[q]);
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-      if (s0 + u < splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
-  }
+  const int64_t total = (int64_t)rows * N / VEC;
+  const int nv = N / VEC;
   double acc = 0.0;
-  if (i < total4) {
-    *reinterpret_cast<float4*>(g.gsum[q] + i * 4) = v;
-    acc = (double)v.x * rh.x + (double)v.y * rh.y + (double)v.z * rh.z + (double)v.w * rh.w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / nv);
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    if (m < B) {
+      if (VEC == 4) {
+        constexpr int NB = 8;
+        const float* p0 = part + i * VEC;
+        const float4 mv = *reinterpret_cast<const float4*>(mask + i * VEC);
+        const float4 rv = *reinterpret_cast<const float4*>(rh + i * VEC);
+        for (int half = 0; half < 2; ++half) {
+          const int sb = half ? s0 : 0, se = half ? splits : s0;
+          for (int sA = sb; sA < se; sA += NB) {
+            float4 t[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) t[u] = *reinterpret_cast<const float4*>(p0 + (int64_t)(sA + u < se ? sA + u : se - 1) * slab);
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+              if (sA + u < se) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+          }
+          if (!half) acc += (double)v[0] * rv.x + (double)v[1] * rv.y + (double)v[2] * rv.z + (double)v[3] * rv.w;
+        }
+        v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
+      } else {
+        for (int s = 0; s < s0; ++s) v[0] += part[(int64_t)s * slab + i];
+        acc += (double)v[0] * rh[i];
+        for (int s = s0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
+        v[0] *= mask[i];
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
+    else out[i] = v[0];
   }
   const double sblk = block_sum(acc, red);
   if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
@@ -726,13 +753,13 @@ struct BiasArgs {
   int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
 };
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
+__device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz, const int bx) {
   __shared__ float red[4][64];
   __shared__ double red_rr[kWaves];
   int l = 0;
-  while (l + 1 < a.L && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
+  while (l + 1 < a.L && bx >= a.blk0[l + 1]) ++l;
   const int N = a.n[l];
-  const int col = ((int)blockIdx.x - a.blk0[l]) * 64 + (threadIdx.x & 63);
+  const int col = (bx - a.blk0[l]) * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   const float* __restrict__ rd = a.rd[l];
   const int colc = col < N ? col : N - 1;   // clamped, not guarded: all loads of a batch are in flight together
@@ -768,8 +795,12 @@ __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
   }
   if (MODE == FUSE_CG) {
     const double sblk = block_sum(racc, red_rr);
-    if (threadIdx.x == 0) fz.part[fz.part_base + (int)blockIdx.x] = sblk;
+    if (threadIdx.x == 0) fz.part[fz.part_base + bx] = sblk;
   }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
+  bias_body<MODE>(a, fz, blockIdx.x);
 }
 
 // ---- narrow output layer (C = dims[L] <= 32 classes): dedicated latency-optimised kernels ----------------
@@ -1018,16 +1049,22 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
 
 // G[c][n] = sum_b (Rd[b][c] h[b][n] + delta[b][c] Rh[b][n]) + rho2 V[c][n];  block = 64 n x 4 batch groups,
 // fixed-order combine through LDS (deterministic).
+struct HeadOuterArgs {
+  const float* rd; const float* h; const float* delta; const float* Rh; const float* V;
+  float rho2; float* out; int N, C, B;
+};
 template <bool HAS_RH, int MODE>
-__global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd, const float* __restrict__ h,
-                                                    const float* __restrict__ delta, const float* __restrict__ Rh,
-                                                    const float* __restrict__ V, float rho2, float* __restrict__ out,
-                                                    int N, int C, int B, FuseArgs fz) {
+__device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const FuseArgs& fz, const int bx, const int by,
+                                                const int gx) {
   // fused modes: fz.a / fz.b / fz.d already point at the head weight's slice of the flat state vectors
   __shared__ float red[4][64];
   __shared__ double red_rr[kWaves];
-  const int c = blockIdx.y;
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float* __restrict__ rd = ha.rd; const float* __restrict__ h = ha.h; const float* __restrict__ delta = ha.delta;
+  const float* __restrict__ Rh = ha.Rh; const float* __restrict__ V = ha.V; float* __restrict__ out = ha.out;
+  const float rho2 = ha.rho2;
+  const int N = ha.N, C = ha.C, B = ha.B;
+  const int c = by;
+  const int n = bx * 64 + (threadIdx.x & 63);
   const int nc = n < N ? n : N - 1;   // clamped, not guarded (see k_head_forward)
   const int g = threadIdx.x >> 6;
   float acc = 0.f;
@@ -1070,7 +1107,45 @@ __global__ __launch_bounds__(256) void k_head_outer(const float* __restrict__ rd
   }
   if (MODE == FUSE_CG) {
     const double sblk = block_sum(racc, red_rr);
-    if (threadIdx.x == 0) fz.part[fz.part_base + (int)(blockIdx.y * gridDim.x + blockIdx.x)] = sblk;
+    if (threadIdx.x == 0) fz.part[fz.part_base + by * gx + bx] = sblk;
+  }
+}
+template <bool HAS_RH, int MODE>
+__global__ __launch_bounds__(256) void k_head_outer(HeadOuterArgs ha, FuseArgs fz) {
+  head_outer_body<HAS_RH, MODE>(ha, fz, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// ---- all weight-shaped outputs of one HVP in ONE launch (fused CG: they all need the step length, which is known
+// only at the end of the R-chain; one grid fills the chip without any stream/event choreography) -----------------------
+// Blocks [blk0[i], blk0[i+1]) are the 128 x 64 tiles of MFMA layer i (largest layers first), then the narrow head's
+// blocks, then the bias blocks.  All MFMA layers must be all-interior (FAST); the launcher falls back to one launch
+// per layer otherwise.
+constexpr int kOuterAllMax = 8;
+struct OuterAllArgs {
+  GemmArgs g[kOuterAllMax];
+  FuseArgs f[kOuterAllMax];
+  int gx[kOuterAllMax];
+  int blk0[kOuterAllMax + 1];
+  int n;
+  HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
+  FuseArgs bf;
+};
+static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
+template <int MODE>
+__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
+  const int b = blockIdx.x;
+  const int nw = oa.blk0[oa.n];
+  if (b < nw) {
+    int i = 0;
+    while (i + 1 < oa.n && b >= oa.blk0[i + 1]) ++i;
+    const int t = b - oa.blk0[i];
+    outer_body<true, MODE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
+  } else if (b < nw + oa.head_blocks) {
+    const int t = b - nw;
+    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+  } else {
+    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks);
   }
 }
 
@@ -1214,8 +1289,8 @@ __global__ __launch_bounds__(kThreads) void k_cg_pdir(const bhg_chunk* __restric
 // ---- per-device side stream + events -------------------------------------------------------------------------------
 struct SideState {
   hipStream_t side;
-  hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS], ev_rh[BHG_MLP_MAX_LAYERS];
-  hipEvent_t ev_join, ev_head, ev_alpha, ev_dir, ev_gsum;
+  hipEvent_t ev_rd[BHG_MLP_MAX_LAYERS];
+  hipEvent_t ev_join;
 };
 int side_state(SideState** out) {
   static SideState per_device[64];
@@ -1224,22 +1299,10 @@ int side_state(SideState** out) {
   BHG_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
   SideState& ss = per_device[dev];
   if (!ss.side) {
-    // the side stream carries work that is OFF the critical path (weight-shaped outputs, the G pass): lowest priority,
-    // so the dependent chain on the caller's stream is dispatched first whenever both have workgroups waiting
-    int least = 0, greatest = 0;
-    static const bool flat_prio = getenv("BHG_SIDE_PRIO_DEFAULT") != nullptr;   // A/B switch (debug)
-    if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
-    BHG_HIP_CHECK(hipStreamCreateWithPriority(&ss.side, hipStreamNonBlocking, least));
+    BHG_HIP_CHECK(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
     const unsigned fl = hipEventDisableTiming | hipEventDisableSystemFence;
-    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) {
-      BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_rd[i], fl));
-      BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_rh[i], fl));
-    }
+    for (int i = 0; i < BHG_MLP_MAX_LAYERS; ++i) BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_rd[i], fl));
     BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_join, fl));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_head, fl));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_alpha, fl));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_dir, fl));
-    BHG_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_gsum, fl));
     // k_outer's dynamic LDS is at most 64 K rows x (128 + 64) floats = 48 KiB; the limit is raised explicitly so a
     // larger kOK only needs this number changed (static LDS of the fused instances counts against the 160 KiB too)
 #define BHG_OUTER_LDS(F, M) \
@@ -1248,6 +1311,8 @@ int side_state(SideState** out) {
     BHG_OUTER_LDS(true, FUSE_CG); BHG_OUTER_LDS(false, FUSE_CG);
     BHG_OUTER_LDS(true, FUSE_NEUMANN); BHG_OUTER_LDS(false, FUSE_NEUMANN);
 #undef BHG_OUTER_LDS
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   }
   *out = &ss;
   return BHG_OK;
@@ -1269,13 +1334,15 @@ int bias_blocks(const bhg_mlp* m) {
   for (int l = 0; l < m->L; ++l) blk += (m->dims[l + 1] + 63) / 64;
   return blk;
 }
+int reduce_blocks(int slab, int N) {
+  int blocks = (N & 3) == 0 ? (slab / 4 + 255) / 256 : (slab + 255) / 256;
+  return blocks > 2048 ? 2048 : blocks;
+}
 
-// Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve / _neumann_solve.
+// Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
-  float* gsum[BHG_MLP_MAX_LAYERS];       // [Bp][dims[l]], l = 1 .. L-2
-  float* gpartial[BHG_MLP_MAX_LAYERS];   // split-K slabs of the G pass
-  int gsplits[BHG_MLP_MAX_LAYERS];
+  int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
   size_t bytes;
 };
@@ -1293,16 +1360,9 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->partRR[0] = static_cast<double*>(take(sizeof(double) * nrr));
   w->partRR[1] = static_cast<double*>(take(sizeof(double) * nrr));
   int nt2 = 0;
-  for (int l = 1; l + 1 < m->L; ++l) nt2 += (m->Bp * m->dims[l] / 4 + 255) / 256;
+  for (int l = 1; l + 1 < m->L; ++l) { w->t2_off[l] = nt2; nt2 += reduce_blocks(m->Bp * m->dims[l], m->dims[l]); }
   w->nT2 = nt2;
   w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
-  for (int l = 1; l + 1 < m->L; ++l) {
-    const int N = m->dims[l], K = m->dims[l + 1];
-    const int tn = skinny_tile_n();
-    w->gsplits[l] = pick_splits((N + tn - 1) / tn, K, 1);
-    w->gsum[l] = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * N));
-    w->gpartial[l] = static_cast<float*>(take(sizeof(float) * (size_t)w->gsplits[l] * m->Bp * N));
-  }
   w->bytes = off;
 }
 
@@ -1325,14 +1385,22 @@ struct ChainMode {
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
 // by the CG / Neumann recurrence while still on chip (fused modes).  On return everything is ordered on `st`.
+//   FUSE_NONE / FUSE_NEUMANN: the outputs of layer l only need Rd_l and Rh_{l-1}, so they run on a library-owned side
+//     stream beside the R-backward chain (event fork / join).
+//   FUSE_CG: the fused epilogues need the step length, which needs the whole R-chain (T2 comes out of the R-backward
+//     reduces) — so there is nothing to overlap: ONE stream, no events (an event record costs the stream a ~4 us
+//     bubble, a cross-stream wait ~8 us: measured, rocprofv3 timelines in profiles/), and ONE launch for all
+//     weight-shaped outputs.
 int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hipStream_t st) {
   const int L = m->L, Bp = m->Bp, B = m->B;
   const float rho2 = cm.mode == FUSE_NONE ? m->ridge2 : 0.f;
   const bool cg = cm.mode == FUSE_CG;
-  static const bool no_side = getenv("BHG_MLP_NO_SIDE") != nullptr;    // A/B switches (debug)
+  static const bool no_side_env = getenv("BHG_MLP_NO_SIDE") != nullptr;    // A/B switches (debug)
   static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;
+  static const bool no_outer_all = getenv("BHG_MLP_NO_OUTER_ALL") != nullptr;
+  const bool no_side = no_side_env || cg;
   const bool head = use_head(m);
-  BHG_REQUIRE(!cg || (head && !no_side), "the fused CG solver needs the narrow-head kernels and the side stream");
+  BHG_REQUIRE(!cg || head, "the fused CG solver needs the narrow-head kernels");
   SideState* ssp = nullptr;
   if (int rc = side_state(&ssp)) return rc;
   SideState& ss = *ssp;
@@ -1359,21 +1427,6 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     part_base_bias = base;
   }
 
-  // ---- fused CG: the chain-independent G pass  G_l = delta_l V_l  (l = 1 .. L-2) on the side stream -------------------
-  if (cg) {
-    BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_dir, 0));   // the direction (and last iteration's scalars) are final
-    for (int l = L - 2; l >= 1; --l) {
-      const int K = m->dims[l + 1], N = m->dims[l];
-      GemmArgs a{};
-      a.pr[0] = {m->delta[l], static_cast<const float*>(dir[2 * l]), K, N};
-      a.pairs = 1;
-      a.M = Bp; a.N = N; a.K = K;
-      a.splits = cm.ws->gsplits[l];
-      a.out = cm.ws->gpartial[l]; a.ldo = N; a.out_rows = Bp;
-      launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, side);
-    }
-  }
-
   // ---- R-forward ------------------------------------------------------------------------------------
   HeadFuse head_fuse{};
   bool fuse_head = false;
@@ -1386,7 +1439,6 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
                           m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
                           l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
                           fuse_head ? &head_fuse : nullptr, cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr);
-      if (cg) BHG_HIP_CHECK(hipEventRecord(ss.ev_head, st));
       continue;
     }
     GemmArgs a{};
@@ -1404,63 +1456,50 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       fuse_head = true;
     } else if (l + 1 < L) {
       launch_reduce_mask(st, m->partial, a.splits, slab, c, m->mask[l], m->Rh[l], Bp, N, B);
-      // (an event record costs the stream a ~4 us bubble, a cross-stream wait ~8 us — measured, rocprofv3 timeline —
-      //  so only the one record the G sums need is made)
-      if (cg && l == L - 3) BHG_HIP_CHECK(hipEventRecord(ss.ev_rh[l], st));
     } else {
       hipLaunchKernelGGL(k_reduce_softmax_jvp, dim3((Bp + 15) / 16), dim3(256), 0, st, (const float*)m->partial,
                          a.splits, slab, c, m->prob, m->sd, m->Rd[l], Bp, N, B);
     }
   }
 
-  // ---- fused CG: reduce the G slabs, T2, then the step length — all on the side stream, beside the R-backward chain --
-  if (cg) {
-    if (L >= 3) {
-      // G_l needs Rh_{l-1}: every Rh_j, j <= L-3, is written by an explicit reduce (only Rh_{L-2} can live inside the
-      // head kernel), the last of them by the reduce of layer L-3
-      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rh[L - 3], 0));
-      int done = 0;
-      for (int l0 = 1; l0 + 1 < L; l0 += 2) {
-        GsumArgs g{};
-        int blk = 0;
-        for (int q = 0; q < 2 && l0 + q + 1 < L; ++q) {
-          const int l = l0 + q;
-          g.part[q] = cm.ws->gpartial[l]; g.splits[q] = cm.ws->gsplits[l]; g.slab[q] = Bp * m->dims[l];
-          g.rh[q] = m->Rh[l - 1]; g.gsum[q] = cm.ws->gsum[l];
-          g.blk0[q] = blk;
-          blk += (Bp * m->dims[l] / 4 + 255) / 256;
-          g.n = q + 1;
-        }
-        g.blk0[g.n] = blk;
-        hipLaunchKernelGGL(k_gsum_dot, dim3(blk), dim3(256), 0, side, g, cm.ws->partT2 + done);
-        done += blk;
-      }
-      BHG_HIP_CHECK(hipEventRecord(ss.ev_gsum, side));
-    }
-    BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_head, 0));
-    AlphaArgs aa{};
-    aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
-    aa.partT2 = cm.ws->partT2; aa.nT2 = L >= 3 ? cm.ws->nT2 : 0;
-    aa.partPP = cm.partPP; aa.nPP = cm.nPP;
-    aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
-    aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
-    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, side, aa);   // every fused epilogue is queued behind it on `side`
-  }
-
-  // ---- R-backward (main stream) overlapped with the weight-shaped outputs (side stream) ----------------
-  // H(W_l) only needs Rd_l and Rh_{l-1}; the R-backward chain that produces Rd_{l-1} is independent of
-  // it.  The many-workgroup outer products therefore run on a library-owned side stream and fill the
-  // CUs the short, latency-bound split-K kernels of the backward chain leave idle.
-  auto launch_outer = [&](int l, hipStream_t s) {
+  // ---- weight-shaped outputs: launch descriptions ----------------------------------------------------------
+  auto outer_args = [&](int l, GemmArgs* ga, size_t* lds, bool* fast) {
     const int Mo = m->dims[l + 1], No = m->dims[l];
     const float* V = static_cast<const float*>(dir[2 * l]);
+    GemmArgs a{};
+    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
+    a.pairs = 1;
+    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
+    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
+    a.splits = 1;
+    a.out = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l]) : nullptr; a.ldo = No; a.out_rows = 0;
+    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
+    a.kstages = (B + kOH - 1) / kOH < 2 ? 2 : (B + kOH - 1) / kOH;   // <= 64 K rows per pipeline stage
+    const int Kh = (((B + a.kstages - 1) / a.kstages) + 1) & ~1;      // (see k_outer)
+    *lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
+    const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
+    if (*lds < lds_c) *lds = lds_c;
+    bool f = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
+    for (int i = 0; i < a.pairs; ++i) f = f && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+    if (cm.mode != FUSE_NONE) f = f && (cm.starts[2 * l] & 3) == 0;   // 16-B aligned state slices
+    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
+    *fast = f && !no_fast;
+    *ga = a;
+  };
+  auto head_outer_args = [&](int l) {
+    HeadOuterArgs ha{};
+    ha.rd = m->Rd[l]; ha.h = m->h[l]; ha.delta = m->delta[l]; ha.Rh = l > 0 ? m->Rh[l - 1] : nullptr;
+    ha.V = static_cast<const float*>(dir[2 * l]); ha.rho2 = rho2;
+    ha.out = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l]) : nullptr;
+    ha.N = m->dims[l]; ha.C = m->dims[l + 1]; ha.B = B;
+    return ha;
+  };
+  auto launch_outer = [&](int l, hipStream_t s) {
     const FuseArgs fz = fuse_at(2 * l, part_base_w[l]);
-    float* outp = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l]) : nullptr;
     if (head && l == L - 1) {
-      const dim3 grid((No + 63) / 64, Mo);
-#define BHG_HEAD_OUTER(RH, MODE)                                                                                       \
-  hipLaunchKernelGGL((k_head_outer<RH, MODE>), grid, dim3(256), 0, s, (const float*)m->Rd[l], m->h[l], m->delta[l],    \
-                     RH ? (const float*)m->Rh[l - 1] : (const float*)nullptr, V, rho2, outp, No, Mo, B, fz)
+      const HeadOuterArgs ha = head_outer_args(l);
+      const dim3 grid((ha.N + 63) / 64, ha.C);
+#define BHG_HEAD_OUTER(RH, MODE) hipLaunchKernelGGL((k_head_outer<RH, MODE>), grid, dim3(256), 0, s, ha, fz)
       if (l > 0) {
         if (cm.mode == FUSE_CG) BHG_HEAD_OUTER(true, FUSE_CG);
         else if (cm.mode == FUSE_NEUMANN) BHG_HEAD_OUTER(true, FUSE_NEUMANN);
@@ -1473,25 +1512,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
 #undef BHG_HEAD_OUTER
       return;
     }
-    GemmArgs a{};
-    a.pr[0] = {m->Rd[l], m->h[l], Mo, No};              // Rd_l^T h_{l-1}
-    a.pairs = 1;
-    if (l > 0) { a.pr[1] = {m->delta[l], m->Rh[l - 1], Mo, No}; a.pairs = 2; }  // delta_l^T Rh_{l-1}
-    a.M = Mo; a.N = No; a.K = B;                        // only the B valid batch rows contribute
-    a.splits = 1;
-    a.out = outp; a.ldo = No; a.out_rows = 0;
-    a.addend = rho2 != 0.f ? V : nullptr; a.addend_scale = rho2;
-    a.kstages = (B + kOH - 1) / kOH < 2 ? 2 : (B + kOH - 1) / kOH;   // <= 64 K rows per pipeline stage
-    const int Kh = (((B + a.kstages - 1) / a.kstages) + 1) & ~1;      // (see k_outer)
-    size_t lds = (size_t)Kh * (kTM + kTN) * sizeof(float);
-    const size_t lds_c = (size_t)kTM * kCPad * sizeof(float);
-    if (lds < lds_c) lds = lds_c;
-    dim3 grid((No + kTN - 1) / kTN, (Mo + kTM - 1) / kTM, 1);
-    bool fast = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
-    for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
-    if (cm.mode != FUSE_NONE) fast = fast && (cm.starts[2 * l] & 3) == 0;   // 16-B aligned state slices
-    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
-    if (no_fast) fast = false;
+    GemmArgs a; size_t lds; bool fast;
+    outer_args(l, &a, &lds, &fast);
+    dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, 1);
 #define BHG_OUTER(MODE)                                                                   \
   do {                                                                                    \
     if (fast) hipLaunchKernelGGL((k_outer<true, MODE>), grid, dim3(256), lds, s, a, fz);  \
@@ -1502,75 +1525,132 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     else BHG_OUTER(FUSE_NONE);
 #undef BHG_OUTER
   };
-  for (int l = L - 1; l >= 1; --l) {
-    // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
-    if (no_side) {
-      launch_outer(l, st);
-    } else {
-      // (fused CG: ev_head / ev_rd[l] were waited for before k_cg_alpha or are recorded below; the side stream's
-      //  own order puts every fused epilogue behind k_cg_alpha)
-      if (!(cg && head && l >= L - 2)) {   // those: Rd_{L-1}, Rd_{L-2} come from the head kernel = ev_head, already waited
-        BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[l], st));
-        BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[l], 0));
-      }
-      launch_outer(l, side);
-    }
-    const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
-    const float* V = static_cast<const float*>(dir[2 * l]);
-    if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
-    GemmArgs a{};
-    if (cg) {   // delta_l V_l comes from the G pass (its sum is the reduce's addend): only Rd_l W_l is on the chain
-      a.pr[0] = {m->Rd[l], m->W[l], K, N};
-      a.pairs = 1;
-    } else {
-      a.pr[0] = {m->delta[l], V, K, N};
-      a.pr[1] = {m->Rd[l], m->W[l], K, N};
-      a.pairs = 2;
-    }
-    a.M = Bp; a.N = N; a.K = K;
-    a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
-    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
-    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
-    const int slab = Bp * N;
-    if (cg && l == L - 2) BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_gsum, 0));   // first consumer of the G sums
-    launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B, nullptr,
-                       cg ? cm.ws->gsum[l] : nullptr);
-  }
+  BiasArgs ba{};
+  int bias_blk = 0;
   {
-    BiasArgs ba{};
     ba.L = L; ba.B = B; ba.rho2 = rho2;
-    int blk = 0;
     for (int l = 0; l < L; ++l) {
       ba.rd[l] = m->Rd[l];
       ba.c[l] = static_cast<const float*>(dir[2 * l + 1]);
       ba.out[l] = cm.mode == FUSE_NONE ? static_cast<float*>(cm.out[2 * l + 1]) : nullptr;
       ba.foff[l] = cm.mode == FUSE_NONE ? 0 : cm.starts[2 * l + 1];
       ba.n[l] = m->dims[l + 1];
-      ba.blk0[l] = blk;
-      blk += (m->dims[l + 1] + 63) / 64;
+      ba.blk0[l] = bias_blk;
+      bias_blk += (m->dims[l + 1] + 63) / 64;
     }
-    ba.blk0[L] = blk;
-    FuseArgs fz = fbase;
-    fz.a = cm.fa; fz.b = cm.fb; fz.d = cm.fd; fz.part_base = part_base_bias;   // offsets travel in ba.foff
-    hipStream_t bs = st;
-    if (L > 1 && !no_side) {  // needs every Rd_l (complete on the main stream now); runs beside H(W_0)
-      BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
-      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
-      bs = side;
-    } else if (cg) {   // single-layer net: everything on the side stream (behind k_cg_alpha)
-      BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
-      BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
-      bs = side;
-    }
-    // fused CG: H(W_0) goes to the side stream as well — it is ordered behind k_cg_alpha there, so the caller's
-    // stream never has to wait for the step length (a cross-stream wait costs ~8 us even when the event is long done)
-    if (cg) launch_outer(0, side);
-    if (cm.mode == FUSE_CG) hipLaunchKernelGGL(k_bias_hvp<FUSE_CG>, dim3(blk), dim3(256), 0, bs, ba, fz);
-    else if (cm.mode == FUSE_NEUMANN) hipLaunchKernelGGL(k_bias_hvp<FUSE_NEUMANN>, dim3(blk), dim3(256), 0, bs, ba, fz);
-    else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(blk), dim3(256), 0, bs, ba, fz);
+    ba.blk0[L] = bias_blk;
   }
-  if (!cg) launch_outer(0, st);  // needs Rd_0, the end of the chain
-  if ((L > 1 && !no_side) || cg) {
+  FuseArgs bias_fz = fbase;
+  bias_fz.a = cm.fa; bias_fz.b = cm.fb; bias_fz.d = cm.fd; bias_fz.part_base = part_base_bias;   // offsets travel in ba.foff
+  auto launch_bias = [&](hipStream_t s) {
+    if (cm.mode == FUSE_CG) hipLaunchKernelGGL(k_bias_hvp<FUSE_CG>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
+    else if (cm.mode == FUSE_NEUMANN) hipLaunchKernelGGL(k_bias_hvp<FUSE_NEUMANN>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
+    else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
+  };
+
+  // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
+  for (int l = L - 1; l >= 1; --l) {
+    if (!cg) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
+      if (no_side) {
+        launch_outer(l, st);
+      } else {
+        BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[l], st));
+        BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[l], 0));
+        launch_outer(l, side);
+      }
+    }
+    const int K = m->dims[l + 1], N = m->dims[l];  // Rd_{l-1}[Bp][N] = delta_l[Bp][K] V_l[K][N] + Rd_l W_l
+    const float* V = static_cast<const float*>(dir[2 * l]);
+    if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
+    GemmArgs a{};
+    a.pr[0] = {m->delta[l], V, K, N};
+    a.pr[1] = {m->Rd[l], m->W[l], K, N};
+    a.pairs = 2;
+    a.M = Bp; a.N = N; a.K = K;
+    a.splits = pick_splits((N + tn - 1) / tn, K, 2);
+    if (cg) {
+      // the two products land in separate slabs (each workgroup takes twice the K range of ONE pair: same count and
+      // length of K loops), so the reduce can dot delta_l V_l with Rh_{l-1} on its way: T2_l
+      if (a.splits < 2) a.splits = 2;
+      a.pair_split = a.splits / 2;
+    }
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
+    const int slab = Bp * N;
+    if (cg) {
+      const int blocks = reduce_blocks(slab, N);
+      double* pt2 = cm.ws->partT2 + cm.ws->t2_off[l];
+      if ((N & 3) == 0)
+        hipLaunchKernelGGL(k_reduce_mask_t2<4>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
+      else
+        hipLaunchKernelGGL(k_reduce_mask_t2<1>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
+    } else {
+      launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
+    }
+  }
+
+  if (cg) {
+    // ---- step length from the batch-sized factors, then every weight-shaped output with the recurrence in its epilogue --
+    AlphaArgs aa{};
+    aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
+    aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
+    aa.partPP = cm.partPP; aa.nPP = cm.nPP;
+    aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
+    aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
+    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+
+    // one launch for all of them when every MFMA layer is all-interior (largest layers first: they set the tail)
+    const int n_mfma = head ? L - 1 : L;
+    OuterAllArgs oa{};
+    bool all_fast = !no_outer_all && n_mfma <= kOuterAllMax && head;
+    size_t lds_max = 0;
+    int order[BHG_MLP_MAX_LAYERS];
+    for (int i = 0; i < n_mfma; ++i) order[i] = i;
+    for (int i = 1; i < n_mfma; ++i)   // insertion sort by tile count, descending
+      for (int j = i; j > 0 && outer_blocks(m, order[j], head) > outer_blocks(m, order[j - 1], head); --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int blk = 0;
+    for (int i = 0; i < n_mfma && all_fast; ++i) {
+      const int l = order[i];
+      size_t lds; bool fast;
+      outer_args(l, &oa.g[i], &lds, &fast);
+      all_fast = all_fast && fast;
+      if (lds > lds_max) lds_max = lds;
+      oa.f[i] = fuse_at(2 * l, part_base_w[l]);
+      oa.gx[i] = (oa.g[i].N + kTN - 1) / kTN;
+      oa.blk0[i] = blk;
+      blk += outer_blocks(m, l, head);
+    }
+    if (all_fast) {
+      oa.n = n_mfma;
+      oa.blk0[n_mfma] = blk;
+      oa.head = head_outer_args(L - 1);
+      oa.hf = fuse_at(2 * (L - 1), part_base_w[L - 1]);
+      oa.head_gx = (oa.head.N + 63) / 64;
+      oa.head_blocks = oa.head_gx * oa.head.C;
+      oa.head_has_rh = L > 1;
+      oa.bf = bias_fz;
+      const int total = blk + oa.head_blocks + bias_blk;
+      if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
+      hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
+    } else {
+      for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
+      launch_bias(st);
+    }
+    BHG_HIP_CHECK(hipGetLastError());
+    return BHG_OK;
+  }
+
+  if (L > 1 && !no_side) {  // the bias terms need every Rd_l (complete on the main stream now); they run beside H(W_0)
+    BHG_HIP_CHECK(hipEventRecord(ss.ev_rd[0], st));
+    BHG_HIP_CHECK(hipStreamWaitEvent(side, ss.ev_rd[0], 0));
+    launch_bias(side);
+  } else {
+    launch_bias(st);
+  }
+  launch_outer(0, st);  // needs Rd_0, the end of the chain
+  if (L > 1 && !no_side) {
     BHG_HIP_CHECK(hipEventRecord(ss.ev_join, side));
     BHG_HIP_CHECK(hipStreamWaitEvent(st, ss.ev_join, 0));
   }
@@ -1600,7 +1680,8 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
     const int Nf = m->dims[l + 1], Kf = m->dims[l];
     const int sf = pick_splits((Nf + skinny_tile_n() - 1) / skinny_tile_n(), Kf, 2);
     mx = mx > (size_t)sf * m->Bp * Nf ? mx : (size_t)sf * m->Bp * Nf;
-    const int sb = pick_splits((Kf + skinny_tile_n() - 1) / skinny_tile_n(), Nf, 2);
+    int sb = pick_splits((Kf + skinny_tile_n() - 1) / skinny_tile_n(), Nf, 2);
+    if (sb < 2) sb = 2;   // fused CG: the two operand pairs of the R-backward GEMM land in separate slabs
     mx = mx > (size_t)sb * m->Bp * Kf ? mx : (size_t)sb * m->Bp * Kf;
   }
   return mx;
@@ -1625,8 +1706,7 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
 // ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
   static const bool off = getenv("BHG_MLP_NO_FUSED_SOLVE") != nullptr;   // A/B switch: callers fall back to HVP + recurrence kernel
-  return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m) &&
-         getenv("BHG_MLP_NO_SIDE") == nullptr;
+  return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m);
 }
 
 size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m) {
@@ -1656,8 +1736,6 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   hipStream_t st = static_cast<hipStream_t>(stream);
   FusedWs w;
   carve_fused_ws(m, fws, &w);
-  SideState* ss = nullptr;
-  if (int rc = side_state(&ss)) return rc;
   char* wsb = static_cast<char*>(ws);
   double* scal = reinterpret_cast<double*>(wsb + kWsScal);
   const double* partR0 = reinterpret_cast<const double*>(wsb + kWsPartR);   // r.r partials of bhg_cg_init (r = p there)
@@ -1671,7 +1749,6 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     const bool timed_it = span_begin(BHG_TIMING_MLP_CG_ITER, &tc, &td);
     if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
-    BHG_HIP_CHECK(hipEventRecord(ss->ev_dir, st));   // p (and for k = 0: bhg_cg_init's state) is final here
     ChainMode cm{};
     cm.mode = FUSE_CG;
     cm.fa = r; cm.fb = x; cm.fd = p; cm.starts = starts;
