@@ -1225,19 +1225,38 @@ struct AlphaArgs {
   const double* partT1; const double* partT2h; int B;
   const double* partT2; int nT2;
   const double* partPP; int nPP;
-  const double* partRR; int nRR;
+  const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
   float cg_alpha, shift;
   double* scal;
 };
 __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
-  __shared__ double red[kWaves];
-  const double t1 = sum_partials(a.partT1, a.B, red);
-  const double t2h = a.partT2h ? sum_partials(a.partT2h, a.B, red) : 0.0;
-  const double t2 = sum_partials(a.partT2, a.nT2, red);
-  const double pp = a.shift != 0.f ? sum_partials(a.partPP, a.nPP, red) : 0.0;
-  const double rr = sum_partials(a.partRR, a.nRR, red);
+  __shared__ double red[5][kWaves];
+  // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
+  // one wave reduction per quantity and a fixed-order combine of the wave results
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
+  if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
+  for (int i = threadIdx.x; i < a.nT2; i += kThreads) acc[2] += a.partT2[i];
+  if (a.shift != 0.f) for (int i = threadIdx.x; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
+  for (int i = threadIdx.x; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double v = wave_sum(acc[q]);
+    if (lane == 0) red[q][w] = v;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const double php = (t1 + t2h + t2) + (double)a.shift * pp;
+    double tot[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWaves; ++i) t += red[q][i];
+      tot[q] = t;
+    }
+    const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
+    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * tot[3];
     const double den = (double)a.cg_alpha * php;
     const float alpha = (float)rr / (float)den;
     a.scal[S_RR_OLD] = rr;
@@ -1398,7 +1417,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   static const bool no_side_env = getenv("BHG_MLP_NO_SIDE") != nullptr;    // A/B switches (debug)
   static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;
   static const bool no_outer_all = getenv("BHG_MLP_NO_OUTER_ALL") != nullptr;
-  const bool no_side = no_side_env || cg;
+  static const bool neumann_side = getenv("BHG_NEUMANN_SIDE") != nullptr;    // A/B: fused Neumann with side-stream outputs
+  // `single`: one stream, no events, all weight-shaped outputs in one launch after the chain
+  const bool single = cg || (cm.mode == FUSE_NEUMANN && !neumann_side && !no_outer_all);
+  const bool no_side = no_side_env || single;
   const bool head = use_head(m);
   BHG_REQUIRE(!cg || head, "the fused CG solver needs the narrow-head kernels");
   SideState* ssp = nullptr;
@@ -1550,7 +1572,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
 
   // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
   for (int l = L - 1; l >= 1; --l) {
-    if (!cg) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
+    if (!single) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
       if (no_side) {
         launch_outer(l, st);
       } else {
@@ -1591,25 +1613,29 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
   }
 
-  if (cg) {
-    // ---- step length from the batch-sized factors, then every weight-shaped output with the recurrence in its epilogue --
-    AlphaArgs aa{};
-    aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
-    aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
-    aa.partPP = cm.partPP; aa.nPP = cm.nPP;
-    aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
-    aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
-    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
-
-    // one launch for all of them when every MFMA layer is all-interior (largest layers first: they set the tail)
+  if (single) {
+    if (cg) {
+      // ---- step length from the batch-sized factors, then every weight-shaped output with the recurrence in its epilogue
+      AlphaArgs aa{};
+      aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
+      aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
+      aa.partPP = cm.partPP; aa.nPP = cm.nPP;
+      aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
+      aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
+      hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    }
+    // one launch for all outputs when every MFMA layer is all-interior.  Tile order = dispatch order: two-pair tiles
+    // (twice the MFMA work) first, so the short one-pair tiles of layer 0 fill the tail
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
     bool all_fast = !no_outer_all && n_mfma <= kOuterAllMax && head;
     size_t lds_max = 0;
     int order[BHG_MLP_MAX_LAYERS];
+    static const bool big_first = getenv("BHG_OUTER_ORDER_BY_SIZE") != nullptr;   // A/B: largest tile count first
+    auto weight = [&](int l) { return big_first ? (double)outer_blocks(m, l, head) : (l > 0 ? 2.0 : 1.0) * 1e9 + outer_blocks(m, l, head); };
     for (int i = 0; i < n_mfma; ++i) order[i] = i;
-    for (int i = 1; i < n_mfma; ++i)   // insertion sort by tile count, descending
-      for (int j = i; j > 0 && outer_blocks(m, order[j], head) > outer_blocks(m, order[j - 1], head); --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int i = 1; i < n_mfma; ++i)   // insertion sort, descending
+      for (int j = i; j > 0 && weight(order[j]) > weight(order[j - 1]); --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
     int blk = 0;
     for (int i = 0; i < n_mfma && all_fast; ++i) {
       const int l = order[i];
@@ -1633,7 +1659,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.bf = bias_fz;
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
-      hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
+      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
+      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba);
     } else {
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
@@ -1755,8 +1782,8 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.shift = hvp_shift; cm.cg_alpha = cg_alpha;
     cm.apply_out = k == K - 1; cm.out_scale = -cg_alpha;   // cg.py:56 and the negation of cg.py:59/68
     cm.ws = &w; cm.scal = scal;
-    cm.partRR_old = k == 0 ? partR0 : w.partRR[k & 1];
-    cm.nRR_old = k == 0 ? n_init : w.nRR;
+    cm.partRR_old = partR0;            // k > 0: r.r was summed by the previous k_cg_pdir (scal[S_RR_NEW])
+    cm.nRR_old = k == 0 ? n_init : 0;
     cm.partPP = k == 0 ? partR0 : w.partPP;   // p = r after the init, so p.p = r.r
     cm.nPP = k == 0 ? n_init : pgrid;
     cm.partRR_new = w.partRR[(k + 1) & 1];
