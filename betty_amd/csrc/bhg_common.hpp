@@ -29,7 +29,8 @@ inline size_t ws_bytes(int T) {
 }
 
 // scalar slots
-enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_NPART0 = 8 /* and 9 */ };
+enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 /* fused solver: p.p of the coming direction */,
+       S_NPART0 = 8 /* and 9 */ };
 
 // ---- error plumbing -------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -39,6 +39,11 @@ struct GemmPair {
   const float* A;  // "M side" operand
   const float* B;  // "N side" operand
   int lda, ldb;    // leading dimensions (elements)
+  // "lazy direction" of the fused CG solver (k_gemm<..., BF = true>): the N-side operand is formed while it is staged,
+  //   Beff = B + (mix ? beta : 0) * B2,  beta = scal[S_BETA]     (B = r slice, B2 = previous direction slice)
+  // so the new CG direction p = r' + beta * p_old is never written out by a kernel of its own (cg.py:53).
+  const float* B2;
+  int mix;
 };
 struct GemmArgs {
   GemmPair pr[2];
@@ -51,6 +56,7 @@ struct GemmArgs {
   const float* addend;  // optional: out = acc + addend_scale * addend[m][n] (same ld as out)
   float addend_scale;
   int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
+  const double* scal;   // BF instances: device scalars (beta)
   int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
                         // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
 };
@@ -151,7 +157,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ lds, int row, in
 // launch_gemm).  The instance then has NO edge path: with the ragged-tile branches in the loop hipcc puts an
 // `s_waitcnt vmcnt(0)` at the top of every step (the control-flow join), which serialises the two-stage
 // register prefetch — step s+1's loads had to land BEFORE step s's MFMAs instead of behind them.
-template <int LA, int LB, int TN, bool FAST>
+template <int LA, int LB, int TN, bool FAST, bool BF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 3 : 2, TN == 32 ? 3 : 2))) void k_gemm(GemmArgs a) {
   static_assert(TN == 64 || TN == 32, "tile width");
   constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
@@ -197,9 +203,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
   // in the body hipcc shuttles all 32 accumulator registers AGPR -> VGPR -> AGPR around every step and
   // drains the load queue at each join.
   float4 ra0[kTM / 32], rb0[TN / 32], ra1[kTM / 32], rb1[TN / 32];
+  float4 rq0[TN / 32], rq1[TN / 32];   // BF: the second N-side operand of the stage (previous direction)
+  float bs0 = 0.f, bs1 = 0.f;          // BF: its weight for the stage's pair (beta or 0), workgroup-uniform
+  const float beta = BF ? (float)a.scal[S_BETA] : 0.f;
   const GemmPair pr0 = a.pr[first];
   const GemmPair pr1 = a.pr[npairs > 1 ? 1 : first];   // operand bases live in SGPRs, not re-fetched per step
-  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32]) {
+  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32], float4 (&rq)[TN / 32], float& bs) {
     step = min(step, nsteps - 1);
     const bool second = step >= nsteps_pair;          // workgroup-uniform
     const int k0 = kbeg + (step - (second ? nsteps_pair : 0)) * kTK;
@@ -213,8 +222,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
     else load_rc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
     if (LB == LAYOUT_KC) load_kc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
     else load_rc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
+    if (BF) {
+      const float* gQ = second ? pr1.B2 : pr0.B2;
+      bs = (second ? pr1.mix : pr0.mix) ? beta : 0.f;
+      if (LB == LAYOUT_KC) load_kc<TN>(gQ, ldb, n0, a.N, k0, kend, fb, rq);
+      else load_rc<TN>(gQ, ldb, n0, a.N, k0, kend, fb, rq);
+    }
   };
-  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], const float4 (&rb)[TN / 32]) {
+  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32], const float4 (&rq)[TN / 32], float bs) {
+    if (BF) {   // same two roundings as k_cg_pdir: p = r' + (beta * p_old); a pair without mix has bs = 0 and B2 = B
+#pragma unroll
+      for (int i = 0; i < TN / 32; ++i) {
+        rb[i].x = __fadd_rn(rb[i].x, __fmul_rn(bs, rq[i].x)); rb[i].y = __fadd_rn(rb[i].y, __fmul_rn(bs, rq[i].y));
+        rb[i].z = __fadd_rn(rb[i].z, __fmul_rn(bs, rq[i].z)); rb[i].w = __fadd_rn(rb[i].w, __fmul_rn(bs, rq[i].w));
+      }
+    }
     if (LA == LAYOUT_KC) store_kc<kTM>(sA[buf], ra); else store_rc<kTM>(sA[buf], ra);
     if (LB == LAYOUT_KC) store_kc<TN>(sB[buf], rb); else store_rc<TN>(sB[buf], rb);
   };
@@ -258,22 +280,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
   if (nsteps > 0) {
-    gload(0, ra0, rb0);
-    gload(1, ra1, rb1);
-    lstore(0, ra0, rb0);
+    gload(0, ra0, rb0, rq0, bs0);
+    gload(1, ra1, rb1, rq1, bs1);
+    lstore(0, ra0, rb0, rq0, bs0);
     __syncthreads();
     int step = 0;
     for (; step + 1 < nsteps; step += 2) {
       // Per step: issue the loads of tile s+2, hand tile s+1 (loaded a step ago) to the OTHER LDS buffer, then
       // run this tile's MFMAs — the LDS stores complete in the shadow of the MFMAs, so the barrier at the end
       // of the step finds them done.  (The buffer being written was last read before the previous barrier.)
-      gload(step + 2, ra0, rb0);   // even step: tile in buffer 0, next tile parked in stage 1
-      lstore(1, ra1, rb1);
+      gload(step + 2, ra0, rb0, rq0, bs0);   // even step: tile in buffer 0, next tile parked in stage 1
+      lstore(1, ra1, rb1, rq1, bs1);
       SCHED_FENCE();
       compute(0);
       __syncthreads();
-      gload(step + 3, ra1, rb1);   // odd step: tile in buffer 1, next tile parked in stage 0
-      lstore(0, ra0, rb0);
+      gload(step + 3, ra1, rb1, rq1, bs1);   // odd step: tile in buffer 1, next tile parked in stage 0
+      lstore(0, ra0, rb0, rq0, bs0);
       SCHED_FENCE();
       compute(1);
       __syncthreads();
@@ -314,28 +336,36 @@ enum : int { FUSE_NONE = 0, FUSE_CG = 1, FUSE_NEUMANN = 2 };
 struct FuseArgs {
   float* a;          // CG: r (in/out)          Neumann: v_out (out)
   float* b;          // CG: x (in/out)          Neumann: p (in/out)
-  const float* d;    // the direction slice:    CG: p    Neumann: v_in
-  const double* scal;  // CG: device scalars, alpha = scal[S_ALPHA]
-  double* part;        // CG: per-workgroup partial of r'.r' -> part[part_base + linear block id]
-  int part_base;
+  float* d;          // the direction slice:    CG: p (in; in/out when lazy)    Neumann: v_in (in)
+  const double* scal;  // CG: device scalars, alpha = scal[S_ALPHA], beta = scal[S_BETA]
+  double* part;        // CG: per-workgroup partials -> part[q * part_stride + part_base + linear block id],
+  int part_base;       //     q = 0: r'.r'   q = 1: r'.p   q = 2: p.p   (p = this iteration's direction)
+  int part_stride;
   float alpha;       // Neumann: step length (host constant)
   float shift;       // operator = raw HVP + shift * I
   float out_scale;   // applied to x (CG) / p (Neumann) when apply_out != 0: the final scaling + negation of the solve
   int apply_out;
+  int lazy;          // CG: the slice at d still holds the PREVIOUS direction; this iteration's is r + beta * d — formed
+                     // here (same roundings as k_cg_pdir) and written back, so no kernel of its own updates it (cg.py:53)
 };
+struct FuseAcc { double rr, rp, pp; };
 __device__ __forceinline__ float fz_mul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fz_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float fz_sub(float a, float b) { return __fsub_rn(a, b); }
-// one element: hv = raw HVP value, dv = direction, av / bv = the two state values; results back in av / bv.
+// one element: hv = raw HVP value, dv = direction (CG lazy: previous direction), av / bv = the two state values;
+// results back in av / bv, the direction actually used back in dv.
 template <int MODE>
-__device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float hv, float dv, float& av, float& bv,
-                                          double& racc) {
+__device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float beta, float hv, float& dv, float& av,
+                                          float& bv, FuseAcc& acc) {
+  if (MODE == FUSE_CG && f.lazy) dv = fz_add(av, fz_mul(beta, dv));
   if (f.shift != 0.f) hv = fz_add(hv, fz_mul(f.shift, dv));
   if (MODE == FUSE_CG) {
     const float nr = fz_sub(av, fz_mul(alpha, hv));
     float nx = fz_add(bv, fz_mul(alpha, dv));
     if (f.apply_out) nx = fz_mul(f.out_scale, nx);
-    racc += (double)nr * nr;
+    acc.rr += (double)nr * nr;
+    acc.rp += (double)nr * dv;
+    acc.pp += (double)dv * dv;
     av = nr; bv = nx;
   } else {
     const float nv = fz_sub(dv, fz_mul(alpha, hv));
@@ -347,6 +377,22 @@ __device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float 
 template <int MODE>
 __device__ __forceinline__ float fuse_alpha(const FuseArgs& f) {
   return MODE == FUSE_CG ? (float)f.scal[S_ALPHA] : f.alpha;
+}
+template <int MODE>
+__device__ __forceinline__ float fuse_beta(const FuseArgs& f) {
+  return MODE == FUSE_CG && f.lazy ? (float)f.scal[S_BETA] : 0.f;
+}
+// block-wide sums of the three partials -> part[q][part_base + idx]   (all threads of the 256-thread block call it)
+__device__ __forceinline__ void fuse_store_partials(const FuseArgs& f, const FuseAcc& acc, int idx, double* red) {
+  const double s0 = block_sum(acc.rr, red);
+  const double s1 = block_sum(acc.rp, red);
+  const double s2 = block_sum(acc.pp, red);
+  if (threadIdx.x == 0) {
+    double* p0 = f.part + f.part_base + idx;
+    p0[0] = s0;
+    p0[f.part_stride] = s1;
+    p0[2 * (int64_t)f.part_stride] = s2;
+  }
 }
 
 // ---- weight-shaped outputs: C[M][N] = sum_pairs A_pair^T B_pair (+ addend), K = batch (<= 128) -----------
@@ -502,7 +548,9 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
     // (the weight tensor W_l occupies flat[start_l + row*ldo + col]); two half-tiles of 4 float4 per thread so the
     // 8-12 state loads of a half are all in flight before the first use.
     const float alpha = fuse_alpha<MODE>(fz);
-    double racc = 0.0;
+    const float beta = fuse_beta<MODE>(fz);
+    const bool wr_d = MODE == FUSE_CG && fz.lazy;
+    FuseAcc racc{0.0, 0.0, 0.0};
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       float4 dv[4], av[4], bv[4];
@@ -526,28 +574,27 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
         const float4 hv = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
         const int64_t off = (int64_t)grow * a.ldo + gcol;
         if (ok[i]) {
-          float4 na = MODE == FUSE_CG ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), nb = bv[i];
-          fuse_elem<MODE>(fz, alpha, hv.x, dv[i].x, na.x, nb.x, racc);
-          fuse_elem<MODE>(fz, alpha, hv.y, dv[i].y, na.y, nb.y, racc);
-          fuse_elem<MODE>(fz, alpha, hv.z, dv[i].z, na.z, nb.z, racc);
-          fuse_elem<MODE>(fz, alpha, hv.w, dv[i].w, na.w, nb.w, racc);
+          float4 na = MODE == FUSE_CG ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), nb = bv[i], nd = dv[i];
+          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc);
+          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc);
+          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc);
+          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc);
           *reinterpret_cast<float4*>(fz.a + off) = na;
           *reinterpret_cast<float4*>(fz.b + off) = nb;
+          if (wr_d) *reinterpret_cast<float4*>(fz.d + off) = nd;
         } else if (!FAST && grow < a.M) {   // ragged right edge / odd leading dimension: element by element
           const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
           for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
-            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = fz.b[off + j];
-            fuse_elem<MODE>(fz, alpha, hh[j], fz.d[off + j], na, nb, racc);
+            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = fz.b[off + j], nd = fz.d[off + j];
+            fuse_elem<MODE>(fz, alpha, beta, hh[j], nd, na, nb, racc);
             fz.a[off + j] = na;
             fz.b[off + j] = nb;
+            if (wr_d) fz.d[off + j] = nd;
           }
         }
       }
     }
-    if (MODE == FUSE_CG) {
-      const double s = block_sum(racc, red_rr);
-      if (t == 0) fz.part[fz.part_base + by * gx + bx] = s;
-    }
+    if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
     return;
   }
 #pragma unroll
@@ -601,7 +648,7 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = 0.f;
     if (m < B) {
-      if (VEC == 4) {
+      if constexpr (VEC == 4) {
         // Batches of 8 slabs: all 8 loads (plus bias and mask) are issued before the first add, so a
         // reduce costs one or two L2 round trips instead of `splits` dependent ones.  Lanes past the
         // last slab re-read it (an L1 hit) and are not added; the summation order stays s = 0, 1, ...
@@ -641,10 +688,10 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
         mk[j] = v[j] > 0.f ? 1.f : 0.f;
         v[j] = v[j] > 0.f ? v[j] : 0.f;
       }
-      if (VEC == 4) *reinterpret_cast<float4*>(relu_mask_out + i * VEC) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(relu_mask_out + i * VEC) = make_float4(mk[0], mk[1], mk[2], mk[3]);
       else relu_mask_out[i] = mk[0];
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
     else out[i] = v[0];
   }
 }
@@ -669,7 +716,7 @@ __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = 0.f;
     if (m < B) {
-      if (VEC == 4) {
+      if constexpr (VEC == 4) {
         constexpr int NB = 8;
         const float* p0 = part + i * VEC;
         const float4 mv = *reinterpret_cast<const float4*>(mask + i * VEC);
@@ -694,7 +741,7 @@ __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict_
         v[0] *= mask[i];
       }
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
     else out[i] = v[0];
   }
   const double sblk = block_sum(acc, red);
@@ -779,7 +826,7 @@ __device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz,
   }
   red[rg][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  double racc = 0.0;
+  FuseAcc racc{0.0, 0.0, 0.0};
   if (rg == 0 && col < N) {
     const int t = threadIdx.x;
     if (MODE == FUSE_NONE) {
@@ -787,16 +834,14 @@ __device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz,
     } else {
       const float hv = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
       const int64_t off = a.foff[l] + col;
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off];
-      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), hv, fz.d[off], na, nb, racc);
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off], nd = fz.d[off];
+      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), hv, nd, na, nb, racc);
       fz.a[off] = na;
       fz.b[off] = nb;
+      if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
     }
   }
-  if (MODE == FUSE_CG) {
-    const double sblk = block_sum(racc, red_rr);
-    if (threadIdx.x == 0) fz.part[fz.part_base + bx] = sblk;
-  }
+  if (MODE == FUSE_CG) fuse_store_partials(fz, racc, bx, red_rr);
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
@@ -1090,7 +1135,7 @@ __device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const F
   }
   red[g][threadIdx.x & 63] = acc;
   __syncthreads();
-  double racc = 0.0;
+  FuseAcc racc{0.0, 0.0, 0.0};
   if (g == 0 && n < N) {
     const int t = threadIdx.x;
     float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
@@ -1099,16 +1144,14 @@ __device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const F
       if (rho2 != 0.f) v += rho2 * V[off];
       out[off] = v;
     } else {
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off];
-      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), v, fz.d[off], na, nb, racc);
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off], nd = fz.d[off];
+      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), v, nd, na, nb, racc);
       fz.a[off] = na;
       fz.b[off] = nb;
+      if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
     }
   }
-  if (MODE == FUSE_CG) {
-    const double sblk = block_sum(racc, red_rr);
-    if (threadIdx.x == 0) fz.part[fz.part_base + by * gx + bx] = sblk;
-  }
+  if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
 }
 template <bool HAS_RH, int MODE>
 __global__ __launch_bounds__(256) void k_head_outer(HeadOuterArgs ha, FuseArgs fz) {
@@ -1160,19 +1203,29 @@ __global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ pro
 }
 
 template <int LA, int LB>
-void launch_gemm(const GemmArgs& a, int tn, hipStream_t st) {
+void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
+  GemmArgs a = a_in;
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
   bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
-  for (int i = 0; i < a.pairs; ++i) fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+  bool bf = false;
+  for (int i = 0; i < a.pairs; ++i) {
+    fast = fast && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+    bf = bf || a.pr[i].mix != 0;
+  }
+  if (bf)   // a pair without mixing reads its own operand twice with weight 0 (B + 0 * B = B exactly; the loop stays branch-free)
+    for (int i = 0; i < a.pairs; ++i)
+      if (!a.pr[i].mix) a.pr[i].B2 = a.pr[i].B;
   static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;   // A/B switch (debug)
   if (no_fast) fast = false;
+#define BHG_GEMM(TNV, F, BFV) hipLaunchKernelGGL((k_gemm<LA, LB, TNV, F, BFV>), grid, dim3(256), 0, st, a)
   if (tn == 64) {
-    if (fast) hipLaunchKernelGGL((k_gemm<LA, LB, 64, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm<LA, LB, 64, false>), grid, dim3(256), 0, st, a);
+    if (bf) { if (fast) BHG_GEMM(64, true, true); else BHG_GEMM(64, false, true); }
+    else    { if (fast) BHG_GEMM(64, true, false); else BHG_GEMM(64, false, false); }
   } else {
-    if (fast) hipLaunchKernelGGL((k_gemm<LA, LB, 32, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemm<LA, LB, 32, false>), grid, dim3(256), 0, st, a);
+    if (bf) { if (fast) BHG_GEMM(32, true, true); else BHG_GEMM(32, false, true); }
+    else    { if (fast) BHG_GEMM(32, true, false); else BHG_GEMM(32, false, false); }
   }
+#undef BHG_GEMM
 }
 inline int skinny_tile_n() {
   static const int tn = getenv("BHG_MLP_TN") ? atoi(getenv("BHG_MLP_TN")) : 32;  // 32 measured +2 % over 64
@@ -1224,7 +1277,7 @@ int pick_splits(int tiles, int K, int pairs) {
 struct AlphaArgs {
   const double* partT1; const double* partT2h; int B;
   const double* partT2; int nT2;
-  const double* partPP; int nPP;
+  const double* partPP; int nPP;   // nPP = 0: p.p = scal[S_PP] (written by k_cg_beta for the lazy direction)
   const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
   float cg_alpha, shift;
   double* scal;
@@ -1256,7 +1309,8 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
       tot[q] = t;
     }
     const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
-    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * tot[3];
+    const double pp = a.nPP > 0 ? tot[3] : a.scal[S_PP];
+    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
     const double den = (double)a.cg_alpha * php;
     const float alpha = (float)rr / (float)den;
     a.scal[S_RR_OLD] = rr;
@@ -1302,6 +1356,64 @@ __global__ __launch_bounds__(kThreads) void k_cg_pdir(const bhg_chunk* __restric
       scal[S_RR_NEW] = rr_new;
       scal[S_BETA] = (double)beta;
     }
+  }
+}
+
+// Lazy direction (default of the fused CG solver): instead of k_cg_pdir's 12*N-byte pass, the coming iteration forms
+// p = r' + beta * p_old wherever it reads the direction (k_gemm<BF> loaders, the fused output epilogue, which also
+// writes it back).  This kernel is what remains of cg.py:51-53 between two iterations:
+//   rr' = sum partials, beta = rr' / rr (fp32 division of fp32-rounded dots, as the reference), and
+//   p.p of the coming direction = rr' + 2 beta r'.p_old + beta^2 p_old.p_old  (only used for the shift * p.p term of
+//   the step length; in exact CG r'.p_old = 0, so this is a sum of positives),
+// plus the direction update of the SMALL slices (biases, narrow head weights), which the head / reduce kernels read
+// directly.  A few blocks; every block recomputes the same scalars from the same partials in the same order.
+struct BetaArgs {
+  const double* part; int n, stride;     // [3][stride] partials of the previous iteration's epilogues (rr', r'.p, p.p)
+  double* scal;
+  const float* r; float* p;
+  int64_t off[BHG_MLP_MAX_LAYERS + 1]; int len[BHG_MLP_MAX_LAYERS + 1]; int nt;   // small slices (flat element offsets)
+};
+__global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
+  __shared__ double red[3][kWaves];
+  __shared__ float s_beta;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.n; i += kThreads) {
+    acc[0] += a.part[i];
+    acc[1] += a.part[a.stride + i];
+    acc[2] += a.part[2 * (int64_t)a.stride + i];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double v = wave_sum(acc[q]);
+    if (lane == 0) red[q][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWaves; ++i) t += red[q][i];
+      tot[q] = t;
+    }
+    const double rr_old = a.scal[S_RR_OLD];
+    const float beta = (float)tot[0] / (float)rr_old;
+    s_beta = beta;
+    if (blockIdx.x == 0) {
+      a.scal[S_RR_NEW] = tot[0];
+      a.scal[S_BETA] = (double)beta;
+      a.scal[S_PP] = tot[0] + 2.0 * (double)beta * tot[1] + (double)beta * (double)beta * tot[2];
+    }
+  }
+  __syncthreads();
+  const float beta = s_beta;
+  for (int t = 0; t < a.nt; ++t) {
+    const float* __restrict__ rs = a.r + a.off[t];
+    float* __restrict__ ps = a.p + a.off[t];
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.len[t]; i += gridDim.x * kThreads)
+      ps[i] = fz_add(rs[i], fz_mul(beta, ps[i]));
   }
 }
 
@@ -1376,8 +1488,8 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->partT1 = static_cast<double*>(take(sizeof(double) * m->Bp));
   w->partT2h = static_cast<double*>(take(sizeof(double) * m->Bp));
   w->partPP = static_cast<double*>(take(sizeof(double) * kMaxBlocks));
-  w->partRR[0] = static_cast<double*>(take(sizeof(double) * nrr));
-  w->partRR[1] = static_cast<double*>(take(sizeof(double) * nrr));
+  w->partRR[0] = static_cast<double*>(take(sizeof(double) * 3 * nrr));   // [3][nRR]: r'.r', r'.p, p.p per epilogue block
+  w->partRR[1] = static_cast<double*>(take(sizeof(double) * 3 * nrr));
   int nt2 = 0;
   for (int l = 1; l + 1 < m->L; ++l) { w->t2_off[l] = nt2; nt2 += reduce_blocks(m->Bp * m->dims[l], m->dims[l]); }
   w->nT2 = nt2;
@@ -1389,7 +1501,7 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
 struct ChainMode {
   int mode;                     // FUSE_NONE: store H*dir into out[] | FUSE_CG | FUSE_NEUMANN
   void* const* out;             // FUSE_NONE
-  float* fa; float* fb; const float* fd;   // fused: flat bases of FuseArgs a / b / d
+  float* fa; float* fb; float* fd;   // fused: flat bases of FuseArgs a / b / d
   const int64_t* starts;        // fused: element offsets of the 2L tensors inside the flat vectors
   float alpha, shift, out_scale;
   int apply_out;
@@ -1400,6 +1512,7 @@ struct ChainMode {
   double* partRR_new;
   double* scal;
   float cg_alpha;
+  int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -1432,11 +1545,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   FuseArgs fbase{};
   fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
   fbase.out_scale = cm.out_scale; fbase.apply_out = cm.apply_out;
+  fbase.part_stride = cg ? cm.ws->nRR : 0;
   auto fuse_at = [&](int tensor, int part_base) {
     FuseArgs f = fbase;
     if (cm.mode != FUSE_NONE) {
       const int64_t o = cm.starts[tensor];
       f.a = cm.fa + o; f.b = cm.fb + o; f.d = cm.fd + o;
+      // lazy direction: only the MFMA layers' weight slices (the small slices were updated by k_cg_beta)
+      f.lazy = cm.lazy && (tensor & 1) == 0 && !(head && tensor == 2 * (L - 1));
     }
     f.part_base = part_base;
     return f;
@@ -1465,6 +1581,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     GemmArgs a{};
     a.pr[0] = {m->h[l], V, K, K};                       // h_{l-1} V_l^T
+    if (cm.lazy) a.pr[0] = {m->h[l], cm.fa + cm.starts[2 * l], K, K, cm.fd + cm.starts[2 * l], 1};   // V_l = r_l + beta * p_l
+    a.scal = cm.scal;
     a.pairs = 1;
     if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
     a.M = Bp; a.N = N; a.K = K;
@@ -1586,6 +1704,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     if (head && l == L - 1) continue;  // Rd_{L-2} was produced by the fused k_head_forward
     GemmArgs a{};
     a.pr[0] = {m->delta[l], V, K, N};
+    if (cm.lazy) a.pr[0] = {m->delta[l], cm.fa + cm.starts[2 * l], K, N, cm.fd + cm.starts[2 * l], 1};
+    a.scal = cm.scal;
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
     a.pairs = 2;
     a.M = Bp; a.N = N; a.K = K;
@@ -1624,15 +1744,16 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
       hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     }
-    // one launch for all outputs when every MFMA layer is all-interior.  Tile order = dispatch order: two-pair tiles
-    // (twice the MFMA work) first, so the short one-pair tiles of layer 0 fill the tail
+    // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
     bool all_fast = !no_outer_all && n_mfma <= kOuterAllMax && head;
     size_t lds_max = 0;
     int order[BHG_MLP_MAX_LAYERS];
-    static const bool big_first = getenv("BHG_OUTER_ORDER_BY_SIZE") != nullptr;   // A/B: largest tile count first
-    auto weight = [&](int l) { return big_first ? (double)outer_blocks(m, l, head) : (l > 0 ? 2.0 : 1.0) * 1e9 + outer_blocks(m, l, head); };
+    // dispatch order = tile order: the layer with the most tiles first (measured 260 vs 256 steps/s against
+    // "two-pair tiles first"; BHG_OUTER_ORDER_BY_WORK selects the latter)
+    static const bool work_first = getenv("BHG_OUTER_ORDER_BY_WORK") != nullptr;
+    auto weight = [&](int l) { return !work_first ? (double)outer_blocks(m, l, head) : (l > 0 ? 2.0 : 1.0) * 1e9 + outer_blocks(m, l, head); };
     for (int i = 0; i < n_mfma; ++i) order[i] = i;
     for (int i = 1; i < n_mfma; ++i)   // insertion sort, descending
       for (int j = i; j > 0 && weight(order[j]) > weight(order[j - 1]); --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
@@ -1770,26 +1891,50 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   const void* dir[2 * BHG_MLP_MAX_LAYERS];
   for (int i = 0; i < 2 * m->L; ++i) dir[i] = p + starts[i];
   const int pgrid = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
+  // Direction update between two iterations: lazy (default; see k_cg_beta) or the 12*N-byte k_cg_pdir pass (A/B switch)
+  static const bool eager = getenv("BHG_CG_EAGER_P") != nullptr;
+  const bool lazy = !eager;
+  BetaArgs ba{};
+  int small_total = 0;
+  {
+    const bool head = use_head(m);
+    ba.stride = w.nRR; ba.n = w.nRR; ba.scal = scal; ba.r = r; ba.p = p;
+    for (int l = 0; l < m->L; ++l) {   // biases
+      ba.off[ba.nt] = starts[2 * l + 1]; ba.len[ba.nt] = m->dims[l + 1]; small_total += ba.len[ba.nt]; ++ba.nt;
+    }
+    if (head) {                        // narrow head weight
+      ba.off[ba.nt] = starts[2 * (m->L - 1)]; ba.len[ba.nt] = m->dims[m->L] * m->dims[m->L - 1]; small_total += ba.len[ba.nt]; ++ba.nt;
+    }
+  }
+  int bgrid = (small_total + 8 * kThreads - 1) / (8 * kThreads);
+  if (bgrid < 1) bgrid = 1;
+  if (bgrid > 64) bgrid = 64;
   for (int k = 0; k < K; ++k) {
     hipEvent_t ta, tb, tc, td;
     const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
     const bool timed_it = span_begin(BHG_TIMING_MLP_CG_ITER, &tc, &td);
-    if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
+    if (lazy && k > 0) {   // beta, p.p of the coming direction, direction update of the small slices
+      ba.part = w.partRR[k & 1];
+      hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);
+    }
+    if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     ChainMode cm{};
     cm.mode = FUSE_CG;
     cm.fa = r; cm.fb = x; cm.fd = p; cm.starts = starts;
     cm.shift = hvp_shift; cm.cg_alpha = cg_alpha;
     cm.apply_out = k == K - 1; cm.out_scale = -cg_alpha;   // cg.py:56 and the negation of cg.py:59/68
     cm.ws = &w; cm.scal = scal;
-    cm.partRR_old = partR0;            // k > 0: r.r was summed by the previous k_cg_pdir (scal[S_RR_NEW])
+    cm.partRR_old = partR0;            // k > 0: r.r is the scalar scal[S_RR_NEW] (k_cg_beta / k_cg_pdir of the last iteration)
     cm.nRR_old = k == 0 ? n_init : 0;
     cm.partPP = k == 0 ? partR0 : w.partPP;   // p = r after the init, so p.p = r.r
-    cm.nPP = k == 0 ? n_init : pgrid;
+    cm.nPP = k == 0 ? n_init : (lazy ? 0 : pgrid);
     cm.partRR_new = w.partRR[(k + 1) & 1];
+    // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
+    cm.lazy = lazy;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
-    if (k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
+    if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
       hipLaunchKernelGGL(k_cg_pdir, dim3(pgrid), dim3(kThreads), 0, st, chunks_dev, n_chunks, (const float*)r, p,
                          (const double*)w.partRR[(k + 1) & 1], w.nRR, w.partPP, scal);
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(td, st));

@@ -16,11 +16,12 @@ except Exception as e:
 PY
 }
 run cg_fused --algo cg
-BHG_OUTER_ORDER_BY_SIZE=1 run cg_fused_bysize --algo cg
+BHG_CG_EAGER_P=1 run cg_fused_eager --algo cg
+BHG_OUTER_ORDER_BY_WORK=1 run cg_fused_bywork --algo cg
 run cg_nofuse --algo cg --no-fuse
 run neumann_fused --algo neumann --cg-iters 10
-BHG_NEUMANN_SIDE=1 run neumann_fused_side --algo neumann --cg-iters 10
-run neumann_nofuse --algo neumann --cg-iters 10 --no-fuse
+
+
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_f -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused > /tmp/tr_f.log 2>&1; echo "trace rc=$?"
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr_f/*kernel_trace.csv 2>/dev/null | head -1)
