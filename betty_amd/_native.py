@@ -114,6 +114,7 @@ SYMBOLS = {
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_float, c_float, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
+    "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_neumann_solve": (
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, c_void_p],

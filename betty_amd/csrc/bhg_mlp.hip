@@ -878,7 +878,8 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       float* __restrict__ aux, const float* __restrict__ delta_top,
                                                       const float* __restrict__ mask_prev,
                                                       float* __restrict__ rd_prev, HeadFuse fz,
-                                                      double* __restrict__ partT1, double* __restrict__ partT2h) {
+                                                      double* __restrict__ partT1, double* __restrict__ partT2h,
+                                                      float* __restrict__ rz_out) {
   extern __shared__ __attribute__((aligned(16))) float srow[];   // FUSED: the row of Rh_{L-2}, K floats
   // partT1 / partT2h != NULL (HEAD_JVP, fused CG solver): this sample row's share of p.Hp (see k_cg_alpha):
   //   partT1[b]  = sum_c Rz[b][c] * Rd_L[b][c]                          (the Gauss-Newton part)
@@ -967,6 +968,7 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   __syncthreads();
   if (mode == HEAD_JVP) {
     float p = 0.f, sdv = 0.f, dt = 0.f;
+    if (rz_out && t < C) rz_out[(int64_t)b * C + t] = rz[t];   // Rz_b(direction): accumulated into Rz(x) by k_cg_alpha
     if (t < C) {
       p = prob[(int64_t)b * C + t];
       sdv = sd[b];
@@ -1050,14 +1052,14 @@ void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float*
                          const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
                          const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
                          float* rd_prev, const HeadFuse* fuse = nullptr, double* partT1 = nullptr,
-                         double* partT2h = nullptr) {
+                         double* partT2h = nullptr, float* rz_out = nullptr) {
   // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
   HeadFuse fz{};
   if (fuse) fz = *fuse;
   const size_t lds = fuse ? (size_t)K * sizeof(float) : 0;
 #define BHG_HEAD(RH, J, F)                                                                                              \
   hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
-                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h)
+                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out)
   if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
   else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
   else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
@@ -1281,9 +1283,13 @@ struct AlphaArgs {
   const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
   float cg_alpha, shift;
   double* scal;
+  // Rz(x) = sum_k alpha_k Rz(p_k): x is a linear combination of the directions and the head kernel computes Rz of
+  // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
+  const float* rz; double* rzx; int nrz; int first;
 };
 __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
   __shared__ double red[5][kWaves];
+  __shared__ float s_alpha;
   // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
   // one wave reduction per quantity and a fixed-order combine of the wave results
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1316,7 +1322,30 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
     a.scal[S_RR_OLD] = rr;
     a.scal[S_PHP] = den;
     a.scal[S_ALPHA] = (double)alpha;
+    s_alpha = alpha;
   }
+  __syncthreads();
+  const double al = (double)s_alpha;
+  for (int i = threadIdx.x; i < a.nrz; i += kThreads) {
+    const double v = al * (double)a.rz[i];
+    a.rzx[i] = a.first ? v : a.rzx[i] + v;
+  }
+}
+
+// coeff[b] = scale * (prob_b - onehot(y_b)) . RzX_b / B   (mixed-derivative coefficient from the accumulated Rz(x))
+__global__ __launch_bounds__(kThreads) void k_coeff_from_rzx(const double* __restrict__ rzx, const float* __restrict__ prob,
+                                                             const int64_t* __restrict__ labels, float* __restrict__ coeff,
+                                                             int rows, int C, int B, float scale) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= rows) return;
+  float out = 0.f;
+  if (b < B) {
+    const int y = (int)labels[b];
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) acc += ((double)prob[(int64_t)b * C + c] - (c == y ? 1.0 : 0.0)) * rzx[(int64_t)b * C + c];
+    out = (float)((double)scale * acc / (double)B);
+  }
+  coeff[b] = out;
 }
 
 // cg.py:52-53 after the fused outputs: beta = r'.r' / r.r ; p <- r' + beta * p ; partial p'.p' (next iteration's
@@ -1473,6 +1502,7 @@ int reduce_blocks(int slab, int N) {
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
+  float* rz; double* rzx;           // [Bp][dims[L]]: Rz of the current direction / accumulated Rz(x)
   int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
   size_t bytes;
@@ -1494,6 +1524,8 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   for (int l = 1; l + 1 < m->L; ++l) { w->t2_off[l] = nt2; nt2 += reduce_blocks(m->Bp * m->dims[l], m->dims[l]); }
   w->nT2 = nt2;
   w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
+  w->rz = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * m->dims[m->L]));
+  w->rzx = static_cast<double*>(take(sizeof(double) * (size_t)m->Bp * m->dims[m->L]));
   w->bytes = off;
 }
 
@@ -1512,6 +1544,7 @@ struct ChainMode {
   double* partRR_new;
   double* scal;
   float cg_alpha;
+  int first;                    // first iteration of a solve (Rz(x) accumulator is set, not added to)
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
 };
 
@@ -1576,7 +1609,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, m->sd,
                           m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
                           l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
-                          fuse_head ? &head_fuse : nullptr, cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr);
+                          fuse_head ? &head_fuse : nullptr, cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr,
+                          cg ? cm.ws->rz : nullptr);
       continue;
     }
     GemmArgs a{};
@@ -1742,6 +1776,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       aa.partPP = cm.partPP; aa.nPP = cm.nPP;
       aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
       aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
+      aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first;
       hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     }
     // one launch for all outputs when every MFMA layer is all-interior
@@ -1932,6 +1967,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.partRR_new = w.partRR[(k + 1) & 1];
     // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
     cm.lazy = lazy;
+    cm.first = k == 0;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
     if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
@@ -1965,6 +2001,20 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   }
+  return BHG_OK;
+}
+
+int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff, float cg_alpha, void* fws,
+                           size_t fws_bytes, void* stream) {
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(labels && coeff && fws, "NULL argument");
+  BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  // x_final = -cg_alpha * sum_k alpha_k p_k  (cg.py:56 and the negation of 59/68)  =>  Rz(x_final) = -cg_alpha * RzX
+  hipLaunchKernelGGL(k_coeff_from_rzx, dim3((m->Bp + kThreads - 1) / kThreads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     (const double*)w.rzx, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -cg_alpha);
+  BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
 

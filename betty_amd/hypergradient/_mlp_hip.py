@@ -168,6 +168,7 @@ class HipMLPState:
         # CG / Neumann pass the SAME view tensors every iteration (views of the persistent flat direction):
         # validate and build the pointer table once per distinct tensor set (the cache holds the tensors, so
         # their ids cannot be recycled while it is alive).
+        self._rzx = None   # a hand-driven HVP invalidates the accumulated Rz(x) of an earlier fused solve
         key = tuple(map(id, direction_views))
         cached = getattr(self, "_dir_cache", None)
         if cached is None or cached[0] != key:
@@ -207,6 +208,8 @@ class HipMLPState:
                                       layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
             "bhg_mlp_cg_solve",
         )
+        # the solver accumulated Rz(x) on its way: mixed_coeff() of exactly this solution needs no R-forward pass
+        self._rzx = (float(cg_alpha), x.data_ptr(), layout)
 
     def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float) -> None:
         """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'."""
@@ -220,6 +223,15 @@ class HipMLPState:
     def mixed_coeff(self, dir_views):
         """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step."""
         buf, B = self.buf, self.B
+        rzx = getattr(self, "_rzx", None)
+        if rzx is not None and len(dir_views) > 0 and dir_views[0].data_ptr() == rzx[1] + 4 * rzx[2].starts[0]:
+            # `dir_views` are the views of the flat solution the fused CG solver just produced
+            _native.check(
+                self.lib.bhg_mlp_cg_mixed_coeff(ctypes.byref(self.desc), buf.labels.data_ptr(), buf.coeff.data_ptr(), rzx[0],
+                                                buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                "bhg_mlp_cg_mixed_coeff",
+            )
+            return buf.coeff[:B].clone()
         if buf.native_prepare:
             tab, _keep = self._dir_table(dir_views)
             _native.check(

@@ -238,6 +238,11 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
                      void* fws, size_t fws_bytes, void* stream);
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K,
                           float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* stream);
+/* Mixed-derivative coefficient (see bhg_mlp_mixed_coeff) of the solution of the LAST bhg_mlp_cg_solve on `fws`,
+ * without another R-forward pass: x is a linear combination of the CG directions, and the solver accumulated
+ * Rz(x) = sum_k alpha_k Rz(p_k) from the Rz every iteration's head kernel computes anyway.                          */
+int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff, float cg_alpha, void* fws,
+                           size_t fws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

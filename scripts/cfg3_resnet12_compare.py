@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""BASELINE cfg 3 shape (ResNet-12 inner, 8.0 M parameters in 50 tensors, prox to the upper copy, CG K=20) with
+"""BASELINE cfg 3 shape (ResNet12(5, 32)-shaped inner, 10.43 M parameters in 122 tensors, 84 x 84 support images, prox to the upper copy, CG K=20) with
 an OPAQUE inner loss (autograd double backward): the fused recurrence of this package vs the reference's
 per-tensor recurrence (oracle restatement) on the same GPU.  Prints hypergradient steps/s of both."""
 import os, sys, time, torch
@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(77); torch.manual_seed(77)
 inner, upper = zoo.ResNet12().to(dev), zoo.ResNet12().to(dev)
 for p, q in zip(inner.parameters(), upper.parameters()):
     q.data.copy_(p.data + 0.05 * torch.randn(p.shape, generator=g).to(dev))
-x = torch.randn(25, 3, 32, 32, generator=g).to(dev); y = torch.arange(5).repeat_interleave(5).to(dev)
+x = torch.randn(25, 3, 84, 84, generator=g).to(dev); y = torch.arange(5).repeat_interleave(5).to(dev)
 vector = [0.01 * torch.randn(p.shape, generator=g).to(dev) for p in inner.parameters()]
 prev = zoo.StubProblem("upper", upper, config=Config())
 curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=20), loss_fn=zoo.make_imaml_loss(prev, 0.5), batch=(x, y))

@@ -25,4 +25,5 @@ run neumann_fused --algo neumann --cg-iters 10
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_f -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused > /tmp/tr_f.log 2>&1; echo "trace rc=$?"
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr_f/*kernel_trace.csv 2>/dev/null | head -1)
-if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_cg_pdir | tee gpurun_out/timeline_fused.txt; python scripts/print_step_outside.py $f | tee gpurun_out/outside_fused.txt; else tail -5 /tmp/tr_f.log; fi
+if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_cg_beta | tee gpurun_out/timeline_fused.txt; python scripts/print_step_outside.py $f | tee gpurun_out/outside_fused.txt; else tail -5 /tmp/tr_f.log; fi
+bash scripts/gpu_pmc2.sh 2>&1 | tail -60

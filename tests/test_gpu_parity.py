@@ -802,7 +802,7 @@ def _resnet12_case(cfg):
     inner, upper = zoo.ResNet12().to(DEV), zoo.ResNet12().to(DEV)
     for p, q in zip(inner.parameters(), upper.parameters()):
         q.data.copy_(p.data + 0.05 * torch.randn(p.shape, generator=g).to(DEV))
-    x = torch.randn(25, 3, 32, 32, generator=g).to(DEV)          # 5-way 5-shot, synthetic
+    x = torch.randn(25, 3, 84, 84, generator=g).to(DEV)          # 5-way 5-shot support set at the example's 84 x 84
     y = torch.arange(5).repeat_interleave(5).to(DEV)
     vector = [0.01 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
     prev = zoo.StubProblem("upper", upper, config=Config())
@@ -811,12 +811,14 @@ def _resnet12_case(cfg):
 
 
 @pytest.mark.parametrize("variant", ["resident", "stream"])
-def test_cfg3_resnet12_full_size_cg20(variant, be):
+def test_cfg3_resnet12_cg20(variant, be):
+    """BASELINE cfg 3 at the example's own shape: ResNet12(5, 32) = 10,430,533 parameters in 122 tensors, 25 support
+    images of 84 x 84, proximal term to the upper copy, CG K = 20 (examples/implicit_maml/main.py:87-92,122-129)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hypergrad_oracle as horc
 
     curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
-    assert len(vector) == 50 and sum(v.numel() for v in vector) == 7_999_365
+    assert len(vector) == 122 and sum(v.numel() for v in vector) == 10_430_533
     want = horc.cg(vector, curr, prev, False)
     again = horc.cg(vector, curr, prev, False)      # the checker's own run-to-run spread (MIOpen atomics)
     noise, _ = rel_err(_np(again), _np(want))
@@ -896,11 +898,13 @@ def test_cfg5_supernet_neumann20(be):
 
     g = torch.Generator().manual_seed(55)
     torch.manual_seed(55)
-    inner, upper = zoo.Supernet().to(DEV), zoo.ArchParams().to(DEV)
-    x = torch.randn(16, 3, 16, 16, generator=g).to(DEV)
-    y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+    # the example's scale (Network(16, 10, 8): 1,399 tensors, CIFAR batch 64 x 3 x 32 x 32,
+    # examples/neural_architecture_search/model_search.py:129-234): width 16, 10 cells -> 1,545 tensors, batch 64
+    inner, upper = zoo.Supernet(c=16, cells=10).to(DEV), zoo.ArchParams(cells=10).to(DEV)
+    x = torch.randn(64, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (64,), generator=g).to(DEV)
     vector = [1e-2 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
-    assert len(vector) == 621
+    assert len(vector) == 1545
     prev = zoo.StubProblem("upper", upper, config=Config())
     curr = zoo.StubProblem("inner", inner, config=Config(type="neumann", neumann_iterations=20, neumann_alpha=0.1),
                            loss_fn=zoo.make_supernet_loss(prev, 0.1), batch=(x, y))
@@ -925,8 +929,7 @@ def test_cfg2_metric_workload_end_to_end(algo, K, be):
     algorithm in fp32 on the device (oracle restatement on ATen), and the product path.  Twenty fp32 CG iterations
     on this 10 M-parameter problem sit ~9e-5 from the truth whoever runs them, and ATen's double backward is not
     reproducible between calls of one process (the reference-fp32 run measured 7e-5 ... 2.7e-4 from the truth),
-    so the product is held to the truth, not to one draw of the reference: within rtol 1e-4 (north_star) or no
-    more than twice as far from it as the reference's own fp32 run."""
+    so the product is held to the truth, not to one draw of the reference: within rtol 1e-4 (north_star), full stop."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hypergrad_oracle as horc
 
@@ -948,5 +951,6 @@ def test_cfg2_metric_workload_end_to_end(algo, K, be):
     e_got, _ = rel_err(_np(got), _np(truth))
     rel, _ = rel_err(_np(got), _np(want))
     print(f"cfg2 full size {algo} K={K}: vs fp64 truth: reference-fp32 {e_ref:.2e}, hip {e_got:.2e}; hip vs reference-fp32 {rel:.2e}")
-    assert e_got <= max(1e-4, 2.0 * e_ref), (algo, e_got, e_ref)
-    assert rel <= max(1e-4, 2.0 * (e_ref + e_got)), (algo, rel, e_ref, e_got)
+    assert e_got <= 1e-4, (algo, e_got, e_ref)   # north_star's tolerance against the fp64 truth, no escape hatch
+    # against ONE fp32 draw of the reference's algorithm the bar is the sum of both distances to the truth
+    assert rel <= 1e-4 + e_ref, (algo, rel, e_ref, e_got)

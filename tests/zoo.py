@@ -124,16 +124,19 @@ class SmallConv(nn.Module):
         return self.fc(x.flatten(1))
 
 
-class _Res12Block(nn.Module):
-    """Three 3x3 conv + BN (batch statistics) + LeakyReLU with a 1x1 projection shortcut, then 2x2 max-pool."""
+class _Res12Unit(nn.Module):
+    """Three 3x3 conv + BN (batch statistics) + LeakyReLU; the first unit of a stage widens (1x1 projection + BN on
+    the shortcut) and halves the resolution with a 2x2 max-pool."""
 
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, first):
         super().__init__()
         chans = [cin, cout, cout, cout]
         self.convs = nn.ModuleList([nn.Conv2d(a, b, 3, padding=1, bias=False) for a, b in zip(chans[:-1], chans[1:])])
         self.norms = nn.ModuleList([nn.BatchNorm2d(cout, track_running_stats=False) for _ in range(3)])
-        self.proj = nn.Conv2d(cin, cout, 1, bias=False)
-        self.proj_norm = nn.BatchNorm2d(cout, track_running_stats=False)
+        self.first = first
+        if first:
+            self.proj = nn.Conv2d(cin, cout, 1, bias=False)
+            self.proj_norm = nn.BatchNorm2d(cout, track_running_stats=False)
 
     def forward(self, x):
         y = x
@@ -141,23 +144,33 @@ class _Res12Block(nn.Module):
             y = norm(conv(y))
             if i < 2:
                 y = F.leaky_relu(y, 0.1)
-        return F.max_pool2d(F.leaky_relu(y + self.proj_norm(self.proj(x)), 0.1), 2)
+        short = self.proj_norm(self.proj(x)) if self.first else x
+        y = F.leaky_relu(y + short, 0.1)
+        return F.max_pool2d(y, 2) if self.first else y
 
 
 class ResNet12(nn.Module):
-    """The few-shot ResNet-12 shape of BASELINE.json cfg 3 (4 residual blocks of 3 convs; widths
-    64-128-256-512 = 8.0 M parameters in 50 tensors) — full-size GPU parity only, no golden file."""
+    """The few-shot ResNet-12 of BASELINE.json cfg 3 at the example's own size, ``ResNet12(ways, 32)`` of
+    examples/implicit_maml/models.py:411-483: 4 stages x 3 units x 3 convs, widths 32-80-160-320 ("wider"), a 1x1
+    projection per stage, 5x5 average pool, linear classifier = 10,430,533 parameters in 122 tensors, for 84 x 84
+    inputs — full-size GPU parity only, no golden file.  (Own restatement of the shape; dropout / DropBlock are off in
+    the example's configuration and omitted.)"""
 
-    def __init__(self, ways=5, widths=(64, 128, 256, 512)):
+    def __init__(self, ways=5, hidden=32):
         super().__init__()
-        chans = [3] + list(widths)
-        self.blocks = nn.ModuleList([_Res12Block(a, b) for a, b in zip(chans[:-1], chans[1:])])
+        widths = [hidden, int(hidden * 2.5), hidden * 5, hidden * 10]
+        units, cin = [], 3
+        for c in widths:
+            for u in range(3):
+                units.append(_Res12Unit(cin if u == 0 else c, c, first=(u == 0)))
+            cin = c
+        self.units = nn.ModuleList(units)
         self.fc = nn.Linear(widths[-1], ways)
 
     def forward(self, x):
-        for blk in self.blocks:
-            x = blk(x)
-        return self.fc(x.mean(dim=(2, 3)))
+        for unit in self.units:
+            x = unit(x)
+        return self.fc(F.adaptive_avg_pool2d(x, 1).flatten(1))
 
 
 class TokenClassifier(nn.Module):
