@@ -108,11 +108,11 @@ def make_loss(upper):
     return loss
 
 
-def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg"):
+def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg", data_seed=None):
     torch.manual_seed(seed)
     inner = InnerMLP().to(device=device, dtype=dtype)
     mwn = MWN(100).to(device=device, dtype=dtype)
-    g = torch.Generator().manual_seed(1234 + seed)
+    g = torch.Generator().manual_seed(1234 + (seed if data_seed is None else data_seed))
     x = torch.randn(BATCH, SIZES[0], generator=g).to(device=device, dtype=dtype)
     y = torch.randint(0, 10, (BATCH,), generator=g)
     flip = torch.rand(BATCH, generator=g) < 0.4
@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=20, help="K: CG / Neumann iterations")
     ap.add_argument("--algo", choices=["cg", "neumann", "darts"], default="cg",
                     help="cg = the BASELINE metric; neumann / darts = secondary lines (BASELINE cfg 2 uses neumann K=10)")
+    ap.add_argument("--mode", choices=["replica", "global"], default="replica",
+                    help="replica = the reference's DDP mode (every rank solves its own problem; default).  global = ONE inner "
+                    "problem whose batch is spread over the ranks: data-parallel HVP, sharded CG state (betty_amd/global_hvp.py)")
     ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
     ap.add_argument("--hvp", choices=["analytic", "analytic-aten", "autograd"], default="analytic",
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
@@ -253,8 +256,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "global":
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -269,8 +276,14 @@ def main():
     be = get_backend()
     be.cg_variant = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}[args.variant]
     K = args.cg_iters
-    curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
-    jvp_fn = hg.jvp_fn_mapping[args.algo]
+    if args.mode == "global":
+        assert args.algo == "cg", "--mode global is the sharded CG solve"
+        # the same inner / upper weights on every rank, a different batch per rank
+        curr, prev, vector = build(device, seed=0, ddp=world > 1, K=K, algo="cg", data_seed=rank)
+        jvp_fn = hg.jvp_fn_mapping["cg_global"]
+    else:
+        curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
+        jvp_fn = hg.jvp_fn_mapping[args.algo]
     if args.hvp == "analytic":
         declare_structure(curr, "hip", fused=not args.no_fuse)
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
@@ -278,7 +291,7 @@ def main():
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
     layout = be.layout(vector)
-    fused = args.hvp == "analytic" and not args.no_fuse and args.algo in ("cg", "neumann")
+    fused = args.hvp == "analytic" and not args.no_fuse and args.algo in ("cg", "neumann") and args.mode == "replica"
     # the predicate bhg_cg_step itself uses (capacity AND the residency census)
     resident = (not fused) and (args.variant == "resident" or (
         args.variant == "auto" and layout.n_chunks <= be.lib.bhg_cg_resident_capacity_chunks() and bool(be.lib.bhg_cg_resident_ok())))
@@ -343,7 +356,9 @@ def main():
         raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
     out = None
     if rank == 0:
-        value = world * args.steps / elapsed
+        # replica mode: every rank completes `steps` independent hypergradient steps; global mode: the ranks share ONE
+        # problem (global batch = world x local batch) and complete `steps` steps together
+        value = (world if args.mode == "replica" else 1) * args.steps / elapsed
         # CG iteration 28*N B (read Hp,p,r,x; write x,r,p), Neumann iteration 20*N B; analytic HVP:
         # >= 20*N B of weight traffic (read W, V twice, write the HVP once) — with the fused solver the HVP output is
         # not written and the recurrence does not read it, but the algorithmic figure is kept (it is the yardstick).
@@ -420,13 +435,14 @@ def main():
                         "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp) + recurrence kernel" if args.hvp == "analytic" else
                         "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else "pytorch-rocm autograd double backward"),
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
-                "parallelism": "replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU",
+                "parallelism": ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world)
+                if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,
                 "lib_sha256": lib_sha256()[:16],
             },
             "roofline": roof,
             "hvp_roofline": hvp_roof,
-            "value_with_kernel_timing": (world * args.steps / elapsed_timed) if elapsed_timed else None,
+            "value_with_kernel_timing": ((world if args.mode == "replica" else 1) * args.steps / elapsed_timed) if elapsed_timed else None,
             "per_iteration_us": per_iter_us,
             "outside_k_loop_ms": (1e3 * elapsed_timed / args.steps - K_eff * per_iter_us * 1e-3) if per_iter_us and elapsed_timed else None,
             "cpu_baseline": None,

@@ -19,6 +19,6 @@ def install(betty_hypergradient=None):
 
     if betty_hypergradient is None:
         import betty.hypergradient as betty_hypergradient  # noqa: PLC0415
-    for key in ("cg", "neumann", "darts", "sama"):
+    for key in ("cg", "neumann", "darts", "sama", "cg_global"):   # cg_global: extension key (global-HVP mode)
         betty_hypergradient.jvp_fn_mapping[key] = hg.jvp_fn_mapping[key]
     return betty_hypergradient.jvp_fn_mapping

@@ -82,6 +82,12 @@ SYMBOLS = {
         c_int,
         [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_int, c_void_p, c_void_p],
     ),
+    "bhg_cg_phase": (
+        c_int,
+        [c_int, _PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p, c_void_p],
+    ),
+    "bhg_cg_partials_dev": (c_void_p, [c_void_p, c_int, c_int]),
+    "bhg_cg_partials_count": (c_int, []),
     "bhg_cg_resident_capacity_chunks": (c_int, []),
     "bhg_cg_resident_ok": (c_int, []),
     "bhg_cg_scalars_dev": (c_void_p, [c_void_p]),

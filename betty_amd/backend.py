@@ -163,6 +163,25 @@ class HipBackend:
             "bhg_cg_step",
         )
 
+    # -- phased CG for sharded state (betty_amd/global_hvp.py) ----------------------------------------------------
+    def cg_phase(self, phase: int, layout, hvp, x, r, p, cg_alpha: float, it: int, out_scale: float = 0.0,
+                 hvp_shift: float = 0.0) -> None:
+        tab, _keep = self._cached_table(hvp, layout)
+        _native.check(
+            self.lib.bhg_cg_phase(int(phase), tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
+                                  r.data_ptr(), p.data_ptr(), cg_alpha, it, out_scale, hvp_shift,
+                                  layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_cg_phase",
+        )
+
+    def cg_partials(self, layout, which: int, it: int) -> torch.Tensor:
+        """The per-block partial sums (float64 view into the layout's workspace) a caller with sharded state must
+        all-reduce(SUM) after bhg_cg_init (which=2), phase 0 (which=0) and phase 1 (which=1)."""
+        ws = layout.workspace
+        off = int(self.lib.bhg_cg_partials_dev(ws.data_ptr(), int(which), int(it))) - ws.data_ptr()
+        n = int(self.lib.bhg_cg_partials_count())
+        return ws[off:off + 8 * n].view(torch.float64)
+
     def after_cg(self, layout) -> None:
         """Health check of the resident kernel's grid barrier WITHOUT stalling the host: the time-out word of the
         solve that was just enqueued is copied to pinned memory behind it, and the copies of EARLIER solves that

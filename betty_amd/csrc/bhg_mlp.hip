@@ -1292,6 +1292,16 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
   __shared__ float s_alpha;
   // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
   // one wave reduction per quantity and a fixed-order combine of the wave results
+  // the Rz(x) accumulation's operands do not depend on alpha: their loads go out first
+  constexpr int kRzPer = 8;
+  float rzv[kRzPer];
+  double rzxv[kRzPer];
+#pragma unroll
+  for (int u = 0; u < kRzPer; ++u) {
+    const int i = threadIdx.x + u * kThreads;
+    rzv[u] = i < a.nrz ? a.rz[i] : 0.f;
+    rzxv[u] = (i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
+  }
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
   if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
@@ -1326,7 +1336,12 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
   }
   __syncthreads();
   const double al = (double)s_alpha;
-  for (int i = threadIdx.x; i < a.nrz; i += kThreads) {
+#pragma unroll
+  for (int u = 0; u < kRzPer; ++u) {
+    const int i = threadIdx.x + u * kThreads;
+    if (i < a.nrz) a.rzx[i] = rzxv[u] + al * (double)rzv[u];
+  }
+  for (int i = threadIdx.x + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
     const double v = al * (double)a.rz[i];
     a.rzx[i] = a.first ? v : a.rzx[i] + v;
   }
@@ -1405,6 +1420,18 @@ struct BetaArgs {
 __global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
   __shared__ double red[3][kWaves];
   __shared__ float s_beta;
+  // this thread's element of the small slices: its loads are issued BEFORE the partial sums are reduced (independent)
+  const int gi = blockIdx.x * kThreads + threadIdx.x;
+  int64_t eoff = -1;
+  {
+    int base = 0;
+    for (int t = 0; t < a.nt; ++t) {
+      if (eoff < 0 && gi < base + a.len[t]) eoff = a.off[t] + (gi - base);
+      base += a.len[t];
+    }
+  }
+  float rv = 0.f, pv = 0.f;
+  if (eoff >= 0) { rv = a.r[eoff]; pv = a.p[eoff]; }
   double acc[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < a.n; i += kThreads) {
     acc[0] += a.part[i];
@@ -1437,13 +1464,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
     }
   }
   __syncthreads();
-  const float beta = s_beta;
-  for (int t = 0; t < a.nt; ++t) {
-    const float* __restrict__ rs = a.r + a.off[t];
-    float* __restrict__ ps = a.p + a.off[t];
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.len[t]; i += gridDim.x * kThreads)
-      ps[i] = fz_add(rs[i], fz_mul(beta, ps[i]));
-  }
+  if (eoff >= 0) a.p[eoff] = fz_add(rv, fz_mul(s_beta, pv));
 }
 
 // ---- per-device side stream + events -------------------------------------------------------------------------------
@@ -1941,9 +1962,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
       ba.off[ba.nt] = starts[2 * (m->L - 1)]; ba.len[ba.nt] = m->dims[m->L] * m->dims[m->L - 1]; small_total += ba.len[ba.nt]; ++ba.nt;
     }
   }
-  int bgrid = (small_total + 8 * kThreads - 1) / (8 * kThreads);
-  if (bgrid < 1) bgrid = 1;
-  if (bgrid > 64) bgrid = 64;
+  const int bgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;   // one element of the small slices per thread
   for (int k = 0; k < K; ++k) {
     hipEvent_t ta, tb, tc, td;
     const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);

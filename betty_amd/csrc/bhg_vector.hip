@@ -929,6 +929,58 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   return BHG_OK;
 }
 
+// ---- phased streaming CG iteration: the same three kernels as BHG_CG_STREAM, one call per phase, so that a caller
+// whose state vectors are SHARDED over ranks (global-HVP mode, betty_amd/global_hvp.py) can all-reduce(SUM) the
+// per-block partials between the phases: the consumer kernels then sum the all-reduced partials = the global dots,
+// identically on every rank.  All ranks must use equally sized shards (same chunk count => same partial count).
+//   phase 0: partP  <- partials of (cg_alpha*Hp).p            -> all-reduce bhg_cg_partials_dev(ws, 0, iter)
+//   phase 1: alpha, r' = r - alpha*Hp, partR <- partials r'.r' -> all-reduce bhg_cg_partials_dev(ws, 1, iter)
+//   phase 2: beta, x += alpha*p, p = r' + beta*p
+// After bhg_cg_init the r.r partials are bhg_cg_partials_dev(ws, 2, 0) (all-reduce them as well).
+int bhg_cg_phase(int phase, const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
+                 float* p, float cg_alpha, int iter, float out_scale, float hvp_shift, void* ws, void* stream) {
+  BHG_COMMON_CHECKS(hvp);
+  BHG_REQUIRE(ws, "workspace is NULL");
+  BHG_REQUIRE(iter >= 0 && phase >= 0 && phase <= 2, "bad phase / iteration index");
+  if (n_chunks == 0) return BHG_OK;
+  BHG_REQUIRE(x && r && p, "state vector is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* w = static_cast<char*>(ws);
+  double* scal = reinterpret_cast<double*>(w + kWsScal);
+  double* partP = reinterpret_cast<double*>(w + kWsPartP);
+  double* partR = reinterpret_cast<double*>(w + kWsPartR);
+  double* partR_old = partR + (size_t)(iter & 1) * kMaxBlocks;
+  double* partR_new = partR + (size_t)((iter + 1) & 1) * kMaxBlocks;
+  const int n_stream = grid_for(n_chunks);
+  if (phase == 2) {
+    hipLaunchKernelGGL(k_cg_dir, dim3(n_stream), dim3(kThreads), 0, st, chunks_dev, n_chunks, x, (const float*)r, p,
+                       (const double*)partR_new, n_stream, out_scale, scal, reinterpret_cast<unsigned*>(w + kWsBarrier),
+                       2u * (unsigned)num_cus());
+    BHG_HIP_CHECK(hipGetLastError());
+    return BHG_OK;
+  }
+  PtrTab tab;
+  if (int rc = make_table(&tab, hvp, T, ws, 0, st)) return rc;
+  if (phase == 0)
+    hipLaunchKernelGGL(k_cg_dot, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, (const float*)p, cg_alpha,
+                       hvp_shift, partP);
+  else
+    hipLaunchKernelGGL(k_cg_resid, dim3(n_stream), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, r, (const float*)p,
+                       hvp_shift, (const double*)partP, (const double*)partR_old, partR_new, n_stream, iter, scal);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+double* bhg_cg_partials_dev(void* ws, int which, int iter) {
+  char* w = static_cast<char*>(ws);
+  if (which == 0) return reinterpret_cast<double*>(w + kWsPartP);
+  double* partR = reinterpret_cast<double*>(w + kWsPartR);
+  if (which == 1) return partR + (size_t)((iter + 1) & 1) * kMaxBlocks;
+  return partR;   // which == 2: the r.r partials bhg_cg_init wrote (consumed by iteration 0)
+}
+
+int bhg_cg_partials_count(void) { return kMaxBlocks; }
+
 int bhg_darts_eps(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, double R,
                   double* out_dev, float* eps_f32_dev, void* ws, void* stream) {
   BHG_COMMON_CHECKS(vec);

@@ -24,6 +24,11 @@ class EngineConfig:
     strategy: str = "default"  # "default" | "distributed" (DDP over RCCL; one process per GPU)
     backend: str = "nccl"
     roll_back: bool = False  # warm-start roll-back (engine_dataclass.py; problem.py:417-436)
+    # strategy "distributed" only (extension, not in the reference): an upper problem with at least this many
+    # parameters exchanges its hypergradient as ONE flat asynchronous all-reduce per path (betty_amd.distributed) —
+    # the exchange of path i runs on the communication stream while the CG solve of path i+1 runs — instead of
+    # through the DDP reducer's 25 MB buckets; its module is then NOT DDP-wrapped.  0 = always use DDP (reference).
+    flat_exchange_min_params: int = 1_000_000
 
 
 class Engine:
@@ -70,7 +75,13 @@ class Engine:
             if p.module is not None:
                 p.module.to(self.device)
                 p.fwd = p.module
-                if strategy == "distributed":
+                n_params = sum(q.numel() for q in p.module.parameters())
+                thr = self.config.flat_exchange_min_params
+                p._flat_exchange = bool(strategy == "distributed" and world > 1 and thr > 0 and n_params >= thr
+                                        and p.config.gradient_accumulation == 1)
+                if p._flat_exchange:
+                    p.synchronize_params(list(p.module.parameters()))   # what DDP's constructor would have broadcast
+                elif strategy == "distributed":
                     from torch.nn.parallel import DistributedDataParallel as DDP
 
                     # same wrapper arguments as problem.py:220-224

@@ -1,0 +1,136 @@
+"""Global-HVP conjugate gradient: ONE inner problem whose batch is spread over the ranks of a process group.
+
+The reference's distributed mode replicates the whole solve: every rank runs ``cg`` on its own batch and only the
+M-sized hypergradient is averaged (that is what ``cg(..., sync=True)`` still does).  This module
+is the extension SURVEY.md §8(e)(2) / north_star describe — not in the reference; its oracle is the reference's ``cg``
+run in ONE process on the concatenated batch (valid when the inner loss is a batch mean without batch-statistics
+layers and all ranks hold equally sized batches):
+
+  * the Hessian-vector product is data parallel: each rank differentiates its own batch,
+  * the CG state ``x, r, p`` is SHARDED: rank g owns elements [g*S, (g+1)*S) of the flat vectors (S a multiple of
+    4096, so every rank has the same chunk count),
+  * per iteration: reduce-scatter(SUM) of the local HVPs (pre-scaled by 1/G: each rank receives its slice of the mean
+    HVP — one collective of N/G per peer instead of an all-reduce of N), the three streaming CG kernels on the slice
+    with the two dot products completed by all-reducing their per-block partials (bhg_cg_phase), all-gather of the
+    new direction,
+  * the mixed second derivative is taken on every rank's own batch in direction of the all-gathered solution and
+    averaged (by the DDP reducer under ``sync=True``, by one flat all-reduce otherwise).
+
+Collectives run on torch.distributed's stream for the group (RCCL over xGMI with backend "nccl"); the next HVP cannot
+start before the direction is gathered, so the overlap available inside one solve is RCCL's own pipelining; the final
+M-sized exchange overlaps with the caller's next kernels like any asynchronous collective.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .backend import get_backend
+from .hypergradient._common import AutogradHVP, inner_gradient, mixed_vjp
+from .hypergradient.structured import structured_hvp_for
+
+SHARD_ALIGN = 4096   # = BHG_CHUNK_ELEMS: equal chunk counts on all ranks
+
+
+def _backend_name(group) -> str:
+    try:
+        return str(dist.get_backend(group))
+    except Exception:  # pragma: no cover
+        return "unknown"
+
+
+def reduce_scatter_sum(full: torch.Tensor, shard: torch.Tensor, rank: int, group) -> None:
+    """shard <- slice ``rank`` of sum_over_ranks(full).  RCCL: one reduce-scatter; gloo (CPU tests) has none."""
+    if _backend_name(group) == "gloo":
+        tmp = full.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        S = shard.numel()
+        shard.copy_(tmp[rank * S:(rank + 1) * S])
+    else:
+        dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_flat(shard: torch.Tensor, full: torch.Tensor, group) -> None:
+    dist.all_gather_into_tensor(full, shard, group=group)
+
+
+class _State:
+    """Buffers of one (layout, world size): sharded x, r, p and the Hp slice; full-length direction / HVP / solution."""
+
+    def __init__(self, be, full_layout, world: int):
+        per = world * SHARD_ALIGN
+        self.Np = (full_layout.flat_size + per - 1) // per * per
+        self.S = self.Np // world
+        dev = full_layout.device
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.p_full, self.h_full, self.x_full = z(self.Np), z(self.Np), z(self.Np)
+        self.x, self.r, self.p, self.hs = z(self.S), z(self.S), z(self.S), z(self.S)
+        self.shard_layout = be.layout([self.hs])
+
+
+_STATES = {}
+
+
+def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = None):
+    """Same signature and result convention as ``cg`` (betty/hypergradient/cg.py:8-70); ``vector`` is this rank's
+    gradient of ITS share of the upper loss (the global one is the mean over ranks).  Returns the GLOBAL hypergradient
+    (identical on all ranks) when ``sync`` is False."""
+    assert len(curr.paths) == 0, "cg method is not supported for higher order MLO!"
+    assert dist.is_available() and dist.is_initialized(), "cg_global needs an initialised process group"
+    config = curr.config
+    be = get_backend()
+    vector = list(vector)
+    G, g = dist.get_world_size(group), dist.get_rank(group)
+
+    provider = structured_hvp_for(curr, prev)
+    if provider is None:
+        in_grad = inner_gradient(curr)
+        hvp_fn = AutogradHVP(in_grad, curr.parameters())
+    else:
+        in_grad = None
+        hvp_fn = provider.prepare()
+    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
+
+    full = be.layout(vector)
+    key = (id(full), G)
+    st = _STATES.get(key)
+    if st is None:
+        st = _STATES[key] = _State(be, full, G)
+    sl = st.shard_layout
+
+    # v = mean over ranks of the local vectors; every rank keeps its slice
+    be.flatten(full, vector, st.h_full, 1.0 / G)
+    reduce_scatter_sum(st.h_full, st.hs, g, group)
+    be.cg_init(sl, [st.hs], st.x, st.r, st.p)                      # x = 0, r = p = v_slice, partials of r.r
+    dist.all_reduce(be.cg_partials(sl, 2, 0), op=dist.ReduceOp.SUM, group=group)
+    all_gather_flat(st.p, st.p_full, group)
+    p_views = full.views(st.p_full, vector)
+
+    K = int(config.cg_iterations)
+    alpha = float(config.cg_alpha)
+    for k in range(K):
+        hvp = hvp_fn(p_views)                                        # H_local p (cg.py:39-41), this rank's batch
+        be.flatten(full, hvp, st.h_full, 1.0 / G)
+        reduce_scatter_sum(st.h_full, st.hs, g, group)               # slice of the MEAN Hessian-vector product
+        last = k == K - 1 and alpha != 0.0
+        args = (sl, [st.hs], st.x, st.r, st.p, alpha, k, (-alpha if last else 0.0), shift)
+        be.cg_phase(0, *args)                                        # partials of (cg_alpha*Hp).p over the slice
+        dist.all_reduce(be.cg_partials(sl, 0, k), op=dist.ReduceOp.SUM, group=group)
+        be.cg_phase(1, *args)                                        # alpha; r' = r - alpha*Hp; partials of r'.r'
+        dist.all_reduce(be.cg_partials(sl, 1, k), op=dist.ReduceOp.SUM, group=group)
+        be.cg_phase(2, *args)                                        # beta; x += alpha*p; p = r' + beta*p
+        if k + 1 < K:
+            all_gather_flat(st.p, st.p_full, group)
+    if K > 0 and alpha == 0.0:
+        be.scale_flat(st.x, -alpha)
+
+    all_gather_flat(st.x, st.x_full, group)
+    neg_x = full.views(st.x_full, vector)
+    out = provider.mixed_vjp(neg_x, sync) if provider is not None else mixed_vjp(in_grad, prev, neg_x, sync)
+    if sync:
+        return None          # accumulated through backward(): the DDP reducer of prev's module averaged it
+    from .distributed import exchange_async  # noqa: PLC0415
+
+    return [t.clone() for t in exchange_async(out, group).wait()]

@@ -19,12 +19,21 @@ def reinforce(vector, curr, prev, sync):
                               "(betty/hypergradient/reinforce.py:6-7); use darts | sama | neumann | cg")
 
 
+def cg_global(vector, curr, prev, sync):
+    """Extension key (not in the reference): ``Config(type="cg_global")`` solves ONE inner problem whose batch is spread
+    over the default process group — data-parallel HVP, sharded CG state (betty_amd/global_hvp.py)."""
+    from ..global_hvp import cg_global as impl  # noqa: PLC0415
+
+    return impl(vector, curr, prev, sync)
+
+
 jvp_fn_mapping = {
     "darts": darts,
     "sama": sama,
     "neumann": neumann,
     "cg": cg,
     "reinforce": reinforce,
+    "cg_global": cg_global,
 }
 
 

@@ -54,6 +54,9 @@ class Problem:
         self._roll_back = False
         self._world_size = 1
         self._snapshot = None
+        # flat asynchronous hypergradient exchange (Engine: strategy "distributed", large upper problems)
+        self._flat_exchange = False
+        self._pending_exchange = []
         # fp16 dynamic loss scaler (problem.py:165-174): created on first use so that a CPU-only import works
         self.scaler = None
         # forward module seen by other problems (a DDP wrapper under strategy "distributed")
@@ -188,6 +191,7 @@ class Problem:
         if hasattr(self, "grad_callback"):
             self.grad_callback()
         if self.gradient_accumulation_boundary():
+            self.finish_exchanges()
             self.optimizer_step()
             if hasattr(self, "param_callback"):
                 self.param_callback()
@@ -200,6 +204,22 @@ class Problem:
 
     def backward(self, loss, params, paths, create_graph=False, retain_graph=True, allow_unused=True):
         """problem.py:521-581."""
+        if self._flat_exchange:
+            # Extension (EngineConfig.flat_exchange_min_params): every gradient piece of this step — the direct one and
+            # one per path — is averaged over the ranks by ONE flat asynchronous all-reduce (RCCL over xGMI) issued as
+            # soon as the piece exists; the exchange of path i overlaps with the CG solve of path i+1 (which then uses
+            # the streaming CG kernels: the resident one needs every CU).  The averaged pieces are accumulated into
+            # .grad just before the optimizer step.
+            from .distributed import exchange_async  # noqa: PLC0415
+
+            grads = torch.autograd.grad(loss, params, create_graph=create_graph, retain_graph=retain_graph or len(paths) > 0,
+                                        allow_unused=allow_unused)
+            self._queue_exchange(params, grads, exchange_async)
+            if self._config.first_order:
+                last = len(paths) - 1
+                for idx, path in enumerate(paths):
+                    self._queue_exchange(params, get_grads(loss, path, retain_graph=(idx != last), do_sync=False), exchange_async)
+            return
         # direct gradient: through autograd.grad + set_grads while a hypergradient (or another
         # accumulation step) is still to come, through backward() (DDP-syncing) otherwise
         if len(paths) > 0 or not self.gradient_accumulation_boundary():
@@ -216,6 +236,17 @@ class Problem:
                 grads = get_grads(loss, path, retain_graph=(idx != last), do_sync=do_sync)
                 if not do_sync:
                     self.set_grads(params, grads)
+
+    def _queue_exchange(self, params, grads, exchange_async):
+        keep = [(p, g) for p, g in zip(params, grads) if g is not None]
+        if keep:
+            self._pending_exchange.append(([p for p, _ in keep], exchange_async([g for _, g in keep])))
+
+    def finish_exchanges(self):
+        """Wait (on the stream, not the host) for the flat exchanges of this step and accumulate the averages."""
+        for plist, handle in self._pending_exchange:
+            self.set_grads(plist, [t.clone() for t in handle.wait()])
+        self._pending_exchange = []
 
     def set_grads(self, params, grads):
         """problem.py:583-597: accumulate ``grads`` into ``.grad`` (assign where there is none), skip

@@ -126,6 +126,17 @@ const double* bhg_cg_scalars_dev(const void* ws);
  * polling since the last bhg_cg_init on that workspace (the result is NaN-poisoned as well). */
 const unsigned* bhg_cg_timeout_flag_dev(const void* ws);
 
+/* ---- phased CG iteration for SHARDED state vectors (global-HVP mode; not in the reference: SURVEY.md §8(e)(2)) -------
+ * The three kernels of BHG_CG_STREAM, one call per phase (0: dot, 1: residual, 2: direction), so the caller can
+ * all-reduce(SUM) the per-block partial sums over its process group between the phases; every rank's consumer kernel
+ * then sums the same all-reduced partials = the global dot products of cg.py:45-46,51.  All ranks must hold equally
+ * sized shards.  bhg_cg_partials_dev(ws, which, iter): device address of bhg_cg_partials_count() doubles —
+ * which = 0: after phase 0; which = 1: after phase 1; which = 2: after bhg_cg_init (r.r).                             */
+int bhg_cg_phase(int phase, const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x,
+                 float* r, float* p, float cg_alpha, int iter, float out_scale, float hvp_shift, void* ws, void* stream);
+double* bhg_cg_partials_dev(void* ws, int which, int iter);
+int bhg_cg_partials_count(void);
+
 /* ---- flat helpers ------------------------------------------------------------- */
 /* flat <- scale * flat  (cg.py:56 / neumann.py:66 when iterations == 0)           */
 int bhg_scale_flat(float* flat, int64_t n, float scale, void* stream);

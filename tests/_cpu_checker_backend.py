@@ -55,6 +55,7 @@ class CpuCheckerBackend:
     def __init__(self):
         self.orc = load_oracle_lib()
         self._rr = {}
+        self._g = {}
 
     def layout(self, tensors):
         return layout_for(tensors)
@@ -98,6 +99,7 @@ class CpuCheckerBackend:
             self.orc.orc_cg_init(t.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), t.numel())
             rr += self.orc.orc_sqnorm(t.data_ptr(), t.numel())
         self._rr[id(layout)] = rr
+        self._g.pop(id(layout), None)
 
     def cg_step(self, layout, hvp, x, r, p, cg_alpha, it, out_scale=0.0, variant=None, hvp_shift=0.0):
         hs = self._prep(hvp)
@@ -113,6 +115,35 @@ class CpuCheckerBackend:
             self.orc.orc_cg_dir(xx.data_ptr(), q.data_ptr(), pp.data_ptr(), xx.numel(), a, b, out_scale)
         self._rr[id(layout)] = rr_new
         self.last_scalars = (rr, den, a, rr_new, b)
+
+    # phased CG for sharded state: one-element "partial arrays" the caller all-reduces between the phases
+    def cg_partials(self, layout, which, it):
+        st = self._g.setdefault(id(layout), {})
+        if which == 2 and "R" not in st:
+            st["R"] = torch.tensor([self._rr[id(layout)]], dtype=torch.float64)
+        return st[{0: "P", 1: "Rn", 2: "R"}[which]]
+
+    def cg_phase(self, phase, layout, hvp, x, r, p, cg_alpha, it, out_scale=0.0, hvp_shift=0.0):
+        st = self._g.setdefault(id(layout), {})
+        hs = self._prep(hvp)
+        xs, rs, ps = self._slices(layout, x), self._slices(layout, r), self._slices(layout, p)
+        if hvp_shift:
+            hs = [h.reshape(-1) + torch.tensor(hvp_shift, dtype=torch.float32) * q for h, q in zip(hs, ps)]
+        if phase == 0:
+            if it == 0 and "R" not in st:
+                st["R"] = torch.tensor([self._rr[id(layout)]], dtype=torch.float64)
+            st["P"] = torch.tensor([sum(self.orc.orc_dot_scaled(h.data_ptr(), q.data_ptr(), h.numel(), cg_alpha)
+                                        for h, q in zip(hs, ps))], dtype=torch.float64)
+        elif phase == 1:
+            a = _f32(_f32(float(st["R"][0])) / _f32(float(st["P"][0])))
+            st["a"] = a
+            st["Rn"] = torch.tensor([sum(self.orc.orc_cg_resid(h.data_ptr(), q.data_ptr(), h.numel(), a)
+                                         for h, q in zip(hs, rs))], dtype=torch.float64)
+        else:
+            b = _f32(_f32(float(st["Rn"][0])) / _f32(float(st["R"][0])))
+            for xx, q, pp in zip(xs, rs, ps):
+                self.orc.orc_cg_dir(xx.data_ptr(), q.data_ptr(), pp.data_ptr(), xx.numel(), st["a"], b, out_scale)
+            st["R"] = st["Rn"].clone()
 
     def darts_eps(self, layout, vector, R):
         ss = sum(self.orc.orc_sqnorm(t.data_ptr(), t.numel()) for t in self._prep(vector))

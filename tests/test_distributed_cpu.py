@@ -188,7 +188,7 @@ def test_flat_async_exchange_of_a_hypergradient():
         assert shapes_ok and err < 1e-6
 
 
-def _engine_worker(rank, world, port, q):
+def _engine_worker(rank, world, port, q, flat=False, compare=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -210,36 +210,57 @@ def _engine_worker(rank, world, port, q):
         x, y = inner.train_data_loader[0]
         half = x.shape[0] // world
         inner.train_data_loader = [(x[rank * half:(rank + 1) * half], y[rank * half:(rank + 1) * half])]
-        engine = Engine(config=EngineConfig(train_iters=100, strategy="distributed", backend="gloo"),
-                        problems=[outer, inner], dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}},
-                        device=torch.device("cpu"))
         with use_backend(CpuCheckerBackend()):
+            engine = Engine(config=EngineConfig(train_iters=100, strategy="distributed", backend="gloo",
+                                                flat_exchange_min_params=1 if flat else 0),
+                            problems=[outer, inner], dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}},
+                            device=torch.device("cpu"))
+            # the scenario's Inner.training_step calls self.module directly (like the reference's test), so under DDP
+            # its own gradients are never reduced; keep that in the flat arm: only the UPPER problem exchanges
+            inner._flat_exchange = False
+            if compare:   # exact A/B of the UPPER exchange only: no reducer on the inner module in either arm (under DDP a
+                inner.fwd = inner.module   # forward through the wrapper arms the reducer for the next direct-call step)
             engine.run()
         lam = outer.module.w.detach().clone()
         gathered = [torch.zeros_like(lam) for _ in range(world)]
         dist.all_gather(gathered, lam)
-        q.put((rank, outer.count, float((gathered[0] - gathered[1]).abs().max()), float((lam - 1.0).abs().max())))
+        assert outer._flat_exchange == flat
+        q.put((rank, outer.count, float((gathered[0] - gathered[1]).abs().max()), float((lam - 1.0).abs().max()), lam.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def test_engine_distributed_strategy_keeps_upper_parameters_in_sync():
-    """Engine(strategy="distributed"): the upper module is DDP-wrapped, the synced hypergradient hop
-    averages over ranks, so after 5 upper steps on different data every rank holds the same lambda."""
-    world = 2
+def _run_engine(world, flat, compare=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q, flat, compare)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
-    for rank, upper_steps, diff, moved in sorted(q.get(timeout=5) for _ in range(world)):
+    return sorted((q.get(timeout=5) for _ in range(world)), key=lambda t: t[0])
+
+
+def test_engine_distributed_strategy_keeps_upper_parameters_in_sync():
+    """Engine(strategy="distributed"): the upper module is DDP-wrapped, the synced hypergradient hop
+    averages over ranks, so after 5 upper steps on different data every rank holds the same lambda."""
+    for rank, upper_steps, diff, moved, _lam in _run_engine(2, flat=False):
         assert upper_steps == 5
         assert diff < 1e-6, "ranks diverged: the hypergradient was not averaged"
         assert moved > 1e-3, "lambda did not move at all"
+
+
+def test_engine_flat_async_exchange_equals_ddp():
+    """EngineConfig.flat_exchange_min_params: direct gradient and per-path hypergradients averaged by flat asynchronous
+    all-reduces (Problem.backward -> exchange_async, waited for before the optimizer step) instead of the DDP reducer:
+    same parameters after 5 upper steps, on every rank."""
+    ddp = _run_engine(2, flat=False, compare=True)
+    flat = _run_engine(2, flat=True, compare=True)
+    for (rank, steps, diff, moved, lam_f), (_, _, _, _, lam_d) in zip(flat, ddp):
+        assert steps == 5 and diff < 1e-6 and moved > 1e-3
+        np.testing.assert_allclose(lam_f, lam_d, rtol=2e-5, atol=1e-7)
 
 
 def _fsdp_darts_worker(rank, world, port, q):
@@ -320,3 +341,84 @@ def test_darts_fsdp_branch_uses_the_norm_of_the_whole_sharded_vector():
         assert err < 2e-3, (rank, err)          # finite differences: the darts tolerance of the golden cases
         assert drift < 2e-7, (rank, drift)
         assert ref_err in (-1.0, 0.0), (rank, ref_err)
+
+
+# ------------------------------------------------------------------------------------------------
+# global-HVP mode (betty_amd/global_hvp.py): ONE inner problem, batch spread over the ranks,
+# sharded CG state.  Oracle = the reference algorithm in ONE process on the concatenated batch.
+# ------------------------------------------------------------------------------------------------
+def _global_worker(rank, world, port, case_name, structured, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hypergrad_oracle as orc
+        import zoo
+        from _cpu_checker_backend import CpuCheckerBackend
+        from conftest import load_golden
+
+        from betty_amd import Config
+        from betty_amd.backend import use_backend
+        from betty_amd.global_hvp import cg_global
+
+        case = zoo.CASE_BY_NAME[case_name]
+        inputs, _ = load_golden(case.family)
+        full_inputs = dict(inputs)
+        n = (inputs["batch_x"].shape[0] // world) * world      # equal shares
+        full_inputs["batch_x"], full_inputs["batch_y"] = inputs["batch_x"][:n], inputs["batch_y"][:n]
+        share = n // world
+        mine = dict(full_inputs)
+        mine["batch_x"] = full_inputs["batch_x"][rank * share:(rank + 1) * share]
+        mine["batch_y"] = full_inputs["batch_y"][rank * share:(rank + 1) * share]
+
+        # single-process oracle on the concatenated batch (every rank computes it: no communication involved)
+        curr, prev, vector = zoo.build_case(case, full_inputs, Config)
+        want = torch.cat([t.reshape(-1) for t in orc.cg(vector, curr, prev, False)]).detach()
+
+        with use_backend(CpuCheckerBackend()):
+            curr, prev, vector = zoo.build_case(case, mine, Config)
+            if structured:
+                zoo.attach_mlp_structure(curr, case.family, impl="torch")
+            got = cg_global(vector, curr, prev, False)
+            got = torch.cat([t.reshape(-1) for t in got]).detach()
+            # sync=True: lands in .grad through backward (no DDP wrapper here: the local share of the mean)
+            curr2, prev2, vector2 = zoo.build_case(case, mine, Config)
+            ret = cg_global(vector2, curr2, prev2, True)
+            local = torch.cat([p.grad.reshape(-1) for p in prev2.trainable_parameters()]).detach()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            synced = torch.stack(gathered).mean(0)
+        rel = float((got - want).norm() / want.norm())
+        rel_sync = float((synced - want).norm() / want.norm())
+        # every rank must hold the same global answer
+        others = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(others, got)
+        same = all(torch.equal(o, got) for o in others)
+        q.put((rank, rel, rel_sync, ret is None, same))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case_name,structured", [("reweight_cg20", False), ("reweight_cg20", True), ("logreg_cg5", False),
+                                                  ("logreg_cg3_a01", False)])
+def test_global_hvp_cg_matches_single_process_oracle(world, case_name, structured):
+    """Sharded x, r, p; reduce-scatter of the data-parallel HVPs; partial-sum all-reduces between the CG phases;
+    all-gather of the direction: the result equals the reference's cg on the concatenated batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_worker, args=(r, world, port, case_name, structured, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, rel_sync, returned_none, same in sorted(q.get(timeout=5) for _ in range(world)):
+        assert rel <= 1e-4, (rank, rel)            # north_star tolerance vs the single-process reference algorithm
+        assert rel_sync <= 1e-4, (rank, rel_sync)  # sync=True: mean over ranks of what landed in .grad
+        assert returned_none and same

@@ -810,24 +810,33 @@ def _resnet12_case(cfg):
     return curr, prev, vector
 
 
-@pytest.mark.parametrize("variant", ["resident", "stream"])
-def test_cfg3_resnet12_cg20(variant, be):
-    """BASELINE cfg 3 at the example's own shape: ResNet12(5, 32) = 10,430,533 parameters in 122 tensors, 25 support
-    images of 84 x 84, proximal term to the upper copy, CG K = 20 (examples/implicit_maml/main.py:87-92,122-129)."""
+@pytest.fixture(scope="module")
+def resnet12_checker():
+    """The checker's answer for cfg 3 (oracle restatement on the device: opaque double backward + per-tensor ATen
+    recurrence), computed ONCE for both kernel variants, and its own run-to-run spread (MIOpen atomics)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hypergrad_oracle as horc
 
     curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
+    want = _np(horc.cg(vector, curr, prev, False))
+    again = _np(horc.cg(vector, curr, prev, False))
+    noise, _ = rel_err(again, want)
+    return want, noise
+
+
+@pytest.mark.parametrize("variant", ["resident", "stream"])
+def test_cfg3_resnet12_cg20(variant, be, resnet12_checker):
+    """BASELINE cfg 3 at the example's own shape: ResNet12(5, 32) = 10,430,533 parameters in 122 tensors, 25 support
+    images of 84 x 84, proximal term to the upper copy, CG K = 20 (examples/implicit_maml/main.py:87-92,122-129)."""
+    want, noise = resnet12_checker
+    curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
     assert len(vector) == 122 and sum(v.numel() for v in vector) == 10_430_533
-    want = horc.cg(vector, curr, prev, False)
-    again = horc.cg(vector, curr, prev, False)      # the checker's own run-to-run spread (MIOpen atomics)
-    noise, _ = rel_err(_np(again), _np(want))
     be.cg_variant = VARIANTS[variant]
     try:
         got = hg.jvp_fn_mapping["cg"](vector, curr, prev, False)
     finally:
         be.cg_variant = _native.BHG_CG_AUTO
-    rel, mx = rel_err(_np(got), _np(want))
+    rel, mx = rel_err(_np(got), want)
     # rtol 1e-4 (north_star) unless the convolution double backward is itself noisier than that on this box
     tol = max(1e-4, 20 * noise)
     print(f"resnet12 cg20 [{variant}]: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
@@ -835,10 +844,6 @@ def test_cfg3_resnet12_cg20(variant, be):
     assert not be.cg_barrier_timed_out(be.layout(vector))
 
 
-# ------------------------------------------------------------------------------------------------
-# BASELINE.json cfg 4 at full size (single-GPU part): RoBERTa-base-shaped inner (124 M parameters),
-# data-reweighting upper, finite-difference DARTS hypergradient
-# ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("radius", [0.01, 1.0])   # 0.01 = Config's default darts_alpha; 1.0 = well above fp32 resolution
 def test_cfg4_roberta_scale_darts(radius, be):
     import copy
