@@ -247,6 +247,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner on the C-level stdout when a process group
+    # comes up, so file descriptor 1 is pointed at stderr for the whole run and the line is written to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -449,7 +454,7 @@ def main():
         }
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps, K)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

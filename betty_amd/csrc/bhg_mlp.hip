@@ -345,6 +345,9 @@ struct FuseArgs {
   float shift;       // operator = raw HVP + shift * I
   float out_scale;   // applied to x (CG) / p (Neumann) when apply_out != 0: the final scaling + negation of the solve
   int apply_out;
+  int x_mode;        // CG, lazy slices only: 0 = x += alpha*p | 1 = leave x alone this iteration | 2 = catch up:
+                     // x = (x + alpha_prev*p_old) + alpha*p — the very two roundings of two separate updates, with x read
+                     // and written every OTHER iteration only (p_old, last iteration's direction, is loaded anyway)
   int lazy;          // CG: the slice at d still holds the PREVIOUS direction; this iteration's is r + beta * d — formed
                      // here (same roundings as k_cg_pdir) and written back, so no kernel of its own updates it (cg.py:53)
 };
@@ -356,12 +359,15 @@ __device__ __forceinline__ float fz_sub(float a, float b) { return __fsub_rn(a, 
 // results back in av / bv, the direction actually used back in dv.
 template <int MODE>
 __device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float beta, float hv, float& dv, float& av,
-                                          float& bv, FuseAcc& acc) {
+                                          float& bv, FuseAcc& acc, float alpha_prev = 0.f) {
+  const float d_old = dv;
   if (MODE == FUSE_CG && f.lazy) dv = fz_add(av, fz_mul(beta, dv));
   if (f.shift != 0.f) hv = fz_add(hv, fz_mul(f.shift, dv));
   if (MODE == FUSE_CG) {
     const float nr = fz_sub(av, fz_mul(alpha, hv));
-    float nx = fz_add(bv, fz_mul(alpha, dv));
+    float nx = bv;
+    if (f.x_mode == 2) nx = fz_add(nx, fz_mul(alpha_prev, d_old));
+    if (f.x_mode != 1) nx = fz_add(nx, fz_mul(alpha, dv));
     if (f.apply_out) nx = fz_mul(f.out_scale, nx);
     acc.rr += (double)nr * nr;
     acc.rp += (double)nr * dv;
@@ -550,6 +556,8 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
     const float alpha = fuse_alpha<MODE>(fz);
     const float beta = fuse_beta<MODE>(fz);
     const bool wr_d = MODE == FUSE_CG && fz.lazy;
+    const bool use_x = !(MODE == FUSE_CG && fz.x_mode == 1);   // workgroup-uniform
+    const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_PREV] : 0.f;
     FuseAcc racc{0.0, 0.0, 0.0};
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -564,7 +572,7 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
         const int64_t off = ok[i] ? (int64_t)grow * a.ldo + gcol : 0;
         dv[i] = ld16(fz.d + off);
         if (MODE == FUSE_CG) av[i] = ld16(fz.a + off);
-        bv[i] = ld16(fz.b + off);
+        bv[i] = use_x ? ld16(fz.b + off) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -575,20 +583,20 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
         const int64_t off = (int64_t)grow * a.ldo + gcol;
         if (ok[i]) {
           float4 na = MODE == FUSE_CG ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), nb = bv[i], nd = dv[i];
-          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc);
-          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc);
-          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc);
-          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc);
+          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc, alpha_prev);
           *reinterpret_cast<float4*>(fz.a + off) = na;
-          *reinterpret_cast<float4*>(fz.b + off) = nb;
+          if (use_x) *reinterpret_cast<float4*>(fz.b + off) = nb;
           if (wr_d) *reinterpret_cast<float4*>(fz.d + off) = nd;
         } else if (!FAST && grow < a.M) {   // ragged right edge / odd leading dimension: element by element
           const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
           for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
-            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = fz.b[off + j], nd = fz.d[off + j];
-            fuse_elem<MODE>(fz, alpha, beta, hh[j], nd, na, nb, racc);
+            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = use_x ? fz.b[off + j] : 0.f, nd = fz.d[off + j];
+            fuse_elem<MODE>(fz, alpha, beta, hh[j], nd, na, nb, racc, alpha_prev);
             fz.a[off + j] = na;
-            fz.b[off + j] = nb;
+            if (use_x) fz.b[off + j] = nb;
             if (wr_d) fz.d[off + j] = nd;
           }
         }
@@ -1329,6 +1337,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
     const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
     const double den = (double)a.cg_alpha * php;
     const float alpha = (float)rr / (float)den;
+    a.scal[S_ALPHA_PREV] = a.scal[S_ALPHA];
     a.scal[S_RR_OLD] = rr;
     a.scal[S_PHP] = den;
     a.scal[S_ALPHA] = (double)alpha;
@@ -1565,6 +1574,7 @@ struct ChainMode {
   double* partRR_new;
   double* scal;
   float cg_alpha;
+  int x_mode;                   // see FuseArgs.x_mode (applies to the lazy slices only)
   int first;                    // first iteration of a solve (Rz(x) accumulator is set, not added to)
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
 };
@@ -1607,6 +1617,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       f.a = cm.fa + o; f.b = cm.fb + o; f.d = cm.fd + o;
       // lazy direction: only the MFMA layers' weight slices (the small slices were updated by k_cg_beta)
       f.lazy = cm.lazy && (tensor & 1) == 0 && !(head && tensor == 2 * (L - 1));
+      f.x_mode = f.lazy ? cm.x_mode : 0;
     }
     f.part_base = part_base;
     return f;
@@ -1986,6 +1997,9 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.partRR_new = w.partRR[(k + 1) & 1];
     // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
     cm.lazy = lazy;
+    // x is read and written every other iteration (FuseArgs.x_mode): even iterations defer, odd ones catch up
+    static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
+    cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
     cm.first = k == 0;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));

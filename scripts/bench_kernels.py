@@ -3,6 +3,11 @@
 the 8 tensors of the cfg-2 MLP).  The HVP producer is emulated by a diagonal multiply that rewrites
 the 8 HVP tensors before every launch (so Hp is as cache-cold/warm as behind a real producer).
 Prints one line per kernel: median / min launch time from HIP events and achieved algorithmic GB/s.
+
+--scrub-mb M (cache-defeated mode): before every timed launch a device copy of 2 x M MiB (default off; use >= 384) runs
+through the memory system, so the 256 MiB Infinity Cache no longer holds the state vectors x, r, p / v, p when the kernel
+starts (the HVP tensors are re-written AFTER the scrub: they are as warm as behind a real producer).  Without it the
+N = 10 M working set (160 MB) stays in the cache from launch to launch and the "GB/s" are fabric-side, not HBM, numbers.
 """
 import argparse
 import json
@@ -36,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--scale", type=int, default=1, help="replicate the tensor list (bigger N)")
+    ap.add_argument("--scrub-mb", type=int, default=0, help="cache-defeated mode: copy 2 x this many MiB before every launch")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
@@ -48,11 +54,25 @@ def main():
     lay = be.layout(vec)
     x, r, p = lay.state(3)
     out = {}
+    scrub = None
+    if args.scrub_mb > 0:
+        sa = torch.zeros(args.scrub_mb * (1 << 20) // 4, device=dev)
+        sb = torch.empty_like(sa)
+        scrub = lambda: sb.copy_(sa)
+
+    def with_scrub(pre):
+        if scrub is None:
+            return pre
+
+        def f():
+            scrub()
+            pre()
+        return f
 
     # calibration: plain device copy of 3 x 40 MB in, 3 x 40 MB out
     src = torch.randn(3 * N, device=dev)
     dst = torch.empty_like(src)
-    med, mn = timeit(lambda: dst.copy_(src), lambda: None, args.iters)
+    med, mn = timeit(lambda: dst.copy_(src), with_scrub(lambda: None), args.iters)
     out["torch_copy_24N"] = dict(us=med, min_us=mn, GBps=24.0 * N / med / 1e3)
 
     def refresh(views):
@@ -75,25 +95,25 @@ def main():
                 be.cg_init(lay, vec, x, r, p)
                 k[0] = 0
 
-        med, mn = timeit(step, refresh(pv), args.iters)
+        med, mn = timeit(step, with_scrub(refresh(pv)), args.iters)
         out[name] = dict(us=med, min_us=mn, GBps=28.0 * N / med / 1e3, frac_of_8TBps=28.0 * N / med / 1e3 / 8000)
         assert not be.cg_barrier_timed_out(lay), "grid barrier timed out"
 
     v, pp = lay.state(2)
     be.neumann_init(lay, vec, v, pp)
     vv = lay.views(v, vec)
-    med, mn = timeit(lambda: be.neumann_step(lay, hv, v, pp, 0.01, 0.0), refresh(vv), args.iters)
+    med, mn = timeit(lambda: be.neumann_step(lay, hv, v, pp, 0.01, 0.0), with_scrub(refresh(vv)), args.iters)
     out["neumann_step"] = dict(us=med, min_us=mn, GBps=20.0 * N / med / 1e3, frac_of_8TBps=20.0 * N / med / 1e3 / 8000)
 
     w = [t.clone() for t in vec]
     coef = torch.tensor([1e-3], device=dev)
-    med, mn = timeit(lambda: be.axpy_multi(lay, w, vec, coef[0], 1.0), lambda: None, args.iters)
+    med, mn = timeit(lambda: be.axpy_multi(lay, w, vec, coef[0], 1.0), with_scrub(lambda: None), args.iters)
     out["axpy_multi"] = dict(us=med, min_us=mn, GBps=12.0 * N / med / 1e3)
-    med, mn = timeit(lambda: be.darts_eps(lay, vec, 0.01), lambda: None, args.iters)
+    med, mn = timeit(lambda: be.darts_eps(lay, vec, 0.01), with_scrub(lambda: None), args.iters)
     out["darts_eps(sqnorm)"] = dict(us=med, min_us=mn, GBps=4.0 * N / med / 1e3)
-    med, mn = timeit(lambda: be.cg_init(lay, vec, x, r, p), lambda: None, args.iters)
+    med, mn = timeit(lambda: be.cg_init(lay, vec, x, r, p), with_scrub(lambda: None), args.iters)
     out["cg_init"] = dict(us=med, min_us=mn, GBps=16.0 * N / med / 1e3)
-    print(json.dumps({"N": N, "T": len(sizes), "kernels": out}, indent=1))
+    print(json.dumps({"N": N, "T": len(sizes), "scrub_mb_before_each_launch": args.scrub_mb, "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":

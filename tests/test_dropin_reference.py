@@ -1,9 +1,12 @@
 """Drop-in under the REAL reference: `betty_amd.install()` replaces the registry entries of a live
-`betty.hypergradient` and the reference's own Engine/Problem (unmodified, imported from /root/reference)
-drives our cg/neumann/darts through `Problem.backward -> get_grads`.  Only runs where the reference
-checkout exists (the build container); kernels are the C oracle via the test-only checker backend
-because that container has no GPU.  The same scenario runs on the GPU through the HIP kernels with
-betty_amd's own caller slice in tests/test_engine_shim.py."""
+`betty.hypergradient` and the reference's own Engine/Problem (unmodified, imported from the checkout named by
+$BETTY_REF, default /root/reference) drives our cg/neumann/darts through `Problem.backward -> get_grads`.
+Only runs where a reference checkout exists:
+  * in the build container (no GPU) the kernels are the C oracle via the test-only checker backend;
+  * `-m gpu` with BETTY_REF pointing at a checkout on a GPU box: the SAME scenario with the reference's Engine over the
+    HIP kernels (`HipBackend`) — the two halves of the drop-in claim in one run.  (The GPU box the driver uses has no
+    reference checkout, so there the scenario runs through betty_amd's own caller slice, tests/test_engine_shim.py.)"""
+import contextlib
 import os
 import sys
 
@@ -12,7 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-REF = "/root/reference"
+REF = os.environ.get("BETTY_REF", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "betty")), reason="reference checkout not present")
 
 
@@ -35,10 +38,25 @@ def ref():
 
 @pytest.mark.parametrize("algo", ["cg", "neumann", "darts"])
 def test_reference_engine_runs_on_our_functions(ref, algo):
-    import betty_amd
     from _cpu_checker_backend import CpuCheckerBackend
-    from betty_amd import hypergradient as hg
     from betty_amd.backend import use_backend
+
+    _reference_engine_scenario(ref, algo, use_backend(CpuCheckerBackend()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["cg", "neumann", "darts"])
+def test_reference_engine_runs_on_the_hip_backend(ref, algo):
+    """The reference's unmodified Engine / ImplicitProblem on the MI355X, hypergradients by libbhg's kernels."""
+    from betty_amd.backend import get_backend
+
+    assert get_backend().name == "hip"
+    _reference_engine_scenario(ref, algo, contextlib.nullcontext())
+
+
+def _reference_engine_scenario(ref, algo, backend_ctx):
+    import betty_amd
+    from betty_amd import hypergradient as hg
 
     Config, EngineConfig, Engine, ImplicitProblem = ref["Config"], ref["EngineConfig"], ref["Engine"], ref["ImplicitProblem"]
     mapping = betty_amd.install(ref["bh"])
@@ -104,7 +122,7 @@ def test_reference_engine_runs_on_our_functions(ref, algo):
                   train_data_loader=[(t(x[:500]), t(y[:500]))], config=cfgs[algo])
     engine = Engine(config=EngineConfig(train_iters=2000), problems=[outer, inner],
                     dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}})
-    with use_backend(CpuCheckerBackend()):
+    with backend_ctx:
         engine.run()
         loss = outer.training_step(outer.cur_batch)
     assert len(calls) == 20  # 2000 iterations / unroll 100
