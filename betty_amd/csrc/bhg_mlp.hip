@@ -57,6 +57,7 @@ struct GemmArgs {
   float addend_scale;
   int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
   const double* scal;   // BF instances: device scalars (beta)
+  int nt_out;           // k_gemm: non-temporal stores of the partial slabs (experiment switch BHG_NT_SLABS)
   int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
                         // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
 };
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
         if (row < a.M) {
           float v = acc[t * KI][rg] + acc[t * KI + 1][rg];
           if (a.addend) v += a.addend_scale * a.addend[(int64_t)row * a.ldo + col];
-          out[(int64_t)row * a.ldo + col] = v;
+          if (a.nt_out) __builtin_nontemporal_store(v, &out[(int64_t)row * a.ldo + col]);   // A/B: stream the slab out
+          else out[(int64_t)row * a.ldo + col] = v;
         }
       }
     }
@@ -704,6 +706,93 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
   }
 }
 
+// ---- fused CG solver: step length BEFORE the weight-shaped outputs, direction update after them -------------------
+// p.(H p) from batch-sized factors of the R-chain (no N-sized H p exists in the fused solver):
+//   p.Hp = sum_b Rz_b . Rd_L,b  +  2 sum_{l>=1} <delta_l V_l, Rh_{l-1}>  +  shift * p.p
+// (second directional derivative of the loss: the Gauss-Newton term through the softmax-CE Hessian plus the
+//  layer-bilinear terms; the identity is checked in fp64 by tests/test_host_logic.py against p . autograd-HVP).
+// den = cg_alpha * p.Hp, alpha = rr / den with fp32 division of the fp32-rounded dots, as the reference does
+// (cg.py:42-47).  One workgroup; every partial array is summed in a fixed order.
+struct AlphaArgs {
+  const double* partT1; const double* partT2h; int B;
+  const double* partT2; int nT2;
+  const double* partPP; int nPP;   // nPP = 0: p.p = scal[S_PP] (written by k_cg_beta for the lazy direction)
+  const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
+  float cg_alpha, shift;
+  double* scal;
+  // Rz(x) = sum_k alpha_k Rz(p_k): x is a linear combination of the directions and the head kernel computes Rz of
+  // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
+  const float* rz; double* rzx; int nrz; int first;
+};
+using gu32 = __attribute__((address_space(1))) unsigned;
+using gf64 = __attribute__((address_space(1))) double;
+// ATOMIC_T2: called by the LAST-arriving workgroup of the final R-backward reduce (k_reduce_mask_t2): the T2 partials of
+// the other workgroups of that launch were published as 8-byte agent-scope atomic stores and are read the same way
+// (MI355X_MICROARCH.md "8-B agent atomics both sides"); everything else was written by earlier launches.
+template <bool ATOMIC_T2>
+__device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
+  __shared__ double red[5][kWaves];
+  __shared__ float s_alpha;
+  // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
+  // one wave reduction per quantity and a fixed-order combine of the wave results
+  // the Rz(x) accumulation's operands do not depend on alpha: their loads go out first
+  constexpr int kRzPer = 8;
+  float rzv[kRzPer];
+  double rzxv[kRzPer];
+#pragma unroll
+  for (int u = 0; u < kRzPer; ++u) {
+    const int i = threadIdx.x + u * kThreads;
+    rzv[u] = i < a.nrz ? a.rz[i] : 0.f;
+    rzxv[u] = (i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
+  }
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
+  if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
+  for (int i = threadIdx.x; i < a.nT2; i += kThreads)
+    acc[2] += ATOMIC_T2 ? __hip_atomic_load((gf64*)(a.partT2 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.partT2[i];
+  if (a.shift != 0.f) for (int i = threadIdx.x; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
+  for (int i = threadIdx.x; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double v = wave_sum(acc[q]);
+    if (lane == 0) red[q][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWaves; ++i) t += red[q][i];
+      tot[q] = t;
+    }
+    const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
+    const double pp = a.nPP > 0 ? tot[3] : a.scal[S_PP];
+    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
+    const double den = (double)a.cg_alpha * php;
+    const float alpha = (float)rr / (float)den;
+    a.scal[S_ALPHA_PREV] = a.scal[S_ALPHA];
+    a.scal[S_RR_OLD] = rr;
+    a.scal[S_PHP] = den;
+    a.scal[S_ALPHA] = (double)alpha;
+    s_alpha = alpha;
+  }
+  __syncthreads();
+  const double al = (double)s_alpha;
+#pragma unroll
+  for (int u = 0; u < kRzPer; ++u) {
+    const int i = threadIdx.x + u * kThreads;
+    if (i < a.nrz) a.rzx[i] = rzxv[u] + al * (double)rzv[u];
+  }
+  for (int i = threadIdx.x + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
+    const double v = al * (double)a.rz[i];
+    a.rzx[i] = a.first ? v : a.rzx[i] + v;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) { alpha_body<false>(a); }
+
 // R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
 // G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
 //   out[m][n] = mask[m][n] * (G + Rd_l W_l)[m][n]            (rows >= B written as zero)
@@ -713,8 +802,12 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict__ part, int s0, int splits, int slab,
                                                         const float* __restrict__ mask, const float* __restrict__ rh,
                                                         float* __restrict__ out, int rows, int N, int B,
-                                                        double* __restrict__ partT2) {
+                                                        double* __restrict__ partT2, unsigned* __restrict__ ticket,
+                                                        int do_alpha, AlphaArgs aa) {
+  // do_alpha (the LAST reduce of the chain): the workgroup that arrives last also computes the step length (alpha_body) —
+  // one launch and its ~5 us floor less on the dependent chain.  Arrival = monotonic ticket, reset by the last arriver.
   __shared__ double red[kWaves];
+  __shared__ unsigned s_last;
   const int64_t total = (int64_t)rows * N / VEC;
   const int nv = N / VEC;
   double acc = 0.0;
@@ -753,7 +846,20 @@ __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict_
     else out[i] = v[0];
   }
   const double sblk = block_sum(acc, red);
-  if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
+  if (!do_alpha) {
+    if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store((gf64*)(partT2 + blockIdx.x), 2.0 * sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add((gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1 ? 1u : 0u;
+    if (s_last) __hip_atomic_store((gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  alpha_body<true>(aa);
 }
 
 // Top of the network: Rz = sum_s part + c ; Rd_L = sd * (p*Rz - p (p.Rz)).
@@ -1215,6 +1321,8 @@ __global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ pro
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   GemmArgs a = a_in;
+  static const bool nt_slabs = getenv("BHG_NT_SLABS") != nullptr;
+  a.nt_out = nt_slabs ? 1 : 0;
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
   bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
   bool bf = false;
@@ -1275,85 +1383,6 @@ int pick_splits(int tiles, int K, int pairs) {
     }
   }
   return s;
-}
-
-// ---- fused CG solver: step length BEFORE the weight-shaped outputs, direction update after them -------------------
-// p.(H p) from batch-sized factors of the R-chain (no N-sized H p exists in the fused solver):
-//   p.Hp = sum_b Rz_b . Rd_L,b  +  2 sum_{l>=1} <delta_l V_l, Rh_{l-1}>  +  shift * p.p
-// (second directional derivative of the loss: the Gauss-Newton term through the softmax-CE Hessian plus the
-//  layer-bilinear terms; the identity is checked in fp64 by tests/test_host_logic.py against p . autograd-HVP).
-// den = cg_alpha * p.Hp, alpha = rr / den with fp32 division of the fp32-rounded dots, as the reference does
-// (cg.py:42-47).  One workgroup; every partial array is summed in a fixed order.
-struct AlphaArgs {
-  const double* partT1; const double* partT2h; int B;
-  const double* partT2; int nT2;
-  const double* partPP; int nPP;   // nPP = 0: p.p = scal[S_PP] (written by k_cg_beta for the lazy direction)
-  const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
-  float cg_alpha, shift;
-  double* scal;
-  // Rz(x) = sum_k alpha_k Rz(p_k): x is a linear combination of the directions and the head kernel computes Rz of
-  // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
-  const float* rz; double* rzx; int nrz; int first;
-};
-__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
-  __shared__ double red[5][kWaves];
-  __shared__ float s_alpha;
-  // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
-  // one wave reduction per quantity and a fixed-order combine of the wave results
-  // the Rz(x) accumulation's operands do not depend on alpha: their loads go out first
-  constexpr int kRzPer = 8;
-  float rzv[kRzPer];
-  double rzxv[kRzPer];
-#pragma unroll
-  for (int u = 0; u < kRzPer; ++u) {
-    const int i = threadIdx.x + u * kThreads;
-    rzv[u] = i < a.nrz ? a.rz[i] : 0.f;
-    rzxv[u] = (i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
-  }
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
-  if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
-  for (int i = threadIdx.x; i < a.nT2; i += kThreads) acc[2] += a.partT2[i];
-  if (a.shift != 0.f) for (int i = threadIdx.x; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
-  for (int i = threadIdx.x; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const double v = wave_sum(acc[q]);
-    if (lane == 0) red[q][w] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWaves; ++i) t += red[q][i];
-      tot[q] = t;
-    }
-    const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
-    const double pp = a.nPP > 0 ? tot[3] : a.scal[S_PP];
-    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
-    const double den = (double)a.cg_alpha * php;
-    const float alpha = (float)rr / (float)den;
-    a.scal[S_ALPHA_PREV] = a.scal[S_ALPHA];
-    a.scal[S_RR_OLD] = rr;
-    a.scal[S_PHP] = den;
-    a.scal[S_ALPHA] = (double)alpha;
-    s_alpha = alpha;
-  }
-  __syncthreads();
-  const double al = (double)s_alpha;
-#pragma unroll
-  for (int u = 0; u < kRzPer; ++u) {
-    const int i = threadIdx.x + u * kThreads;
-    if (i < a.nrz) a.rzx[i] = rzxv[u] + al * (double)rzv[u];
-  }
-  for (int i = threadIdx.x + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
-    const double v = al * (double)a.rz[i];
-    a.rzx[i] = a.first ? v : a.rzx[i] + v;
-  }
 }
 
 // coeff[b] = scale * (prob_b - onehot(y_b)) . RzX_b / B   (mixed-derivative coefficient from the accumulated Rz(x))
@@ -1532,6 +1561,7 @@ int reduce_blocks(int slab, int N) {
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
+  unsigned* ticket;                 // arrival counter of the last R-backward reduce (zero between launches)
   float* rz; double* rzx;           // [Bp][dims[L]]: Rz of the current direction / accumulated Rz(x)
   int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
@@ -1554,6 +1584,7 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   for (int l = 1; l + 1 < m->L; ++l) { w->t2_off[l] = nt2; nt2 += reduce_blocks(m->Bp * m->dims[l], m->dims[l]); }
   w->nT2 = nt2;
   w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
+  w->ticket = static_cast<unsigned*>(take(256));
   w->rz = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * m->dims[m->L]));
   w->rzx = static_cast<double*>(take(sizeof(double) * (size_t)m->Bp * m->dims[m->L]));
   w->bytes = off;
@@ -1754,6 +1785,19 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
   };
 
+  // fused CG: the step length from the batch-sized factors (k_cg_alpha / alpha_body) — computed by the last workgroup of
+  // the chain's last reduce when there is one, by a launch of its own otherwise (BHG_CG_ALPHA_KERNEL forces the latter)
+  AlphaArgs aa{};
+  static const bool alpha_in_reduce = getenv("BHG_CG_ALPHA_KERNEL") == nullptr;
+  bool alpha_done = false;
+  if (cg) {
+    aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
+    aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
+    aa.partPP = cm.partPP; aa.nPP = cm.nPP;
+    aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
+    aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
+    aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first;
+  }
   // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
   for (int l = L - 1; l >= 1; --l) {
     if (!single) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
@@ -1788,29 +1832,24 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     if (cg) {
       const int blocks = reduce_blocks(slab, N);
       double* pt2 = cm.ws->partT2 + cm.ws->t2_off[l];
+      const int do_alpha = alpha_in_reduce && l == 1;   // the last reduce of the chain: its last workgroup computes alpha
+      if (do_alpha) alpha_done = true;
       if ((N & 3) == 0)
         hipLaunchKernelGGL(k_reduce_mask_t2<4>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
-                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2,
+                           cm.ws->ticket, do_alpha, aa);
       else
         hipLaunchKernelGGL(k_reduce_mask_t2<1>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
-                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2,
+                           cm.ws->ticket, do_alpha, aa);
     } else {
       launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
     }
   }
 
   if (single) {
-    if (cg) {
-      // ---- step length from the batch-sized factors, then every weight-shaped output with the recurrence in its epilogue
-      AlphaArgs aa{};
-      aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
-      aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
-      aa.partPP = cm.partPP; aa.nPP = cm.nPP;
-      aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
-      aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
-      aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first;
-      hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
-    }
+    // ---- step length known: every weight-shaped output with the recurrence in its epilogue
+    if (cg && !alpha_done) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
