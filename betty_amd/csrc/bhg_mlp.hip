@@ -57,7 +57,7 @@ struct GemmArgs {
   float addend_scale;
   int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
   const double* scal;   // BF instances: device scalars (beta)
-  int nt_out;           // k_gemm: non-temporal stores of the partial slabs (experiment switch BHG_NT_SLABS)
+  int nt_out;           // k_gemm: non-temporal stores of the partial slabs
   int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
                         // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
 };
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
         if (row < a.M) {
           float v = acc[t * KI][rg] + acc[t * KI + 1][rg];
           if (a.addend) v += a.addend_scale * a.addend[(int64_t)row * a.ldo + col];
-          if (a.nt_out) __builtin_nontemporal_store(v, &out[(int64_t)row * a.ldo + col]);   // A/B: stream the slab out
+          if (a.nt_out) __builtin_nontemporal_store(v, &out[(int64_t)row * a.ldo + col]);
           else out[(int64_t)row * a.ldo + col] = v;
         }
       }
@@ -724,13 +724,10 @@ struct AlphaArgs {
   // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
   const float* rz; double* rzx; int nrz; int first;
 };
-using gu32 = __attribute__((address_space(1))) unsigned;
-using gf64 = __attribute__((address_space(1))) double;
-// ATOMIC_T2: called by the LAST-arriving workgroup of the final R-backward reduce (k_reduce_mask_t2): the T2 partials of
-// the other workgroups of that launch were published as 8-byte agent-scope atomic stores and are read the same way
-// (MI355X_MICROARCH.md "8-B agent atomics both sides"); everything else was written by earlier launches.
-template <bool ATOMIC_T2>
-__device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
+// (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
+//  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
+//  launch cost, 264.7 vs 265.3 steps/s in a same-box A/B.)
+__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
   __shared__ double red[5][kWaves];
   __shared__ float s_alpha;
   // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
@@ -749,7 +746,7 @@ __device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
   for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
   if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
   for (int i = threadIdx.x; i < a.nT2; i += kThreads)
-    acc[2] += ATOMIC_T2 ? __hip_atomic_load((gf64*)(a.partT2 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.partT2[i];
+    acc[2] += a.partT2[i];
   if (a.shift != 0.f) for (int i = threadIdx.x; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
   for (int i = threadIdx.x; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -791,7 +788,6 @@ __device__ __forceinline__ void alpha_body(const AlphaArgs& a) {
     a.rzx[i] = a.first ? v : a.rzx[i] + v;
   }
 }
-__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) { alpha_body<false>(a); }
 
 // R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
 // G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
@@ -802,12 +798,8 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict__ part, int s0, int splits, int slab,
                                                         const float* __restrict__ mask, const float* __restrict__ rh,
                                                         float* __restrict__ out, int rows, int N, int B,
-                                                        double* __restrict__ partT2, unsigned* __restrict__ ticket,
-                                                        int do_alpha, AlphaArgs aa) {
-  // do_alpha (the LAST reduce of the chain): the workgroup that arrives last also computes the step length (alpha_body) —
-  // one launch and its ~5 us floor less on the dependent chain.  Arrival = monotonic ticket, reset by the last arriver.
+                                                        double* __restrict__ partT2) {
   __shared__ double red[kWaves];
-  __shared__ unsigned s_last;
   const int64_t total = (int64_t)rows * N / VEC;
   const int nv = N / VEC;
   double acc = 0.0;
@@ -846,20 +838,7 @@ __global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict_
     else out[i] = v[0];
   }
   const double sblk = block_sum(acc, red);
-  if (!do_alpha) {
-    if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
-    return;
-  }
-  if (threadIdx.x == 0) {
-    __hip_atomic_store((gf64*)(partT2 + blockIdx.x), 2.0 * sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add((gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == gridDim.x - 1 ? 1u : 0u;
-    if (s_last) __hip_atomic_store((gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  alpha_body<true>(aa);
+  if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
 }
 
 // Top of the network: Rz = sum_s part + c ; Rd_L = sd * (p*Rz - p (p.Rz)).
@@ -1321,8 +1300,10 @@ __global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ pro
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   GemmArgs a = a_in;
-  static const bool nt_slabs = getenv("BHG_NT_SLABS") != nullptr;
-  a.nt_out = nt_slabs ? 1 : 0;
+  // split-K slabs leave with non-temporal stores: they stream out while the kernel runs instead of sitting dirty in L2
+  // until its end (same-box A/B: 3.707 vs 3.778 ms per step; BHG_NO_NT_SLABS restores plain stores)
+  static const bool nt_slabs = getenv("BHG_NO_NT_SLABS") == nullptr;
+  a.nt_out = (nt_slabs && (a.splits > 1 || a.out_rows > 0)) ? 1 : 0;
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
   bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
   bool bf = false;
@@ -1561,7 +1542,6 @@ int reduce_blocks(int slab, int N) {
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
-  unsigned* ticket;                 // arrival counter of the last R-backward reduce (zero between launches)
   float* rz; double* rzx;           // [Bp][dims[L]]: Rz of the current direction / accumulated Rz(x)
   int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
@@ -1584,7 +1564,6 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   for (int l = 1; l + 1 < m->L; ++l) { w->t2_off[l] = nt2; nt2 += reduce_blocks(m->Bp * m->dims[l], m->dims[l]); }
   w->nT2 = nt2;
   w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
-  w->ticket = static_cast<unsigned*>(take(256));
   w->rz = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * m->dims[m->L]));
   w->rzx = static_cast<double*>(take(sizeof(double) * (size_t)m->Bp * m->dims[m->L]));
   w->bytes = off;
@@ -1785,11 +1764,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     else hipLaunchKernelGGL(k_bias_hvp<FUSE_NONE>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
   };
 
-  // fused CG: the step length from the batch-sized factors (k_cg_alpha / alpha_body) — computed by the last workgroup of
-  // the chain's last reduce when there is one, by a launch of its own otherwise (BHG_CG_ALPHA_KERNEL forces the latter)
-  AlphaArgs aa{};
-  static const bool alpha_in_reduce = getenv("BHG_CG_ALPHA_KERNEL") == nullptr;
-  bool alpha_done = false;
+  AlphaArgs aa{};   // fused CG: the step length from the batch-sized factors (k_cg_alpha)
   if (cg) {
     aa.partT1 = cm.ws->partT1; aa.partT2h = L >= 2 ? cm.ws->partT2h : nullptr; aa.B = B;
     aa.partT2 = cm.ws->partT2; aa.nT2 = cm.ws->nT2;
@@ -1832,16 +1807,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     if (cg) {
       const int blocks = reduce_blocks(slab, N);
       double* pt2 = cm.ws->partT2 + cm.ws->t2_off[l];
-      const int do_alpha = alpha_in_reduce && l == 1;   // the last reduce of the chain: its last workgroup computes alpha
-      if (do_alpha) alpha_done = true;
       if ((N & 3) == 0)
         hipLaunchKernelGGL(k_reduce_mask_t2<4>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
-                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2,
-                           cm.ws->ticket, do_alpha, aa);
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
       else
         hipLaunchKernelGGL(k_reduce_mask_t2<1>, dim3(blocks), dim3(256), 0, st, (const float*)m->partial, a.pair_split, a.splits,
-                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2,
-                           cm.ws->ticket, do_alpha, aa);
+                           slab, (const float*)m->mask[l - 1], (const float*)m->Rh[l - 1], m->Rd[l - 1], Bp, N, B, pt2);
     } else {
       launch_reduce_mask(st, m->partial, a.splits, slab, nullptr, m->mask[l - 1], m->Rd[l - 1], Bp, N, B);
     }
@@ -1849,7 +1820,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
 
   if (single) {
     // ---- step length known: every weight-shaped output with the recurrence in its epilogue
-    if (cg && !alpha_done) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    if (cg) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
