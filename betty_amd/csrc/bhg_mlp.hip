@@ -377,7 +377,11 @@ __device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float 
     av = nr; bv = nx;
   } else {
     const float nv = fz_sub(dv, fz_mul(alpha, hv));
-    float np = fz_add(nv, bv);
+    // x_mode for Neumann: 1 = leave the accumulator p alone this iteration, 2 = catch up: p = (p + v_in) + v' — v_in is
+    // last iteration's v' (the direction just read), so these are the very roundings of two separate p += v' updates
+    float np = bv;
+    if (f.x_mode == 2) np = fz_add(np, dv);
+    if (f.x_mode != 1) np = fz_add(np, nv);
     if (f.apply_out) np = fz_mul(f.out_scale, np);
     av = nv; bv = np;
   }
@@ -558,7 +562,7 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
     const float alpha = fuse_alpha<MODE>(fz);
     const float beta = fuse_beta<MODE>(fz);
     const bool wr_d = MODE == FUSE_CG && fz.lazy;
-    const bool use_x = !(MODE == FUSE_CG && fz.x_mode == 1);   // workgroup-uniform
+    const bool use_x = fz.x_mode != 1 || MODE == FUSE_NONE;   // workgroup-uniform
     const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_PREV] : 0.f;
     FuseAcc racc{0.0, 0.0, 0.0};
 #pragma unroll
@@ -1627,7 +1631,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       f.a = cm.fa + o; f.b = cm.fb + o; f.d = cm.fd + o;
       // lazy direction: only the MFMA layers' weight slices (the small slices were updated by k_cg_beta)
       f.lazy = cm.lazy && (tensor & 1) == 0 && !(head && tensor == 2 * (L - 1));
-      f.x_mode = f.lazy ? cm.x_mode : 0;
+      f.x_mode = (f.lazy || cm.mode == FUSE_NEUMANN) ? cm.x_mode : 0;
     }
     f.part_base = part_base;
     return f;
@@ -2041,6 +2045,9 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     cm.fa = vout; cm.fb = p; cm.fd = vin; cm.starts = starts;
     cm.alpha = alpha; cm.shift = hvp_shift;
     cm.apply_out = k == K - 1; cm.out_scale = -alpha;   // neumann.py:66 and the negation of neumann.py:45/54
+    // the accumulator p is read and written every OTHER iteration (FuseArgs.x_mode): even iterations defer, odd catch up
+    static const bool p_every = getenv("BHG_NEUMANN_P_EVERY_ITER") != nullptr;   // A/B switch
+    cm.x_mode = p_every ? 0 : ((k & 1) ? 2 : (k + 1 < K ? 1 : 0));
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   }

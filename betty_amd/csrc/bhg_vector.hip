@@ -327,7 +327,12 @@ __global__ __launch_bounds__(kThreads) void k_cg_dir(const bhg_chunk* __restrict
 constexpr int kResThreads = 512;
 constexpr int kResWaves = kResThreads / 64;
 constexpr int kResV = kChunk / (kResThreads * 4);  // float4 per thread per chunk = 2
-constexpr int kResMax = 11;   // chunks per workgroup; 2 x 11 x 2 float4 = 176 VGPRs of state (252 total, no spill)
+constexpr int kResMax = 11;   // chunks per workgroup, register-only instance; 2 x 11 x 2 float4 = 176 VGPRs of state (252 total, no spill)
+// LDS-assisted instance (round 2): the direction slices of the first kResLds slots are parked in the CU's otherwise
+// unused LDS (9 x 16 KiB = 144 KiB) instead of registers, which frees registers for more Hp/r' slots:
+// 15 slots = 15 x 8 (Hp) + 6 x 8 (p in registers) = 168 VGPRs of state -> 15.7 M elements at 28*N bytes.
+constexpr int kResMaxLds = 15;
+constexpr int kResLds = 9;
 
 __device__ __forceinline__ double block_sum_res(double v, double* red) {
   v = wave_sum(v);
@@ -383,7 +388,7 @@ __device__ __forceinline__ double grid_wait_sum(const double* part, unsigned* co
 // i+1 above the stores of chunk i to the same array itself, so the pipeline is explicit.
 constexpr int kResDepth = 3;
 constexpr unsigned kSpinLimit = 1u << 22;  // ~4 s of polling before a grid barrier gives up
-template <typename F>
+template <int NSLOT, typename F>
 __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const bhg_chunk* __restrict__ chunks,
                                                 int n_chunks, F f) {
   const int G = gridDim.x;
@@ -393,20 +398,20 @@ __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const b
     const int c = blockIdx.x + d * G;
 #pragma unroll
     for (int j = 0; j < kResV; ++j) buf[d][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d < kResMax && c < n_chunks) {
+    if (d < NSLOT && c < n_chunks) {
       const bhg_chunk ck = chunks[c];
 #pragma unroll
       for (int j = 0; j < kResV; ++j) buf[d][j] = ld4(vec + ck.flat_off, 4 * (threadIdx.x + kResThreads * j), ck.len);
     }
   }
 #pragma unroll
-  for (int i = 0; i < kResMax; ++i) {
+  for (int i = 0; i < NSLOT; ++i) {
     const int c = blockIdx.x + i * G;
     float4 cur[kResV];
 #pragma unroll
     for (int j = 0; j < kResV; ++j) cur[j] = buf[i % kResDepth][j];
     const int cn = c + kResDepth * G;
-    if (i + kResDepth < kResMax && cn < n_chunks) {
+    if (i + kResDepth < NSLOT && cn < n_chunks) {
       const bhg_chunk ckn = chunks[cn];
 #pragma unroll
       for (int j = 0; j < kResV; ++j)
@@ -423,6 +428,7 @@ __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const b
   }
 }
 
+template <int NSLOT, int NLDS>
 __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
     float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale, float shift,
@@ -430,17 +436,22 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     double* __restrict__ partP, unsigned* __restrict__ barrier_words, double* __restrict__ scal,
     unsigned spin_limit) {
   __shared__ double red[kResWaves];
+  extern __shared__ __attribute__((aligned(16))) float4 sq[];   // NLDS x kResV x 512 float4: parked direction slices
   const int G = gridDim.x;
 
-  float4 h[kResMax][kResV], q[kResMax][kResV];
+  float4 h[NSLOT][kResV], q[NSLOT - NLDS][kResV];
+  // direction slice of slot i: LDS for the first NLDS slots (conflict-free: consecutive lanes, consecutive 16 B), else
+  // registers; i is a compile-time constant in every (fully unrolled) use
+  auto Q = [&](int i, int j) -> float4 { return i < NLDS ? sq[(i * kResV + j) * kResThreads + threadIdx.x] : q[i - NLDS < 0 ? 0 : i - NLDS][j]; };
   // ---- phase 1: load Hp, p once (all loads in flight together); den = (cg_alpha*Hp).p
 #pragma unroll
-  for (int i = 0; i < kResMax; ++i) {
+  for (int i = 0; i < NSLOT; ++i) {
     const int c = blockIdx.x + i * G;
+    float4 qv[kResV];
 #pragma unroll
     for (int j = 0; j < kResV; ++j) {
       h[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      q[i][j] = h[i][j];
+      qv[j] = h[i][j];
     }
     if (c < n_chunks) {
       const bhg_chunk ck = chunks[c];
@@ -449,8 +460,13 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
       for (int j = 0; j < kResV; ++j) {
         const int e = 4 * (threadIdx.x + kResThreads * j);
         h[i][j] = ld4(hs, e, ck.len);
-        q[i][j] = ld4(p + ck.flat_off, e, ck.len);
+        qv[j] = ld4(p + ck.flat_off, e, ck.len);
       }
+    }
+#pragma unroll
+    for (int j = 0; j < kResV; ++j) {
+      if (i < NLDS) sq[(i * kResV + j) * kResThreads + threadIdx.x] = qv[j];   // each thread reads back only its own entries
+      else q[i - NLDS < 0 ? 0 : i - NLDS][j] = qv[j];
     }
   }
   // numerator r.r from the previous producer (k_cg_init or the previous iteration); these
@@ -464,15 +480,16 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
   }
   double acc = 0.0;
 #pragma unroll
-  for (int i = 0; i < kResMax; ++i) {
+  for (int i = 0; i < NSLOT; ++i) {
 #pragma unroll
     for (int j = 0; j < kResV; ++j) {
+      const float4 qq = Q(i, j);
       if (shift != 0.f) {  // H p = (raw HVP) + shift * p: the Hessian's diagonal part never round-trips through HBM
-        h[i][j].x = add_rn(h[i][j].x, mul_rn(shift, q[i][j].x)); h[i][j].y = add_rn(h[i][j].y, mul_rn(shift, q[i][j].y));
-        h[i][j].z = add_rn(h[i][j].z, mul_rn(shift, q[i][j].z)); h[i][j].w = add_rn(h[i][j].w, mul_rn(shift, q[i][j].w));
+        h[i][j].x = add_rn(h[i][j].x, mul_rn(shift, qq.x)); h[i][j].y = add_rn(h[i][j].y, mul_rn(shift, qq.y));
+        h[i][j].z = add_rn(h[i][j].z, mul_rn(shift, qq.z)); h[i][j].w = add_rn(h[i][j].w, mul_rn(shift, qq.w));
       }
-      acc += (double)mul_rn(cg_alpha, h[i][j].x) * q[i][j].x + (double)mul_rn(cg_alpha, h[i][j].y) * q[i][j].y +
-             (double)mul_rn(cg_alpha, h[i][j].z) * q[i][j].z + (double)mul_rn(cg_alpha, h[i][j].w) * q[i][j].w;
+      acc += (double)mul_rn(cg_alpha, h[i][j].x) * qq.x + (double)mul_rn(cg_alpha, h[i][j].y) * qq.y +
+             (double)mul_rn(cg_alpha, h[i][j].z) * qq.z + (double)mul_rn(cg_alpha, h[i][j].w) * qq.w;
     }
   }
   grid_arrive(block_sum_res(acc, red), partP, barrier_words);
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
 
   // ---- phase 2a: r' = r - a*Hp (kept in h, stored once) ; partial r'.r' ; ARRIVE
   acc = 0.0;
-  resident_stream(r, chunks, n_chunks, [&](int i, int j, float4 rv) {
+  resident_stream<NSLOT>(r, chunks, n_chunks, [&](int i, int j, float4 rv) {
     float4 nr;
     nr.x = sub_rn(rv.x, mul_rn(alpha, h[i][j].x)); nr.y = sub_rn(rv.y, mul_rn(alpha, h[i][j].y));
     nr.z = sub_rn(rv.z, mul_rn(alpha, h[i][j].z)); nr.w = sub_rn(rv.w, mul_rn(alpha, h[i][j].w));
@@ -493,10 +510,11 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
   grid_arrive(block_sum_res(acc, red), partR_new, barrier_words);
 
   // ---- phase 2b (hides the second barrier): x += a*p [x <- out_scale*x on the last step]
-  resident_stream(x, chunks, n_chunks, [&](int i, int j, float4 xv) {
+  resident_stream<NSLOT>(x, chunks, n_chunks, [&](int i, int j, float4 xv) {
+    const float4 qq = Q(i, j);
     float4 nx;
-    nx.x = add_rn(xv.x, mul_rn(alpha, q[i][j].x)); nx.y = add_rn(xv.y, mul_rn(alpha, q[i][j].y));
-    nx.z = add_rn(xv.z, mul_rn(alpha, q[i][j].z)); nx.w = add_rn(xv.w, mul_rn(alpha, q[i][j].w));
+    nx.x = add_rn(xv.x, mul_rn(alpha, qq.x)); nx.y = add_rn(xv.y, mul_rn(alpha, qq.y));
+    nx.z = add_rn(xv.z, mul_rn(alpha, qq.z)); nx.w = add_rn(xv.w, mul_rn(alpha, qq.w));
     if (out_scale != 0.f) {
       nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
       nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
@@ -509,16 +527,17 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
 
   // ---- phase 3: p = r' + b*p (registers only -> store)
 #pragma unroll
-  for (int i = 0; i < kResMax; ++i) {
+  for (int i = 0; i < NSLOT; ++i) {
     const int c = blockIdx.x + i * G;
     if (c < n_chunks) {
       const bhg_chunk ck = chunks[c];
 #pragma unroll
       for (int j = 0; j < kResV; ++j) {
         const int e = 4 * (threadIdx.x + kResThreads * j);
+        const float4 qq = Q(i, j);
         float4 np;
-        np.x = add_rn(h[i][j].x, mul_rn(beta, q[i][j].x)); np.y = add_rn(h[i][j].y, mul_rn(beta, q[i][j].y));
-        np.z = add_rn(h[i][j].z, mul_rn(beta, q[i][j].z)); np.w = add_rn(h[i][j].w, mul_rn(beta, q[i][j].w));
+        np.x = add_rn(h[i][j].x, mul_rn(beta, qq.x)); np.y = add_rn(h[i][j].y, mul_rn(beta, qq.y));
+        np.z = add_rn(h[i][j].z, mul_rn(beta, qq.z)); np.w = add_rn(h[i][j].w, mul_rn(beta, qq.w));
         st4(p + ck.flat_off, e, ck.len, np);
       }
     }
@@ -826,7 +845,7 @@ static unsigned spin_limit() {
   return v;
 }
 
-int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMax; }
+int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMaxLds; }
 
 // One-time residency census (MI355X_MICROARCH.md "Residency and cooperative launch": size grid-barrier
 // grids from measured residency, never from the occupancy API alone): launch the real resident kernel on
@@ -853,7 +872,7 @@ int bhg_cg_resident_ok(void) {
     double* partR = reinterpret_cast<double*>(w + kWsPartR);
     PtrTab tab;
     memset(&tab, 0, sizeof(tab));
-    hipLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, nullptr, tab, (const bhg_chunk*)nullptr, 0,
+    hipLaunchKernelGGL((k_cg_resident<kResMax, 0>), dim3(G), dim3(kResThreads), 0, nullptr, tab, (const bhg_chunk*)nullptr, 0,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, 1.0f, 0, 0.0f, 0.0f,
                        (const double*)partR, partR + kMaxBlocks, reinterpret_cast<double*>(w + kWsPartP),
                        reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal),
@@ -920,10 +939,25 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
                           out_scale, scal, reinterpret_cast<unsigned*>(w + kWsBarrier), 2u * (unsigned)num_cus());
   } else {
     const int G = num_cus();
-    hipExtLaunchKernelGGL(k_cg_resident, dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
-                          timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
-                          hvp_shift, (const double*)partR_old, partR_new, partP,
-                          reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
+    if (n_chunks <= G * kResMax) {   // register-only instance: fastest while it fits (11.5 M elements)
+      hipExtLaunchKernelGGL((k_cg_resident<kResMax, 0>), dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
+                            timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
+                            hvp_shift, (const double*)partR_old, partR_new, partP,
+                            reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
+    } else {                         // LDS-assisted instance: 9 direction slices per workgroup parked in LDS (15.7 M elements)
+      static bool attr_set[kMaxDevices];
+      const int dev = current_device();
+      constexpr size_t lds = (size_t)kResLds * kResV * kResThreads * sizeof(float4);
+      if (dev >= 0 && !attr_set[dev]) {
+        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResMaxLds, kResLds>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+      }
+      hipExtLaunchKernelGGL((k_cg_resident<kResMaxLds, kResLds>), dim3(G), dim3(kResThreads), lds, st, timed ? ea : nullptr,
+                            timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
+                            hvp_shift, (const double*)partR_old, partR_new, partP,
+                            reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
+    }
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;

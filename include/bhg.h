@@ -105,7 +105,8 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
  * After the call ws holds the iteration's scalars (see bhg_cg_read_scalars).      */
 #define BHG_CG_AUTO 0
 #define BHG_CG_STREAM 1     /* 3 streaming kernels, 40*N bytes per iteration         */
-#define BHG_CG_RESIDENT 2   /* 1 persistent kernel, 28*N bytes, N <= on-chip capacity */
+#define BHG_CG_RESIDENT 2   /* 1 persistent kernel, 28*N bytes, N <= on-chip capacity: registers only up to
+                               11 chunks per CU, 15 with 9 direction slices per CU parked in LDS */
 int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, void* ws, void* stream);
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,

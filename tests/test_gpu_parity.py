@@ -326,6 +326,40 @@ def test_cg_full_size_diagonal_hessian_converges_exactly(variant, be):
     assert int(ws_timeout.item()) == 0, "grid barrier timed out"
 
 
+def test_cg_resident_lds_assisted_instance(be):
+    """N = 15.1 M (1.5 x the cfg-2 tensor list) exceeds the register-only resident capacity (11.5 M) and fits the
+    LDS-assisted instance (9 of 15 direction slices per workgroup parked in LDS): same closed form, bitwise equal to
+    the streaming kernels iteration by iteration is not required (different summation grouping of the dots), but the
+    solve must be exact to fp32 CG accuracy, bit-reproducible, and must not time out."""
+    sizes = CFG2_SIZES + [5_000_000, 4097, 63]
+    N = sum(sizes)
+    gen = torch.Generator().manual_seed(11)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
+    diag = [dvals[torch.arange(n, device=DEV) % 4] for n in sizes]
+    lay = be.layout(vec)
+    G = be.lib.bhg_cg_resident_capacity_chunks() // 15
+    if not be.lib.bhg_cg_resident_ok() or not (11 * G < lay.n_chunks <= 15 * G):
+        pytest.skip("size does not select the LDS-assisted instance on this device")
+    outs = []
+    for variant in ("resident", "resident", "stream"):
+        x, r, p = lay.state(3)
+        be.cg_init(lay, vec, x, r, p)
+        K = 4
+        for k in range(K):
+            hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
+            be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == K - 1 else 0.0), variant=VARIANTS[variant])
+            lay._cg_variant = None
+        assert not be.cg_barrier_timed_out(lay)
+        outs.append(x.clone())
+        for xv, v, d in zip(lay.views(x, vec), vec, diag):
+            want = -(v / d)
+            assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item(), (variant, N)
+    assert torch.equal(outs[0], outs[1]), "the resident kernel must be bit-reproducible"
+    rel = (outs[0] - outs[2]).norm() / outs[2].norm()
+    assert rel <= 1e-6, rel
+
+
 def test_neumann_full_size_closed_form(be):
     """H = diag(d): p_K = sum_{j<=K} (1 - alpha d)^j v, result = -alpha p_K (fp32 geometric sum)."""
     gen = torch.Generator().manual_seed(6)
