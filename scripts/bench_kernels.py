@@ -41,11 +41,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--scale", type=int, default=1, help="replicate the tensor list (bigger N)")
+    ap.add_argument("--extra", type=int, default=0, help="append one tensor of this many elements (e.g. 5000000 -> N = 15 M: "
+                    "beyond the register-only resident capacity, inside the LDS-assisted one)")
     ap.add_argument("--scrub-mb", type=int, default=0, help="cache-defeated mode: copy 2 x this many MiB before every launch")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
-    sizes = SIZES * args.scale
+    sizes = SIZES * args.scale + ([args.extra] if args.extra > 0 else [])
     N = sum(sizes)
     gen = torch.Generator().manual_seed(0)
     vec = [torch.randn(n, generator=gen).to(dev) for n in sizes]
