@@ -371,12 +371,12 @@ def main():
         roof = None
         mall_note = ("working set (x, r, p, W, activations = %.0f MB) is smaller than the 256 MiB Infinity Cache: this is "
                      "fabric-side bandwidth on cache-resident data, quoted against the 8 TB/s HBM peak as north_star asks; "
-                     "cache-defeated figures: profiles/r02_cache_defeated.json" % ((3 * 4 * N + 4 * N + 8e6) / 1e6))
+                     "cache-defeated figures: profiles/r02_bench_kernels_N10M_cache_defeated.json" % ((3 * 4 * N + 4 * N + 8e6) / 1e6))
         if fused and args.algo == "cg" and "cg_iter" in spans:
             us, n = spans["cg_iter"]
             alg = rec_bytes + 20.0 * N
-            roof = {"bound": "hbm", "kernel": "bhg_mlp_cg_solve: one fused CG-HVP iteration (HVP chain with r/x update in its "
-                    "output kernels + k_cg_pdir)", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "bhg_mlp_cg_solve: one fused CG-HVP iteration (k_cg_beta + HVP chain whose output kernels carry the "
+                    "r/x/p update)", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": pmc_traffic("cg_iter_fused", N),
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n, "note": mall_note}
         elif fused and args.algo == "neumann" and "hvp" in spans:

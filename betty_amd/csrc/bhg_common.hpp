@@ -29,7 +29,7 @@ inline size_t ws_bytes(int T) {
 }
 
 // scalar slots
-enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 /* fused solver: p.p of the coming direction */, S_ALPHA_PREV = 6 /* fused solver: last iteration's alpha */,
+enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 /* fused solver: p.p of the coming direction */, S_ALPHA_RING = 10 /* and 11: fused solver, alpha of iteration k in slot 10 + (k & 1) */,
        S_NPART0 = 8 /* and 9 */ };
 
 // ---- error plumbing -------------------------------------------------------------

@@ -343,7 +343,9 @@ struct FuseArgs {
   double* part;        // CG: per-workgroup partials -> part[q * part_stride + part_base + linear block id],
   int part_base;       //     q = 0: r'.r'   q = 1: r'.p   q = 2: p.p   (p = this iteration's direction)
   int part_stride;
-  float alpha;       // Neumann: step length (host constant)
+  float alpha;       // Neumann: step length (host constant); CG with alpha_ready: computed by the calling kernel itself
+  int alpha_ready;
+  int kpar;          // CG: iteration parity (alpha of iteration k lives in scal[S_ALPHA_RING + (k & 1)])
   float shift;       // operator = raw HVP + shift * I
   float out_scale;   // applied to x (CG) / p (Neumann) when apply_out != 0: the final scaling + negation of the solve
   int apply_out;
@@ -388,7 +390,7 @@ __device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float 
 }
 template <int MODE>
 __device__ __forceinline__ float fuse_alpha(const FuseArgs& f) {
-  return MODE == FUSE_CG ? (float)f.scal[S_ALPHA] : f.alpha;
+  return (MODE == FUSE_CG && !f.alpha_ready) ? (float)f.scal[S_ALPHA] : f.alpha;
 }
 template <int MODE>
 __device__ __forceinline__ float fuse_beta(const FuseArgs& f) {
@@ -563,7 +565,7 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
     const float beta = fuse_beta<MODE>(fz);
     const bool wr_d = MODE == FUSE_CG && fz.lazy;
     const bool use_x = fz.x_mode != 1 || MODE == FUSE_NONE;   // workgroup-uniform
-    const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_PREV] : 0.f;
+    const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_RING + (fz.kpar ^ 1)] : 0.f;
     FuseAcc racc{0.0, 0.0, 0.0};
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -727,11 +729,15 @@ struct AlphaArgs {
   // Rz(x) = sum_k alpha_k Rz(p_k): x is a linear combination of the directions and the head kernel computes Rz of
   // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
   const float* rz; double* rzx; int nrz; int first;
+  int kpar;   // iteration parity (S_ALPHA_RING slot)
 };
 // (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
 //  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
 //  launch cost, 264.7 vs 265.3 steps/s in a same-box A/B.)
-__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
+// All 256 threads of a workgroup call it and get alpha; `writer` additionally publishes the scalars and accumulates
+// Rz(x).  Every caller sums the same partials in the same order => the same alpha bit for bit, so k_outer_all lets
+// every workgroup compute it for itself (block 0 is the writer) instead of waiting for a launch of its own.
+__device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool writer) {
   __shared__ double red[5][kWaves];
   __shared__ float s_alpha;
   // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
@@ -743,8 +749,8 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
 #pragma unroll
   for (int u = 0; u < kRzPer; ++u) {
     const int i = threadIdx.x + u * kThreads;
-    rzv[u] = i < a.nrz ? a.rz[i] : 0.f;
-    rzxv[u] = (i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
+    rzv[u] = (writer && i < a.nrz) ? a.rz[i] : 0.f;
+    rzxv[u] = (writer && i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
   }
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
@@ -774,13 +780,16 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
     const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
     const double den = (double)a.cg_alpha * php;
     const float alpha = (float)rr / (float)den;
-    a.scal[S_ALPHA_PREV] = a.scal[S_ALPHA];
-    a.scal[S_RR_OLD] = rr;
-    a.scal[S_PHP] = den;
-    a.scal[S_ALPHA] = (double)alpha;
+    if (writer) {
+      a.scal[S_RR_OLD] = rr;
+      a.scal[S_PHP] = den;
+      a.scal[S_ALPHA] = (double)alpha;
+      a.scal[S_ALPHA_RING + a.kpar] = (double)alpha;
+    }
     s_alpha = alpha;
   }
   __syncthreads();
+  if (!writer) return s_alpha;
   const double al = (double)s_alpha;
 #pragma unroll
   for (int u = 0; u < kRzPer; ++u) {
@@ -791,7 +800,9 @@ __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) {
     const double v = al * (double)a.rz[i];
     a.rzx[i] = a.first ? v : a.rzx[i] + v;
   }
+  return s_alpha;
 }
+__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) { (void)alpha_compute(a, true); }
 
 // R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
 // G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
@@ -1272,22 +1283,33 @@ struct OuterAllArgs {
   HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
   FuseArgs bf;
 };
-static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
+static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) + sizeof(AlphaArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
 template <int MODE>
-__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
+__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba, AlphaArgs aa, int inline_alpha) {
   const int b = blockIdx.x;
   const int nw = oa.blk0[oa.n];
+  // fused CG: every workgroup derives the step length from the batch-sized partials itself (5 KB of L2-resident
+  // doubles) instead of waiting for a 5 us launch that does it once; workgroup 0 publishes it
+  float alpha = 0.f;
+  const bool own = MODE == FUSE_CG && inline_alpha;
+  if (own) alpha = alpha_compute(aa, b == 0);
   if (b < nw) {
     int i = 0;
     while (i + 1 < oa.n && b >= oa.blk0[i + 1]) ++i;
     const int t = b - oa.blk0[i];
-    outer_body<true, MODE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
+    FuseArgs f = oa.f[i];
+    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
+    outer_body<true, MODE>(oa.g[i], f, t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
   } else if (b < nw + oa.head_blocks) {
     const int t = b - nw;
-    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
-    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    FuseArgs f = oa.hf;
+    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
+    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, f, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    else head_outer_body<false, MODE>(oa.head, f, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
   } else {
-    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks);
+    FuseArgs f = oa.bf;
+    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
+    bias_body<MODE>(ba, f, b - nw - oa.head_blocks);
   }
 }
 
@@ -1588,6 +1610,7 @@ struct ChainMode {
   double* partRR_new;
   double* scal;
   float cg_alpha;
+  int kpar;                     // iteration parity
   int x_mode;                   // see FuseArgs.x_mode (applies to the lazy slices only)
   int first;                    // first iteration of a solve (Rz(x) accumulator is set, not added to)
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
@@ -1624,6 +1647,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
   fbase.out_scale = cm.out_scale; fbase.apply_out = cm.apply_out;
   fbase.part_stride = cg ? cm.ws->nRR : 0;
+  fbase.kpar = cm.kpar;
   auto fuse_at = [&](int tensor, int part_base) {
     FuseArgs f = fbase;
     if (cm.mode != FUSE_NONE) {
@@ -1775,7 +1799,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     aa.partPP = cm.partPP; aa.nPP = cm.nPP;
     aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
     aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
-    aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first;
+    aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first; aa.kpar = cm.kpar;
   }
   // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
   for (int l = L - 1; l >= 1; --l) {
@@ -1823,8 +1847,15 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   }
 
   if (single) {
-    // ---- step length known: every weight-shaped output with the recurrence in its epilogue
-    if (cg) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    // ---- the step length, then every weight-shaped output with the recurrence in its epilogue.  With the one-launch
+    // form every workgroup of k_outer_all computes alpha itself (BHG_CG_ALPHA_KERNEL: a launch of its own, A/B)
+    static const bool alpha_kernel = getenv("BHG_CG_ALPHA_KERNEL") != nullptr;
+    bool alpha_launched = false;
+    auto launch_alpha = [&]() {
+      if (cg && !alpha_launched) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+      alpha_launched = true;
+    };
+    if (alpha_kernel) launch_alpha();
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
@@ -1861,9 +1892,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.bf = bias_fz;
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
-      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
-      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba);
+      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba, aa, alpha_launched ? 0 : 1);
+      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba, aa, 0);
     } else {
+      launch_alpha();
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
     }
@@ -2015,6 +2047,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
     cm.first = k == 0;
+    cm.kpar = k & 1;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
     if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

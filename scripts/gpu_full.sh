@@ -47,3 +47,4 @@ f=$(ls /tmp/tr_n/*kernel_trace.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_outer_all | tee gpurun_out/timeline_neumann_fused.txt; fi
 bash scripts/gpu_pmc2.sh 2>&1 | tail -45
 bash scripts/gpu_pmc_sq.sh 2>&1 | tail -28
+timeout 300 python scripts/bench_kernels.py --scale 1 --extra 5000000 --iters 40 2>/dev/null > gpurun_out/bench_kernels_N15M.json; python -c "import json; d=json.load(open(\"gpurun_out/bench_kernels_N15M.json\")); print(\"N15M\", {k:(round(v[\"us\"],1), round(v[\"GBps\"])) for k,v in d[\"kernels\"].items()})"
