@@ -734,9 +734,6 @@ struct AlphaArgs {
 // (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
 //  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
 //  launch cost, 264.7 vs 265.3 steps/s in a same-box A/B.)
-// All 256 threads of a workgroup call it and get alpha; `writer` additionally publishes the scalars and accumulates
-// Rz(x).  Every caller sums the same partials in the same order => the same alpha bit for bit, so k_outer_all lets
-// every workgroup compute it for itself (block 0 is the writer) instead of waiting for a launch of its own.
 __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool writer) {
   __shared__ double red[5][kWaves];
   __shared__ float s_alpha;
@@ -1283,33 +1280,24 @@ struct OuterAllArgs {
   HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
   FuseArgs bf;
 };
-static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) + sizeof(AlphaArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
+static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
+// (Measured, not kept: every workgroup of this kernel deriving the step length itself from the batch-sized partials
+//  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba, AlphaArgs aa, int inline_alpha) {
+__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
   const int b = blockIdx.x;
   const int nw = oa.blk0[oa.n];
-  // fused CG: every workgroup derives the step length from the batch-sized partials itself (5 KB of L2-resident
-  // doubles) instead of waiting for a 5 us launch that does it once; workgroup 0 publishes it
-  float alpha = 0.f;
-  const bool own = MODE == FUSE_CG && inline_alpha;
-  if (own) alpha = alpha_compute(aa, b == 0);
   if (b < nw) {
     int i = 0;
     while (i + 1 < oa.n && b >= oa.blk0[i + 1]) ++i;
     const int t = b - oa.blk0[i];
-    FuseArgs f = oa.f[i];
-    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
-    outer_body<true, MODE>(oa.g[i], f, t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
+    outer_body<true, MODE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
   } else if (b < nw + oa.head_blocks) {
     const int t = b - nw;
-    FuseArgs f = oa.hf;
-    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
-    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, f, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
-    else head_outer_body<false, MODE>(oa.head, f, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
   } else {
-    FuseArgs f = oa.bf;
-    if (own) { f.alpha = alpha; f.alpha_ready = 1; }
-    bias_body<MODE>(ba, f, b - nw - oa.head_blocks);
+    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks);
   }
 }
 
@@ -1847,15 +1835,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   }
 
   if (single) {
-    // ---- the step length, then every weight-shaped output with the recurrence in its epilogue.  With the one-launch
-    // form every workgroup of k_outer_all computes alpha itself (BHG_CG_ALPHA_KERNEL: a launch of its own, A/B)
-    static const bool alpha_kernel = getenv("BHG_CG_ALPHA_KERNEL") != nullptr;
-    bool alpha_launched = false;
-    auto launch_alpha = [&]() {
-      if (cg && !alpha_launched) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
-      alpha_launched = true;
-    };
-    if (alpha_kernel) launch_alpha();
+    // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
+    if (cg) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
@@ -1892,10 +1873,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.bf = bias_fz;
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
-      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba, aa, alpha_launched ? 0 : 1);
-      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba, aa, 0);
+      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
+      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba);
     } else {
-      launch_alpha();
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
     }
