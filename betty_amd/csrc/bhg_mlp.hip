@@ -645,17 +645,15 @@ __global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
 }
 
 // ---- split-K epilogues ---------------------------------------------------------------------------------
-// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + addend[m][n] + bias[n]);  rows >= B are written as zero.
+// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + bias[n]);  rows >= B are written as zero.
 // One float4 per thread when N % 4 == 0 (all split loads independent => in flight together);
 // fixed summation order over splits => deterministic.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ part, int splits, int slab,
                                                      const float* __restrict__ bias, const float* __restrict__ mask,
                                                      float* __restrict__ out, int rows, int N, int B,
-                                                     float* __restrict__ relu_mask_out,
-                                                     const float* __restrict__ addend) {
+                                                     float* __restrict__ relu_mask_out) {
   // relu_mask_out != NULL: forward-pass mode — out = relu(sum + bias), relu_mask_out = (sum + bias > 0)
-  // addend != NULL: a chain-independent term computed earlier (delta_l V_l of the fused solver's G pass)
   const int64_t total = (int64_t)rows * N / VEC;
   const int nv = N / VEC;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -671,10 +669,8 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
         constexpr int NB = 8;
         const float* p0 = part + i * VEC;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 adv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
         if (mask) mv = *reinterpret_cast<const float4*>(mask + i * VEC);
-        if (addend) adv = *reinterpret_cast<const float4*>(addend + i * VEC);
         for (int s0 = 0; s0 < splits; s0 += NB) {
           float4 t[NB];
 #pragma unroll
@@ -687,12 +683,10 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
             if (s0 + u < splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
           }
         }
-        if (addend) { v[0] += adv.x; v[1] += adv.y; v[2] += adv.z; v[3] += adv.w; }
         v[0] = (v[0] + bv.x) * mv.x; v[1] = (v[1] + bv.y) * mv.y;
         v[2] = (v[2] + bv.z) * mv.z; v[3] = (v[3] + bv.w) * mv.w;
       } else {
         for (int s = 0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
-        if (addend) v[0] += addend[i];
         if (bias) v[0] += bias[n];
         if (mask) v[0] *= mask[i];
       }
@@ -1346,18 +1340,17 @@ inline int skinny_tile_n() {
 }
 
 void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
-                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr,
-                        const float* addend = nullptr) {
+                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr) {
   if ((N & 3) == 0) {
     int blocks = (slab / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out, addend);
+                       relu_mask_out);
   } else {
     int blocks = (slab + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out, addend);
+                       relu_mask_out);
   }
 }
 
