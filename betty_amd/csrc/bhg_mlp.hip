@@ -58,6 +58,7 @@ struct GemmArgs {
   int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
   const double* scal;   // BF instances: device scalars (beta)
   int nt_out;           // k_gemm: non-temporal stores of the partial slabs
+  int xpose_out;        // k_gemm FAST 128 x 32: slab tile transposed through LDS -> 16-B stores
   int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
                         // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
 };
@@ -307,6 +308,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 
   // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)blockIdx.z * a.out_rows * a.ldo : 0);
+  if (FAST && TN == 32 && LA == LAYOUT_KC && !a.addend && a.xpose_out) {
+    // all-interior 128 x 32 tile: transpose through LDS (the A buffer, free now) so the slab leaves as four 16-B stores
+    // per lane (8 lanes cover one 128-B row segment) instead of sixteen 4-B stores
+    __syncthreads();                       // every wave is done reading the operand tiles
+    float* sC = sA[0];                     // [128][kPadK]
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = wm + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+      sC[row * kPadK + li] = acc[0][rg] + acc[1][rg];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = idx >> 3, c4 = 4 * (idx & 7);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * kPadK + c4);
+      f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)(m0 + row) * a.ldo + n0 + c4);
+      if (a.nt_out) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
+    }
+    return;
+  }
   const int col = n0 + wn + li;
   if (col < a.N) {
 #pragma unroll
@@ -1312,6 +1335,10 @@ void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   // until its end (same-box A/B: 3.707 vs 3.778 ms per step; BHG_NO_NT_SLABS restores plain stores)
   static const bool nt_slabs = getenv("BHG_NO_NT_SLABS") == nullptr;
   a.nt_out = (nt_slabs && (a.splits > 1 || a.out_rows > 0)) ? 1 : 0;
+  // slab tiles of all-interior 128 x 32 instances leave through LDS as 16-B stores (11.7 vs 12.6 us for a 2-step
+  // launch, 276.5 vs 270.5 steps/s, two same-box repetitions; BHG_GEMM_NO_XPOSE restores the direct 4-B stores)
+  static const bool xpose = getenv("BHG_GEMM_NO_XPOSE") == nullptr;
+  a.xpose_out = xpose ? 1 : 0;
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
   bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
   bool bf = false;
