@@ -922,8 +922,8 @@ struct BiasArgs {
   int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
 };
 template <int MODE>
-__device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz, const int bx) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz, const int bx, float* red_base) {
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(red_base);   // 4 x 64 floats of LDS provided by the caller
   __shared__ double red_rr[kWaves];
   int l = 0;
   while (l + 1 < a.L && bx >= a.blk0[l + 1]) ++l;
@@ -967,7 +967,8 @@ __device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz,
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
-  bias_body<MODE>(a, fz, blockIdx.x);
+  __shared__ float red[4 * 64];
+  bias_body<MODE>(a, fz, blockIdx.x, red);
 }
 
 // ---- narrow output layer (C = dims[L] <= 32 classes): dedicated latency-optimised kernels ----------------
@@ -1224,9 +1225,9 @@ struct HeadOuterArgs {
 };
 template <bool HAS_RH, int MODE>
 __device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const FuseArgs& fz, const int bx, const int by,
-                                                const int gx) {
+                                                const int gx, float* red_base) {
   // fused modes: fz.a / fz.b / fz.d already point at the head weight's slice of the flat state vectors
-  __shared__ float red[4][64];
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(red_base);   // 4 x 64 floats of LDS provided by the caller
   __shared__ double red_rr[kWaves];
   const float* __restrict__ rd = ha.rd; const float* __restrict__ h = ha.h; const float* __restrict__ delta = ha.delta;
   const float* __restrict__ Rh = ha.Rh; const float* __restrict__ V = ha.V; float* __restrict__ out = ha.out;
@@ -1279,7 +1280,8 @@ __device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const F
 }
 template <bool HAS_RH, int MODE>
 __global__ __launch_bounds__(256) void k_head_outer(HeadOuterArgs ha, FuseArgs fz) {
-  head_outer_body<HAS_RH, MODE>(ha, fz, blockIdx.x, blockIdx.y, gridDim.x);
+  __shared__ float red[4 * 64];
+  head_outer_body<HAS_RH, MODE>(ha, fz, blockIdx.x, blockIdx.y, gridDim.x, red);
 }
 
 // ---- all weight-shaped outputs of one HVP in ONE launch (fused CG: they all need the step length, which is known
@@ -1301,7 +1303,12 @@ static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments
 // (Measured, not kept: every workgroup of this kernel deriving the step length itself from the batch-sized partials
 //  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
+  // the small blocks borrow their 1 KiB of reduction scratch from the dynamic LDS of the MFMA tiles, and the register
+  // budget is held to 128 (amdgpu_waves_per_eu(4,4): 124 VGPRs, accumulators in VGPR form, no scratch): FOUR workgroups
+  // fit a CU (4 x 38.4 KiB at batch <= 100) instead of three — the kernel is bound by the recurrence traffic it carries,
+  // more tiles in flight = more memory parallelism: 281.5 vs 275.8 steps/s (CG), 605 vs 584 (Neumann), same-box A/B x 2
+  extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
   const int b = blockIdx.x;
   const int nw = oa.blk0[oa.n];
   if (b < nw) {
@@ -1311,10 +1318,10 @@ __global__ __launch_bounds__(256) void k_outer_all(OuterAllArgs oa, BiasArgs ba)
     outer_body<true, MODE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
   } else if (b < nw + oa.head_blocks) {
     const int t = b - nw;
-    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
-    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx);
+    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx, dyn_smem);
+    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx, dyn_smem);
   } else {
-    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks);
+    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks, dyn_smem);
   }
 }
 

@@ -1,10 +1,9 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp; mkdir -p gpurun_out
-for arm in "base" "nostore BHG_DEBUG_GEMM=1" "nomfma BHG_DEBUG_GEMM=2"; do
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "fused or structured or mlp or cfg2" 2>&1 | tail -3
+for arm in "w4" "w3 BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_w3.so" "w4b" "w3b BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_w3.so"; do
   set -- $arm; tag=$1; shift
-  cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gp_$tag -o t -- python $GRAFT_REPO_ROOT/scripts/gemm_probe.py 768 3072 12288 > /tmp/gp_$tag.log 2>&1; echo "probe $tag rc=$?"
-  cd $GRAFT_REPO_ROOT
-  f=$(ls /tmp/gp_$tag/*kernel_trace.csv 2>/dev/null | head -1)
-  if [ -n "$f" ]; then python scripts/print_gemm_probe.py $f 768 3072 12288; else tail -5 /tmp/gp_$tag.log; fi
+  env "$@" timeout 300 python bench.py --steps 150 --cpu-steps 0 --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('== $tag', round(d['value'],1), round(d['ms_per_step'],3))"
+  env "$@" timeout 300 python bench.py --steps 150 --cpu-steps 0 --no-kernel-timing --algo neumann --cg-iters 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('== $tag neumann', round(d['value'],1), round(d['ms_per_step'],3))"
 done
