@@ -333,6 +333,11 @@ constexpr int kResMax = 11;   // chunks per workgroup, register-only instance; 2
 // 15 slots = 15 x 8 (Hp) + 6 x 8 (p in registers) = 168 VGPRs of state -> 15.7 M elements at 28*N bytes.
 constexpr int kResMaxLds = 15;
 constexpr int kResLds = 9;
+// Hybrid instance (HYBRID = true): kResHyb resident slots (fewer than kResMaxLds: the streamed loops need registers of
+// their own) + every further chunk streamed inside the same launch.  BHG_CG_AUTO uses it while at least half of the
+// vector is resident (N <= 2 x kResHyb x G chunks = 29 M elements); beyond that the dedicated streaming kernels, with
+// four 256-thread workgroups per CU, have the better memory parallelism.
+constexpr int kResHyb = 14;
 
 __device__ __forceinline__ double block_sum_res(double v, double* red) {
   v = wave_sum(v);
@@ -428,7 +433,10 @@ __device__ __forceinline__ void resident_stream(float* __restrict__ vec, const b
   }
 }
 
-template <int NSLOT, int NLDS>
+// HYBRID (round 2): chunks beyond the NSLOT x G resident ones are STREAMED inside the same launch — they take part in
+// the same two grid-wide dots and are re-read like in the 3-kernel form (40 bytes per element instead of 28), so the
+// kernel has no size limit any more: N = 20 M costs 28*15.7 M + 40*4.3 M bytes in ONE launch instead of 40*20 M in three.
+template <int NSLOT, int NLDS, bool HYBRID>
 __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     PtrTab tab, const bhg_chunk* __restrict__ chunks, int n_chunks, float* __restrict__ x,
     float* __restrict__ r, float* __restrict__ p, float cg_alpha, int iter, float out_scale, float shift,
@@ -492,6 +500,28 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
              (double)mul_rn(cg_alpha, h[i][j].z) * qq.z + (double)mul_rn(cg_alpha, h[i][j].w) * qq.w;
     }
   }
+  if (HYBRID) {   // streamed chunks: (cg_alpha*Hp).p without keeping anything
+    for (int c = NSLOT * G + blockIdx.x; c < n_chunks; c += G) {
+      const bhg_chunk ck = chunks[c];
+      const float* hs = tab_ptr(tab, ck.tensor) + ck.src_off;
+      float4 hv[kResV], qv[kResV];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        hv[j] = ld4(hs, e, ck.len);
+        qv[j] = ld4(p + ck.flat_off, e, ck.len);
+      }
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        if (shift != 0.f) {
+          hv[j].x = add_rn(hv[j].x, mul_rn(shift, qv[j].x)); hv[j].y = add_rn(hv[j].y, mul_rn(shift, qv[j].y));
+          hv[j].z = add_rn(hv[j].z, mul_rn(shift, qv[j].z)); hv[j].w = add_rn(hv[j].w, mul_rn(shift, qv[j].w));
+        }
+        acc += (double)mul_rn(cg_alpha, hv[j].x) * qv[j].x + (double)mul_rn(cg_alpha, hv[j].y) * qv[j].y +
+               (double)mul_rn(cg_alpha, hv[j].z) * qv[j].z + (double)mul_rn(cg_alpha, hv[j].w) * qv[j].w;
+      }
+    }
+  }
   grid_arrive(block_sum_res(acc, red), partP, barrier_words);
   const double den = grid_wait_sum(partP, barrier_words, (unsigned)G * (2u * iter + 1u), red, barrier_words + 1,
                                    spin_limit);
@@ -507,6 +537,33 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
     acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
     return nr;
   });
+  if (HYBRID) {   // streamed chunks: r' = r - a*Hp with Hp (and p for the shift) read again
+    for (int c = NSLOT * G + blockIdx.x; c < n_chunks; c += G) {
+      const bhg_chunk ck = chunks[c];
+      const float* hs = tab_ptr(tab, ck.tensor) + ck.src_off;
+      float4 hv[kResV], rv[kResV];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        hv[j] = ld4(hs, e, ck.len);
+        rv[j] = ld4(r + ck.flat_off, e, ck.len);
+        if (shift != 0.f) {
+          const float4 qq = ld4(p + ck.flat_off, e, ck.len);
+          hv[j].x = add_rn(hv[j].x, mul_rn(shift, qq.x)); hv[j].y = add_rn(hv[j].y, mul_rn(shift, qq.y));
+          hv[j].z = add_rn(hv[j].z, mul_rn(shift, qq.z)); hv[j].w = add_rn(hv[j].w, mul_rn(shift, qq.w));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        float4 nr;
+        nr.x = sub_rn(rv[j].x, mul_rn(alpha, hv[j].x)); nr.y = sub_rn(rv[j].y, mul_rn(alpha, hv[j].y));
+        nr.z = sub_rn(rv[j].z, mul_rn(alpha, hv[j].z)); nr.w = sub_rn(rv[j].w, mul_rn(alpha, hv[j].w));
+        st4(r + ck.flat_off, e, ck.len, nr);
+        acc += (double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z + (double)nr.w * nr.w;
+      }
+    }
+  }
   grid_arrive(block_sum_res(acc, red), partR_new, barrier_words);
 
   // ---- phase 2b (hides the second barrier): x += a*p [x <- out_scale*x on the last step]
@@ -538,6 +595,34 @@ __global__ __launch_bounds__(kResThreads, 2) void k_cg_resident(
         float4 np;
         np.x = add_rn(h[i][j].x, mul_rn(beta, qq.x)); np.y = add_rn(h[i][j].y, mul_rn(beta, qq.y));
         np.z = add_rn(h[i][j].z, mul_rn(beta, qq.z)); np.w = add_rn(h[i][j].w, mul_rn(beta, qq.w));
+        st4(p + ck.flat_off, e, ck.len, np);
+      }
+    }
+  }
+  if (HYBRID) {   // streamed chunks: x += a*p and p = r' + b*p in one pass (r', p, x read; x, p written), like k_cg_dir
+    for (int c = NSLOT * G + blockIdx.x; c < n_chunks; c += G) {
+      const bhg_chunk ck = chunks[c];
+      float4 rv[kResV], qv[kResV], xv[kResV];
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        rv[j] = ld4(r + ck.flat_off, e, ck.len);
+        qv[j] = ld4(p + ck.flat_off, e, ck.len);
+        xv[j] = ld4(x + ck.flat_off, e, ck.len);
+      }
+#pragma unroll
+      for (int j = 0; j < kResV; ++j) {
+        const int e = 4 * (threadIdx.x + kResThreads * j);
+        float4 nx, np;
+        nx.x = add_rn(xv[j].x, mul_rn(alpha, qv[j].x)); nx.y = add_rn(xv[j].y, mul_rn(alpha, qv[j].y));
+        nx.z = add_rn(xv[j].z, mul_rn(alpha, qv[j].z)); nx.w = add_rn(xv[j].w, mul_rn(alpha, qv[j].w));
+        if (out_scale != 0.f) {
+          nx.x = mul_rn(out_scale, nx.x); nx.y = mul_rn(out_scale, nx.y);
+          nx.z = mul_rn(out_scale, nx.z); nx.w = mul_rn(out_scale, nx.w);
+        }
+        np.x = add_rn(rv[j].x, mul_rn(beta, qv[j].x)); np.y = add_rn(rv[j].y, mul_rn(beta, qv[j].y));
+        np.z = add_rn(rv[j].z, mul_rn(beta, qv[j].z)); np.w = add_rn(rv[j].w, mul_rn(beta, qv[j].w));
+        st4(x + ck.flat_off, e, ck.len, nx);
         st4(p + ck.flat_off, e, ck.len, np);
       }
     }
@@ -845,7 +930,7 @@ static unsigned spin_limit() {
   return v;
 }
 
-int bhg_cg_resident_capacity_chunks(void) { return num_cus() * kResMaxLds; }
+int bhg_cg_resident_capacity_chunks(void) { return num_cus() * 2 * kResHyb; }
 
 // One-time residency census (MI355X_MICROARCH.md "Residency and cooperative launch": size grid-barrier
 // grids from measured residency, never from the occupancy API alone): launch the real resident kernel on
@@ -872,7 +957,7 @@ int bhg_cg_resident_ok(void) {
     double* partR = reinterpret_cast<double*>(w + kWsPartR);
     PtrTab tab;
     memset(&tab, 0, sizeof(tab));
-    hipLaunchKernelGGL((k_cg_resident<kResMax, 0>), dim3(G), dim3(kResThreads), 0, nullptr, tab, (const bhg_chunk*)nullptr, 0,
+    hipLaunchKernelGGL((k_cg_resident<kResMax, 0, false>), dim3(G), dim3(kResThreads), 0, nullptr, tab, (const bhg_chunk*)nullptr, 0,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, 1.0f, 0, 0.0f, 0.0f,
                        (const double*)partR, partR + kMaxBlocks, reinterpret_cast<double*>(w + kWsPartP),
                        reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal),
@@ -940,23 +1025,31 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   } else {
     const int G = num_cus();
     if (n_chunks <= G * kResMax) {   // register-only instance: fastest while it fits (11.5 M elements)
-      hipExtLaunchKernelGGL((k_cg_resident<kResMax, 0>), dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
+      hipExtLaunchKernelGGL((k_cg_resident<kResMax, 0, false>), dim3(G), dim3(kResThreads), 0, st, timed ? ea : nullptr,
                             timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
                             hvp_shift, (const double*)partR_old, partR_new, partP,
                             reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
-    } else {                         // LDS-assisted instance: 9 direction slices per workgroup parked in LDS (15.7 M elements)
+    } else {
       static bool attr_set[kMaxDevices];
       const int dev = current_device();
       constexpr size_t lds = (size_t)kResLds * kResV * kResThreads * sizeof(float4);
       if (dev >= 0 && !attr_set[dev]) {
-        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResMaxLds, kResLds>),
+        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResMaxLds, kResLds, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResHyb, kResLds, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
       }
-      hipExtLaunchKernelGGL((k_cg_resident<kResMaxLds, kResLds>), dim3(G), dim3(kResThreads), lds, st, timed ? ea : nullptr,
-                            timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
-                            hvp_shift, (const double*)partR_old, partR_new, partP,
-                            reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
+      if (n_chunks <= G * kResMaxLds)   // LDS-assisted instance: 9 direction slices per workgroup parked in LDS (15.7 M elements)
+        hipExtLaunchKernelGGL((k_cg_resident<kResMaxLds, kResLds, false>), dim3(G), dim3(kResThreads), lds, st, timed ? ea : nullptr,
+                              timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
+                              hvp_shift, (const double*)partR_old, partR_new, partP,
+                              reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
+      else                              // hybrid instance: 14 resident slots per workgroup, the rest streamed in the same launch
+        hipExtLaunchKernelGGL((k_cg_resident<kResHyb, kResLds, true>), dim3(G), dim3(kResThreads), lds, st, timed ? ea : nullptr,
+                              timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,
+                              hvp_shift, (const double*)partR_old, partR_new, partP,
+                              reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
     }
   }
   BHG_HIP_CHECK(hipGetLastError());

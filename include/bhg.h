@@ -105,16 +105,18 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
  * After the call ws holds the iteration's scalars (see bhg_cg_read_scalars).      */
 #define BHG_CG_AUTO 0
 #define BHG_CG_STREAM 1     /* 3 streaming kernels, 40*N bytes per iteration         */
-#define BHG_CG_RESIDENT 2   /* 1 persistent kernel, 28*N bytes, N <= on-chip capacity: registers only up to
-                               11 chunks per CU, 15 with 9 direction slices per CU parked in LDS */
+#define BHG_CG_RESIDENT 2   /* 1 persistent kernel: 28*N bytes while the vector fits on chip (registers only up to
+                               11 chunks per CU, 15 with 9 direction slices per CU parked in LDS); beyond that a
+                               hybrid instance keeps 14 chunks per CU resident and streams the rest in the same
+                               launch (40 bytes per streamed element), up to bhg_cg_resident_capacity_chunks() */
 int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, void* ws, void* stream);
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, float cg_alpha, int iter, float out_scale,
                 float hvp_shift /* operator = HVP + hvp_shift*I, see bhg_neumann_step */, int variant,
                 void* ws, void* stream);
-/* Largest number of chunks BHG_CG_RESIDENT can hold on the current device (0 when
- * no device is visible). */
+/* Largest number of chunks BHG_CG_RESIDENT accepts on the current device = twice the hybrid instance's resident
+ * part (at least half of the vector stays on chip); 0 when no device is visible. */
 int bhg_cg_resident_capacity_chunks(void);
 /* 1 when a one-time census found all workgroups of the resident kernel co-resident on the current
  * device (needed by its grid barrier), else 0; BHG_CG_AUTO falls back to BHG_CG_STREAM when 0.

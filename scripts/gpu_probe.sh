@@ -1,9 +1,8 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "fused or structured or mlp or cfg2" 2>&1 | tail -3
-for arm in "w4" "w3 BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_w3.so" "w4b" "w3b BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_w3.so"; do
-  set -- $arm; tag=$1; shift
-  env "$@" timeout 300 python bench.py --steps 150 --cpu-steps 0 --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('== $tag', round(d['value'],1), round(d['ms_per_step'],3))"
-  env "$@" timeout 300 python bench.py --steps 150 --cpu-steps 0 --no-kernel-timing --algo neumann --cg-iters 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('== $tag neumann', round(d['value'],1), round(d['ms_per_step'],3))"
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=10 -k "resident or hybrid or falls_back or deterministic or kernels_vs_oracle or diagonal or variants or roberta" 2>&1 | tail -8
+timeout 300 python scripts/bench_kernels.py --scale 2 --iters 30 2>/dev/null > gpurun_out/bench_kernels_N20M.json; python -c "
+import json; d=json.load(open('gpurun_out/bench_kernels_N20M.json')); print('N20M', {k:(round(v['us'],1), round(v['GBps'])) for k,v in d['kernels'].items()})"
+timeout 300 python scripts/bench_kernels.py --scale 1 --iters 30 2>/dev/null | python -c "
+import json,sys; d=json.load(sys.stdin); print('N10M', {k:(round(v['us'],1), round(v['GBps'])) for k,v in d['kernels'].items()})"

@@ -338,7 +338,7 @@ def test_cg_resident_lds_assisted_instance(be):
     dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
     diag = [dvals[torch.arange(n, device=DEV) % 4] for n in sizes]
     lay = be.layout(vec)
-    G = be.lib.bhg_cg_resident_capacity_chunks() // 15
+    G = be.lib.bhg_cg_resident_capacity_chunks() // 28
     if not be.lib.bhg_cg_resident_ok() or not (11 * G < lay.n_chunks <= 15 * G):
         pytest.skip("size does not select the LDS-assisted instance on this device")
     outs = []
@@ -749,11 +749,46 @@ def test_set_grads_multi_tensor_accumulate(be):
         assert torch.equal(p.grad, want)
 
 
-def test_cg_auto_falls_back_to_stream_beyond_resident_capacity(be):
-    """2 x the cfg-2 tensor list (N = 20 M) exceeds the register-resident capacity: BHG_CG_AUTO must take
-    the 3-kernel streaming form and still solve the 4-eigenvalue diagonal system exactly; forcing the
-    resident variant must be refused with BHG_ERR_CAPACITY, not mis-computed."""
+def test_cg_hybrid_resident_instance_at_20M(be):
+    """2 x the cfg-2 tensor list (N = 20 M) exceeds every all-on-chip instance: BHG_CG_AUTO takes the HYBRID resident
+    kernel (14 resident slots per workgroup + the remaining chunks streamed inside the same launch); it must solve
+    the 4-eigenvalue diagonal system exactly, bit-reproducibly, agree with the 3-kernel streaming form, never time out."""
     sizes = CFG2_SIZES * 2
+    gen = torch.Generator().manual_seed(8)
+    vec = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
+    diag = [dvals[torch.arange(n, device=DEV) % 4] for n in sizes]
+    lay = be.layout(vec)
+    cap = be.lib.bhg_cg_resident_capacity_chunks()
+    assert cap >= 5000 or cap == 0
+    if not be.lib.bhg_cg_resident_ok() or lay.n_chunks > cap:
+        pytest.skip("hybrid resident instance not eligible on this device")
+    outs = []
+    for variant in (_native.BHG_CG_AUTO, _native.BHG_CG_RESIDENT, _native.BHG_CG_STREAM):
+        x, r, p = lay.state(3)
+        be.cg_init(lay, vec, x, r, p)
+        K = 4
+        for k in range(K):
+            hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
+            be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == K - 1 else 0.0), variant=variant)
+            if k == 0 and variant == _native.BHG_CG_AUTO:
+                assert lay._cg_variant == _native.BHG_CG_RESIDENT
+            lay._cg_variant = None if variant != _native.BHG_CG_AUTO else lay._cg_variant
+        assert not be.cg_barrier_timed_out(lay)
+        outs.append(x.clone())
+        for xv, v, d in zip(lay.views(x, vec), vec, diag):
+            want = -(v / d)
+            assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert torch.equal(outs[0], outs[1]), "the hybrid resident kernel must be bit-reproducible"
+    rel = (outs[0] - outs[2]).norm() / outs[2].norm()
+    assert rel <= 1e-6, rel
+
+
+def test_cg_auto_falls_back_to_stream_beyond_resident_capacity(be):
+    """4 x the cfg-2 tensor list (N = 40 M): less than half of the vector would be resident, BHG_CG_AUTO must take the
+    3-kernel streaming form and still solve the 4-eigenvalue diagonal system exactly; forcing the resident variant
+    must be refused with BHG_ERR_CAPACITY, not mis-computed."""
+    sizes = CFG2_SIZES * 4
     gen = torch.Generator().manual_seed(8)
     vec = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
     dvals = torch.tensor([0.5, 1.0, 2.0, 4.0], device=DEV)
@@ -764,10 +799,12 @@ def test_cg_auto_falls_back_to_stream_beyond_resident_capacity(be):
     be.cg_init(lay, vec, x, r, p)
     with pytest.raises(_native.NativeLibraryError, match="capacity"):
         be.cg_step(lay, [d * t for d, t in zip(diag, lay.views(p, vec))], x, r, p, 1.0, 0, variant=_native.BHG_CG_RESIDENT)
+    lay._cg_variant = None
     K = 4
     for k in range(K):
         hv = [d * t for d, t in zip(diag, lay.views(p, vec))]
         be.cg_step(lay, hv, x, r, p, 1.0, k, out_scale=(-1.0 if k == K - 1 else 0.0), variant=_native.BHG_CG_AUTO)
+    assert lay._cg_variant == _native.BHG_CG_STREAM
     for xv, v, d in zip(lay.views(x, vec), vec, diag):
         want = -(v / d)
         assert (xv - want).abs().max().item() <= 2e-5 * want.abs().max().item()
