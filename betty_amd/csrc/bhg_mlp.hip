@@ -445,8 +445,11 @@ constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging
 // single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
 // FAST: all tiles interior and 16-B aligned (checked by the launcher): no ragged path, loads unconditional with
 // clamped row index and a 0/1 multiplier (same reasons as k_gemm's FAST instance).
-template <bool FAST, int MODE>
+// PRE (fused, FAST only): the last stage re-loads nothing; the first half tile's state slices are requested instead, so
+// they travel under that stage's MFMAs, and the second half's are requested before the first half is processed.
+template <bool FAST, int MODE, bool PRE = false>
 __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz, const int bx, const int by, const int gx) {
+  static_assert(!PRE || (FAST && MODE != FUSE_NONE), "PRE is the fused all-interior epilogue");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ double red_rr[kWaves];
   const int K = a.K;
@@ -558,14 +561,39 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
   };
 
   const int nstages = nsp * a.pairs;
+  const bool use_x = fz.x_mode != 1 || MODE == FUSE_NONE;   // workgroup-uniform
+  float4 pdv[4], pav[4], pbv[4];                // PRE: state slices of half tile 0
+  auto hload = [&](int hb, float4* dv, float4* av, float4* bv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 4) + 16 * (4 * hb + i);
+      const int64_t off = (int64_t)(m0 + row) * a.ldo + n0 + 4 * (t & 15);
+      dv[i] = ld16(fz.d + off);
+      if (MODE == FUSE_CG) av[i] = ld16(fz.a + off);
+      bv[i] = use_x ? ld16(fz.b + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
   gload(0);
   lstore();
-  for (int stage = 0; stage < nstages; ++stage) {
-    gload(min(stage + 1, nstages - 1));         // in flight during this stage's MFMAs (the last one re-loads itself: unused)
-    __syncthreads();                            // this stage's tile is complete in LDS
-    compute(stage);
-    __syncthreads();                            // everyone is done reading it
-    lstore();                                   // (after the last stage: a dead store, overwritten by the C staging below)
+  if (PRE) {
+    for (int stage = 0; stage + 1 < nstages; ++stage) {
+      gload(stage + 1);                         // in flight during this stage's MFMAs
+      __syncthreads();                          // this stage's tile is complete in LDS
+      compute(stage);
+      __syncthreads();                          // everyone is done reading it
+      lstore();
+    }
+    hload(0, pdv, pav, pbv);
+    __syncthreads();
+    compute(nstages - 1);
+  } else {
+    for (int stage = 0; stage < nstages; ++stage) {
+      gload(min(stage + 1, nstages - 1));       // in flight during this stage's MFMAs (the last one re-loads itself: unused)
+      __syncthreads();                          // this stage's tile is complete in LDS
+      compute(stage);
+      __syncthreads();                          // everyone is done reading it
+      lstore();                                 // (after the last stage: a dead store, overwritten by the C staging below)
+    }
   }
   __syncthreads();  // LDS is reused as the C staging tile below
 
@@ -587,9 +615,34 @@ __device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz
     const float alpha = fuse_alpha<MODE>(fz);
     const float beta = fuse_beta<MODE>(fz);
     const bool wr_d = MODE == FUSE_CG && fz.lazy;
-    const bool use_x = fz.x_mode != 1 || MODE == FUSE_NONE;   // workgroup-uniform
     const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_RING + (fz.kpar ^ 1)] : 0.f;
     FuseAcc racc{0.0, 0.0, 0.0};
+    if constexpr (PRE) {
+      float4 dv1[4], av1[4], bv1[4];
+      if (MODE != FUSE_CG) hload(1, dv1, av1, bv1);   // (CG: three state vectors — both halves at once do not fit 128 registers)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        if (MODE == FUSE_CG && hb == 1) hload(1, dv1, av1, bv1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (t >> 4) + 16 * (4 * hb + i);
+          const int c4 = 4 * (t & 15);
+          const float4 hv = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
+          const int64_t off = (int64_t)(m0 + row) * a.ldo + n0 + c4;
+          float4 na = MODE == FUSE_CG ? (hb ? av1[i] : pav[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 nb = hb ? bv1[i] : pbv[i], nd = hb ? dv1[i] : pdv[i];
+          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc, alpha_prev);
+          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc, alpha_prev);
+          *reinterpret_cast<float4*>(fz.a + off) = na;
+          if (use_x) *reinterpret_cast<float4*>(fz.b + off) = nb;
+          if (wr_d) *reinterpret_cast<float4*>(fz.d + off) = nd;
+        }
+      }
+      if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
+      return;
+    }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       float4 dv[4], av[4], bv[4];
@@ -1302,7 +1355,14 @@ struct OuterAllArgs {
 static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
 // (Measured, not kept: every workgroup of this kernel deriving the step length itself from the batch-sized partials
 //  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.)
-template <int MODE>
+// Where its time goes (CG 56 us / Neumann 41 us at the benchmark, state traffic 200 MB / 120 MB): the two fit
+// T = 18 us + bytes / 5.3 TB/s, i.e. the MFMA phase (17.5 us is the fp32 matrix-pipe floor of the 4 GFLOP) and the
+// streaming of the state slices ADD UP — the four workgroups of a CU start together, so they all sit in the MFMA phase
+// together and then all in the epilogue.  PRE (first half tile's state requested under the last stage's MFMAs, no
+// redundant re-load of the last stage) buys 2 us.  A five-workgroups-per-CU instance (34-row stages, C staged 64 rows
+// at a time, quarter-tile pipelining: 1224 tiles = one resident wave) was built and measured SLOWER (63 us; 79 us with
+// the register spills of the pipelined form), so four it stays.
+template <int MODE, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
   // the small blocks borrow their 1 KiB of reduction scratch from the dynamic LDS of the MFMA tiles, and the register
   // budget is held to 128 (amdgpu_waves_per_eu(4,4): 124 VGPRs, accumulators in VGPR form, no scratch): FOUR workgroups
@@ -1315,7 +1375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int i = 0;
     while (i + 1 < oa.n && b >= oa.blk0[i + 1]) ++i;
     const int t = b - oa.blk0[i];
-    outer_body<true, MODE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
+    outer_body<true, MODE, PRE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
   } else if (b < nw + oa.head_blocks) {
     const int t = b - nw;
     if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx, dyn_smem);
@@ -1552,8 +1612,10 @@ int side_state(SideState** out) {
     BHG_OUTER_LDS(true, FUSE_CG); BHG_OUTER_LDS(false, FUSE_CG);
     BHG_OUTER_LDS(true, FUSE_NEUMANN); BHG_OUTER_LDS(false, FUSE_NEUMANN);
 #undef BHG_OUTER_LDS
-    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   }
   *out = &ss;
   return BHG_OK;
@@ -1900,8 +1962,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.bf = bias_fz;
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
-      if (cg) hipLaunchKernelGGL(k_outer_all<FUSE_CG>, dim3(total), dim3(256), lds_max, st, oa, ba);
-      else hipLaunchKernelGGL(k_outer_all<FUSE_NEUMANN>, dim3(total), dim3(256), lds_max, st, oa, ba);
+      static const bool no_pre = getenv("BHG_OUTER_NO_PRE") != nullptr;   // A/B runs
+      if (no_pre) {
+        if (cg) hipLaunchKernelGGL((k_outer_all<FUSE_CG, false>), dim3(total), dim3(256), lds_max, st, oa, ba);
+        else hipLaunchKernelGGL((k_outer_all<FUSE_NEUMANN, false>), dim3(total), dim3(256), lds_max, st, oa, ba);
+      } else {
+        if (cg) hipLaunchKernelGGL((k_outer_all<FUSE_CG, true>), dim3(total), dim3(256), lds_max, st, oa, ba);
+        else hipLaunchKernelGGL((k_outer_all<FUSE_NEUMANN, true>), dim3(total), dim3(256), lds_max, st, oa, ba);
+      }
     } else {
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);

@@ -1,8 +1,7 @@
 #!/bin/bash
+# N > 1 code path of bench.py on a 1-GPU box: 2 ranks share the GPU (gloo), replica and global modes.
 set -u
 export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=10 -k "resident or hybrid or falls_back or deterministic or kernels_vs_oracle or diagonal or variants or roberta" 2>&1 | tail -8
-timeout 300 python scripts/bench_kernels.py --scale 2 --iters 30 2>/dev/null > gpurun_out/bench_kernels_N20M.json; python -c "
-import json; d=json.load(open('gpurun_out/bench_kernels_N20M.json')); print('N20M', {k:(round(v['us'],1), round(v['GBps'])) for k,v in d['kernels'].items()})"
-timeout 300 python scripts/bench_kernels.py --scale 1 --iters 30 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin); print('N10M', {k:(round(v['us'],1), round(v['GBps'])) for k,v in d['kernels'].items()})"
+export BHG_ALL_RANKS_ON_GPU0=1
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 2 --dist-backend gloo --cpu-steps 0 > gpurun_out/bench_2ranks_replica.json 2> gpurun_out/bench_2ranks_replica.err; echo "replica rc=$?"; cut -c1-600 gpurun_out/bench_2ranks_replica.json; tail -3 gpurun_out/bench_2ranks_replica.err | cut -c1-300
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --cpu-steps 0 --mode global > gpurun_out/bench_2ranks_global.json 2> gpurun_out/bench_2ranks_global.err; echo "global rc=$?"; cut -c1-600 gpurun_out/bench_2ranks_global.json; tail -3 gpurun_out/bench_2ranks_global.err | cut -c1-300

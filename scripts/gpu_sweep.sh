@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B sweep of the split-K sizing / tile-width switches under the one-pass solver (bench lines only).
+# A/B of the k_outer_all instances (BHG_OUTER_NO_PRE) under the one-pass solver: parity first, then bench lines.
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "fused or structured_goldens or cfg2" 2>&1 | tail -3
 run() { tag=$1; shift
   timeout 300 python bench.py --steps 100 --cpu-steps 0 --no-kernel-timing "$@" 2> gpurun_out/bench_$tag.err > gpurun_out/bench_$tag.json
   python - <<PY
@@ -13,11 +14,19 @@ except Exception as e:
     print("== $tag bench failed:", e); print(open("gpurun_out/bench_$tag.err").read()[-800:])
 PY
 }
-run base
-BHG_SPLIT_TARGET=512 run split512
-BHG_SPLIT_TARGET=640 run split640
-BHG_SPLIT_TARGET=1024 BHG_SPLIT_CAP=24 run split1024
-BHG_MLP_TN=64 BHG_SPLIT_TARGET=512 BHG_SPLIT_CAP=24 run tn64_512
-BHG_MLP_TN=64 BHG_SPLIT_TARGET=768 BHG_SPLIT_CAP=32 run tn64_768
-BHG_NO_NT_SLABS=1 run no_nt
-run base_again
+BHG_OUTER_NO_PRE=1 run nopre
+run pre
+BHG_OUTER_NO_PRE=1 run nopre_again
+run pre_again
+BHG_OUTER_NO_PRE=1 run nopre_neumann --algo neumann
+run pre_neumann --algo neumann
+BHG_OUTER_NO_PRE=1 run nopre_neumann_again --algo neumann
+run pre_neumann_again --algo neumann
+for v in nopre pre; do
+  rm -rf /tmp/tr_$v
+  if [ $v = nopre ]; then export BHG_OUTER_NO_PRE=1; else unset BHG_OUTER_NO_PRE; fi
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$v -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused > /tmp/tr_$v.log 2>&1)
+  f=$(find /tmp/tr_$v -name '*kernel_trace.csv' | head -1)
+  echo "--- timeline $v"
+  if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_cg_beta | grep -E "k_outer_all|iteration span"; else tail -3 /tmp/tr_$v.log; fi
+done
