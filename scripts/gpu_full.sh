@@ -26,7 +26,7 @@ run darts --algo darts
 run cg_global_ws1 --algo cg --mode global --steps 20
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_default -o bench -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 > /tmp/prof_default.log 2>&1; echo "rocprof stats rc=$?"
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/prof_default; cp /tmp/prof_default/*kernel_stats*.csv gpurun_out/prof_default/ 2>/dev/null
-tail -1 /tmp/prof_default.log | cut -c1-400 > gpurun_out/prof_default/bench_line_under_rocprof.json
+grep "^{\"metric\"" /tmp/prof_default.log | tail -1 > gpurun_out/prof_default/bench_line_under_rocprof.json
 python - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_default/*kernel_stats*.csv")
@@ -48,3 +48,9 @@ if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f k_outer_all | tee 
 bash scripts/gpu_pmc2.sh 2>&1 | tail -45
 bash scripts/gpu_pmc_sq.sh 2>&1 | tail -28
 timeout 300 python scripts/bench_kernels.py --scale 1 --extra 5000000 --iters 40 2>/dev/null > gpurun_out/bench_kernels_N15M.json; python -c "import json; d=json.load(open(\"gpurun_out/bench_kernels_N15M.json\")); print(\"N15M\", {k:(round(v[\"us\"],1), round(v[\"GBps\"])) for k,v in d[\"kernels\"].items()})"
+kb() { tag=$1; shift; timeout 300 python scripts/bench_kernels.py --iters 40 "$@" 2>/dev/null > gpurun_out/bench_kernels_$tag.json; python -c "import json; d=json.load(open(\"gpurun_out/bench_kernels_$tag.json\")); print(\"$tag\", {k:(round(v[\"us\"],1), round(v[\"GBps\"])) for k,v in d[\"kernels\"].items()})"; }
+kb N10M_cached --scale 1
+kb N10M_cache_defeated --scale 1 --scrub-mb 512
+kb N20M --scale 2
+kb N120M --scale 12
+kb N120M_cache_defeated --scale 12 --scrub-mb 512

@@ -1,7 +1,8 @@
 #!/bin/bash
-# N > 1 code path of bench.py on a 1-GPU box: 2 ranks share the GPU (gloo), replica and global modes.
+# rocprofv3 kernel stats of the default bench command + the bench line printed under the profiler.
 set -u
-export TMPDIR=/tmp; mkdir -p gpurun_out
-export BHG_ALL_RANKS_ON_GPU0=1
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 2 --dist-backend gloo --cpu-steps 0 > gpurun_out/bench_2ranks_replica.json 2> gpurun_out/bench_2ranks_replica.err; echo "replica rc=$?"; cut -c1-600 gpurun_out/bench_2ranks_replica.json; tail -3 gpurun_out/bench_2ranks_replica.err | cut -c1-300
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --cpu-steps 0 --mode global > gpurun_out/bench_2ranks_global.json 2> gpurun_out/bench_2ranks_global.err; echo "global rc=$?"; cut -c1-600 gpurun_out/bench_2ranks_global.json; tail -3 gpurun_out/bench_2ranks_global.err | cut -c1-300
+export TMPDIR=/tmp; mkdir -p gpurun_out/prof_default
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_default -o bench -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 > /tmp/prof_default.log 2>&1; echo "rocprof stats rc=$?"
+cd $GRAFT_REPO_ROOT; cp /tmp/prof_default/*kernel_stats*.csv gpurun_out/prof_default/ 2>/dev/null
+grep "^{\"metric\"" /tmp/prof_default.log | tail -1 > gpurun_out/prof_default/bench_line_under_rocprof.json
+head -c 300 gpurun_out/prof_default/bench_line_under_rocprof.json
