@@ -630,6 +630,26 @@ def test_mlp_hvp_full_size_cfg2():
     comb = [t.clone() for t in hvp([0.5 * u - 2.0 * v for u, v in zip(direction, other)])]
     rel, _ = rel_err(_np(comb), _np([0.5 * a - 2.0 * b for a, b in zip(got, h2)]))
     assert rel <= 1e-5, rel
+    # symmetry of the Hessian, <u, H v> = <v, H u>, dots in fp64: another property that needs no reference run
+    uHv = sum((u.double() * hv.double()).sum().item() for u, hv in zip(other, got))
+    vHu = sum((v.double() * hu.double()).sum().item() for v, hu in zip(direction, h2))
+    assert abs(uHv - vHu) <= 1e-5 * max(abs(uHv), abs(vHu)), (uHv, vHu)
+
+
+@pytest.mark.parametrize("algo,K", [("cg", 20), ("neumann", 10)])
+def test_fused_solver_power_of_two_scaling_full_size(algo, K):
+    """BASELINE cfg-2 shapes: the solvers are linear in the right-hand side and every operation on the way commutes
+    with a power-of-two scale (products, sums, the fp32 roundings, the step-length quotients), so
+    solve(4 v) == 4 solve(v) BIT FOR BIT — a full-size check that needs no reference and no tolerance."""
+    import bench
+
+    curr, prev, vector = bench.build(torch.device(DEV), seed=0, K=K, algo=algo)
+    bench.declare_structure(curr, "hip", fused=True)
+    one = [t.clone() for t in hg.jvp_fn_mapping[algo](vector, curr, prev, False)]
+    four = hg.jvp_fn_mapping[algo]([4.0 * v for v in vector], curr, prev, False)
+    for a, b in zip(one, four):
+        assert torch.isfinite(b).all()
+        assert torch.equal(4.0 * a, b), (algo, (4.0 * a - b).abs().max().item())
 
 
 # ------------------------------------------------------------------------------------------------
