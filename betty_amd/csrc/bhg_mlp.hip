@@ -1059,7 +1059,11 @@ struct HeadFuse {
   const float* mask;   // m_{L-2}[rows][K]
   float* rh_out;       // Rh_{L-2}[rows][K]
 };
-template <bool HAS_RH, int JMAX, bool FUSED>
+// PF (solver iterations: HEAD_JVP with the fused R-backward, K <= 512, C <= 12): the kernel is a chain of dependent
+// L2 round trips (slab batches -> dot-product operands -> softmax inputs -> three class batches of the R-backward);
+// every load that does not depend on the kernel's own results is requested up front instead: the dot-product operands
+// together with the first slab batch, the R-backward operands while the dot products run.  Same arithmetic, same order.
+template <bool HAS_RH, int JMAX, bool FUSED, bool PF = false>
 __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ Rh, const float* __restrict__ h,
                                                       const float* __restrict__ W, const float* __restrict__ V,
                                                       const float* __restrict__ cb, const float* __restrict__ prob,
@@ -1094,27 +1098,6 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
       for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  if (FUSED) {
-    for (int k = 4 * t; k < K; k += 1024) {
-      const float* p0 = fz.part + (int64_t)b * K + k;
-      const float4 bv = ld16(fz.bias + k);
-      const float4 mv = ld16(fz.mask + (int64_t)b * K + k);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = 0; s0 < fz.splits; s0 += 8) {     // same batching and summation order as k_reduce_mask
-        float4 tt[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < fz.splits ? s0 + u : fz.splits - 1) * fz.slab);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < fz.splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
-      }
-      v.x = (v.x + bv.x) * mv.x; v.y = (v.y + bv.y) * mv.y; v.z = (v.z + bv.z) * mv.z; v.w = (v.w + bv.w) * mv.w;
-      *reinterpret_cast<float4*>(srow + k) = v;
-      *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = v;
-    }
-    __syncthreads();
-  }
-  const float* rhb = HAS_RH ? (FUSED ? srow : Rh + (int64_t)b * K) : nullptr;
   const float* hb = h + (int64_t)b * K;
   float acc[JMAX], cbv[JMAX];
   const float* vrow[JMAX];
@@ -1127,7 +1110,80 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
     wrow[j] = W + (int64_t)cc * K;
     cbv[j] = cb[cc];
   }
-  for (int k = 4 * lane; k < K; k += 256) {
+  // PF: operands of the dot products (k = 4 lane and 4 lane + 256; clamped, not guarded) and the softmax inputs
+  float4 pf_h[2], pf_v[2][JMAX], pf_w[2][JMAX];
+  float pf_p = 0.f, pf_sd = 0.f, pf_dt = 0.f;
+  if (PF) {
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+      const int k = 4 * lane + 256 * tr;
+      const int kc = k < K ? k : 0;
+      pf_h[tr] = ld16(hb + kc);
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        pf_v[tr][j] = ld16(vrow[j] + kc);
+        pf_w[tr][j] = ld16(wrow[j] + kc);
+      }
+    }
+    const int tc = t < C ? t : C - 1;
+    pf_p = prob[(int64_t)b * C + tc];
+    pf_sd = sd[b];
+    pf_dt = delta_top[(int64_t)b * C + tc];
+  }
+  if (FUSED) {
+    for (int k = 4 * t; k < K; k += 1024) {
+      const float* p0 = fz.part + (int64_t)b * K + k;
+      const float4 bv = ld16(fz.bias + k);
+      const float4 mv = ld16(fz.mask + (int64_t)b * K + k);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      constexpr int NB = PF ? 16 : 8;                 // slabs in flight together; the summation order is s = 0, 1, ... either way
+      for (int s0 = 0; s0 < fz.splits; s0 += NB) {    // (as k_reduce_mask)
+        float4 tt[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < fz.splits ? s0 + u : fz.splits - 1) * fz.slab);
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+          if (s0 + u < fz.splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
+      }
+      v.x = (v.x + bv.x) * mv.x; v.y = (v.y + bv.y) * mv.y; v.z = (v.z + bv.z) * mv.z; v.w = (v.w + bv.w) * mv.w;
+      *reinterpret_cast<float4*>(srow + k) = v;
+      *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = v;
+    }
+    __syncthreads();
+  }
+  const float* rhb = HAS_RH ? (FUSED ? srow : Rh + (int64_t)b * K) : nullptr;
+  // PF: operands of the fused R-backward (k = 4 t, all C <= 12 classes), requested while the dot products run
+  float4 pf_mk, pf_W[12], pf_V[12];
+  if (PF) {
+    const int kd = 4 * t < K ? 4 * t : 0;
+    pf_mk = ld16(mask_prev + (int64_t)b * K + kd);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const int cc = min(c, C - 1);
+      pf_W[c] = ld16(W + (int64_t)cc * K + kd);
+      pf_V[c] = ld16(V + (int64_t)cc * K + kd);
+    }
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+      const int k = 4 * lane + 256 * tr;
+      if (k < K) {
+        const float4 hv = pf_h[tr];
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_RH) rv = *reinterpret_cast<const float4*>(rhb + k);
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          float a = acc[j];
+          const float4 vv = pf_v[tr][j], ww = pf_w[tr][j];
+          a = fmaf(hv.x, vv.x, a); a = fmaf(hv.y, vv.y, a); a = fmaf(hv.z, vv.z, a); a = fmaf(hv.w, vv.w, a);
+          if (HAS_RH) {
+            a = fmaf(rv.x, ww.x, a); a = fmaf(rv.y, ww.y, a); a = fmaf(rv.z, ww.z, a); a = fmaf(rv.w, ww.w, a);
+          }
+          acc[j] = a;
+        }
+      }
+    }
+  }
+  for (int k = 4 * lane; k < (PF ? 0 : K); k += 256) {
     const float4 hv = *reinterpret_cast<const float4*>(hb + k);
     float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_RH) rv = *reinterpret_cast<const float4*>(rhb + k);
@@ -1160,9 +1216,12 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
     float p = 0.f, sdv = 0.f, dt = 0.f;
     if (rz_out && t < C) rz_out[(int64_t)b * C + t] = rz[t];   // Rz_b(direction): accumulated into Rz(x) by k_cg_alpha
     if (t < C) {
-      p = prob[(int64_t)b * C + t];
-      sdv = sd[b];
-      if (rd_prev) dt = delta_top[(int64_t)b * C + t];
+      if (PF) { p = pf_p; sdv = pf_sd; dt = pf_dt; }
+      else {
+        p = prob[(int64_t)b * C + t];
+        sdv = sd[b];
+        if (rd_prev) dt = delta_top[(int64_t)b * C + t];
+      }
       pz[t] = p * rz[t];
     }
     __syncthreads();
@@ -1182,7 +1241,29 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
       partT1[b] = s1;
     }
     double dacc = 0.0;
-    if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
+    if (PF) {       // (rd_prev != NULL by construction)
+      const int k = 4 * t;
+      if (k < K) {
+        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          if (c < C) {
+            const float r = rdl[c], d = dtl[c];
+            const float4 v = pf_V[c], w = pf_W[c];
+            acc2.x += d * v.x + r * w.x; acc2.y += d * v.y + r * w.y;
+            acc2.z += d * v.z + r * w.z; acc2.w += d * v.w + r * w.w;
+            accd.x += d * v.x; accd.y += d * v.y; accd.z += d * v.z; accd.w += d * v.w;
+          }
+        }
+        acc2.x *= pf_mk.x; acc2.y *= pf_mk.y; acc2.z *= pf_mk.z; acc2.w *= pf_mk.w;
+        *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
+        if (HAS_RH && partT2h) {
+          const float4 rh4 = *reinterpret_cast<const float4*>(rhb + k);
+          dacc += (double)accd.x * rh4.x + (double)accd.y * rh4.y + (double)accd.z * rh4.z + (double)accd.w * rh4.w;
+        }
+      }
+    } else if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
       for (int k = 4 * t; k < K; k += 1024) {
         const float4 mk = *reinterpret_cast<const float4*>(mask_prev + (int64_t)b * K + k);
         float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1250,7 +1331,12 @@ void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float*
 #define BHG_HEAD(RH, J, F)                                                                                              \
   hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
                      mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out)
-  if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
+  static const bool no_pf = getenv("BHG_HEAD_NO_PREFETCH") != nullptr;   // A/B switch
+  const bool pf = !no_pf && fuse && C <= 12 && K <= 512 && mode == HEAD_JVP && rd_prev && delta_top && mask_prev;
+  if (pf) {
+    hipLaunchKernelGGL((k_head_forward<true, 3, true, true>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C,
+                       B, mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out);
+  } else if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
   else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
   else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
 #undef BHG_HEAD
