@@ -85,6 +85,7 @@ __device__ __forceinline__ void stagger_prio(int mode, int lin, int per_cu) {
 // 16-B load through a native vector type: `regs[i] = *(const float4*)p` on the HIP struct type becomes a
 // memcpy into a private ARRAY that SROA then leaves in scratch memory when nothing else touches the array.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ float4 ld16(const float* __restrict__ p) {
   const f32x4 v = *reinterpret_cast<const f32x4*>(p);
   return make_float4(v.x, v.y, v.z, v.w);
@@ -1497,6 +1498,231 @@ __global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ pro
   delta[i] = b < B ? sd[b] * (prob[i] - ((int)labels[b] == c ? 1.f : 0.f)) : 0.f;
 }
 
+// ---- skinny GEMM with the split along K INSIDE the workgroup ("wsk") ------------------------------------------------
+// The split-K launches above leave [splits][Bp][N] partial slabs that a reduce launch sums, biases and masks (12.6 MB
+// written and re-read, one more launch on the dependent chain per layer).  Here ONE workgroup owns a final 32 x 32
+// output tile: its 8 waves take disjoint K ranges (with two operand pairs: waves 0-3 the first pair, 4-7 the second),
+// the eight partial tiles meet in LDS and are summed in fixed order (deterministic), and the same epilogue
+//   out[m][n] = mask[m][n] * (sum + bias[n])        (rows >= B written as zero)
+// [+ the block's partial of T2 = 2 <first pair's product, Rh> for the fused CG step length] runs before anything
+// leaves the chip.  No slabs, no reduce launch.  Operands go from global memory straight into the MFMA register layout
+// (v_mfma_f32_16x16x4_f32: lane l holds A[l & 15][l >> 4]); any k <-> lane assignment is valid as long as the A and the
+// B fragment of a lane agree, so a lane's 16-B load along K feeds four MFMAs:
+//   K-contiguous operand: lane (li, lk) loads [row li][k0 + 16 h + 4 lk .. + 3]       -> 64 B contiguous per row
+//   N-contiguous operand: lane (li, lk) loads [k0 + 16 h + 4 lk + c][n0 + 2 li .. + 1] -> 128 B contiguous per k;
+//                         component t of the 8-B load belongs to column n0 + 2 li + t (interleaved column blocks).
+// A D-deep ring of register stages keeps D chunks of 32 k in flight per wave; there is no barrier in the K loop.
+// The price is operand reuse: a 32 x 32 tile moves 8 KiB (12 KiB with the lazy direction) per 32 MFMAs through the
+// vector cache against 5-6 KiB for a 128 x 32 tile — the reason this form is an A/B arm (BHG_MLP_WSK), not a given.
+struct WskArgs {
+  GemmPair pr[2];
+  int pairs;
+  int M, N, K;          // K per pair; M, N multiples of 32, K a multiple of 32 * (8 / pairs)
+  int B;                // valid rows
+  const float* bias;    // [N] or NULL
+  const float* mask;    // [M][N] or NULL
+  const float* rh;      // [M][N]: T2 partner (needs pairs == 2 and partT2) or NULL
+  float* out;           // [M][N]
+  double* partT2;       // one partial per workgroup or NULL
+  const double* scal;   // BF instances: beta
+  int ntm, ntn;         // output tiles
+};
+constexpr int kWskWaves = 8;
+constexpr int kWskPad = 33;
+
+template <int LB, bool MIX, int D>
+__device__ __forceinline__ void wsk_loop(const GemmPair& pr, const int m0, const int n0, const int kbeg, const int nch,
+                                         const float bs, f32x4 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const float* gA = pr.A + (int64_t)(m0 + li) * pr.lda + kbeg + 4 * lk;
+  const float* gB;
+  const float* gQ;
+  if (LB == LAYOUT_KC) {
+    gB = pr.B + (int64_t)(n0 + li) * pr.ldb + kbeg + 4 * lk;
+    gQ = pr.B2 + (int64_t)(n0 + li) * pr.ldb + kbeg + 4 * lk;
+  } else {
+    gB = pr.B + (int64_t)(kbeg + 4 * lk) * pr.ldb + n0 + 2 * li;
+    gQ = pr.B2 + (int64_t)(kbeg + 4 * lk) * pr.ldb + n0 + 2 * li;
+  }
+  const int64_t a16 = (int64_t)16 * pr.lda, b16 = (int64_t)16 * pr.ldb;
+  f32x4 sa[D][2][2];        // [stage][row block][k half]
+  f32x4 sb[D][2][2];        // K-contiguous B: [stage][col block][k half]
+  f32x4 sq[D][2][2];
+  f32x2 tb[D][2][4];        // N-contiguous B: [stage][k half][k component] (x, y = the two interleaved column blocks)
+  f32x2 tq[D][2][4];
+  auto load = [&](const int d, int ch) {
+    ch = min(ch, nch - 1);   // past the end: re-load the last chunk (never used), keeps the loop free of control flow
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) sa[d][rb][h] = *reinterpret_cast<const f32x4*>(gA + rb * a16 + ch * 32 + 16 * h);
+      if (LB == LAYOUT_KC) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          sb[d][cb][h] = *reinterpret_cast<const f32x4*>(gB + cb * b16 + ch * 32 + 16 * h);
+          if (MIX) sq[d][cb][h] = *reinterpret_cast<const f32x4*>(gQ + cb * b16 + ch * 32 + 16 * h);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t o = (int64_t)(ch * 32 + 16 * h + c) * pr.ldb;
+          tb[d][h][c] = *reinterpret_cast<const f32x2*>(gB + o);
+          if (MIX) tq[d][h][c] = *reinterpret_cast<const f32x2*>(gQ + o);
+        }
+      }
+    }
+  };
+  auto compute = [&](const int d) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float b0, b1;
+        if (LB == LAYOUT_KC) {
+          b0 = sb[d][0][h][c]; b1 = sb[d][1][h][c];
+          if (MIX) {   // p = r' + (beta * p_old): the two roundings of k_cg_pdir
+            b0 = __fadd_rn(b0, __fmul_rn(bs, sq[d][0][h][c]));
+            b1 = __fadd_rn(b1, __fmul_rn(bs, sq[d][1][h][c]));
+          }
+        } else {
+          b0 = tb[d][h][c].x; b1 = tb[d][h][c].y;
+          if (MIX) {
+            b0 = __fadd_rn(b0, __fmul_rn(bs, tq[d][h][c].x));
+            b1 = __fadd_rn(b1, __fmul_rn(bs, tq[d][h][c].y));
+          }
+        }
+        const float a0 = sa[d][0][h][c], a1 = sa[d][1][h][c];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(d, d);
+  int s = 0;
+  for (; s + D <= nch; s += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(d);
+      load(d, s + D + d);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (s + d < nch) compute(d);
+}
+
+template <int LB, bool BF, int D>
+__global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
+  __shared__ float sP[kWskWaves][32][kWskPad];
+  __shared__ double red[kWskWaves];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  // tile of this workgroup.  Workgroup ids go round-robin over the 8 XCDs: all row tiles of a column tile sit on ONE
+  // XCD (the streamed weight-side operand is fetched into one L2), consecutive column tiles on different XCDs.
+  int tm, tn;
+  {
+    const int b = blockIdx.x;
+    if ((a.ntn & 7) == 0) {
+      const int xcd = b & 7, j = b >> 3;
+      tm = j % a.ntm;
+      tn = (j / a.ntm) * 8 + xcd;
+    } else {
+      tm = b % a.ntm;
+      tn = b / a.ntm;
+    }
+  }
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int nwp = kWskWaves / a.pairs;   // waves per operand pair
+  const int pi = wave / nwp;             // wave-uniform
+  const int wq = wave - pi * nwp;
+  const int Kw = a.K / nwp;
+  const GemmPair pr = a.pr[pi];
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc);
+  else wsk_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc);
+
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = LB == LAYOUT_KC ? 16 * cb + li : 2 * li + cb;
+        sP[wave][16 * rb + 4 * lk + r][col] = acc[rb][cb][r];
+      }
+  __syncthreads();
+  double t2 = 0.0;
+#pragma unroll
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * kWskWaves) {
+    const int row = e >> 5, col = e & 31;
+    const int m = m0 + row, n = n0 + col;
+    const int64_t idx = (int64_t)m * a.N + n;
+    float v = 0.f;
+    for (int w = 0; w < nwp; ++w) v += sP[w][row][col];
+    if (a.partT2 && m < a.B) t2 += (double)v * (double)a.rh[idx];
+    for (int w = nwp; w < kWskWaves; ++w) v += sP[w][row][col];
+    if (a.bias) v += a.bias[n];
+    if (a.mask) v *= a.mask[idx];
+    a.out[idx] = m < a.B ? v : 0.f;
+  }
+  if (a.partT2) {
+    t2 = wave_sum(t2);
+    if (lane == 0) red[wave] = t2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWskWaves; ++i) s += red[i];
+      a.partT2[blockIdx.x] = 2.0 * s;
+    }
+  }
+}
+
+// BHG_MLP_WSK: 0 = split-K launches + reduce (default until measured faster), 1 = in-workgroup split where the shape
+// allows.  Read on every call so a test can compare both arms in one process.
+inline bool wsk_enabled() {
+  const char* e = getenv("BHG_MLP_WSK");
+  return e && atoi(e) != 0;
+}
+inline int wsk_depth() {
+  const char* e = getenv("BHG_MLP_WSK_DEPTH");
+  const int d = e ? atoi(e) : 3;
+  return d == 2 ? 2 : 3;
+}
+inline bool wsk_eligible(const WskArgs& a) {
+  if (a.pairs < 1 || a.pairs > 2) return false;
+  const int nwp = kWskWaves / a.pairs;
+  bool ok = a.M % 32 == 0 && a.N % 32 == 0 && a.K % (32 * nwp) == 0 && a.K >= 32 * nwp;
+  for (int i = 0; i < a.pairs; ++i) ok = ok && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
+  return ok;
+}
+template <int LB>
+void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st) {
+  WskArgs a = a_in;
+  a.ntm = a.M / 32;
+  a.ntn = a.N / 32;
+  bool bf = false;
+  for (int i = 0; i < a.pairs; ++i) bf = bf || a.pr[i].mix != 0;
+  const dim3 grid(a.ntm * a.ntn), block(64 * kWskWaves);
+  const int d = wsk_depth();
+#define BHG_WSK(BFV, DV) hipLaunchKernelGGL((k_gemm_wsk<LB, BFV, DV>), grid, block, 0, st, a)
+  if (bf) { if (d == 2) BHG_WSK(true, 2); else BHG_WSK(true, 3); }
+  else    { if (d == 2) BHG_WSK(false, 2); else BHG_WSK(false, 3); }
+#undef BHG_WSK
+}
+
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   GemmArgs a = a_in;
@@ -1821,6 +2047,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   SideState& ss = *ssp;
   hipStream_t side = ss.side;
   const int tn = skinny_tile_n();
+  const bool wsk = wsk_enabled();
 
   FuseArgs fbase{};
   fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
@@ -1869,11 +2096,19 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     a.pairs = 1;
     if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
     a.M = Bp; a.N = N; a.K = K;
+    const bool to_head = head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024;
+    if (wsk && !to_head && l + 1 < L) {
+      // in-workgroup split-K: the 32 x 32 tile is summed, biased and masked before it leaves the chip (no reduce launch)
+      WskArgs w{};
+      w.pr[0] = a.pr[0]; w.pr[1] = a.pr[1]; w.pairs = a.pairs; w.M = Bp; w.N = N; w.K = K; w.B = B;
+      w.bias = c; w.mask = m->mask[l]; w.out = m->Rh[l]; w.scal = cm.scal;
+      if (wsk_eligible(w)) { launch_gemm_wsk<LAYOUT_KC>(w, st); continue; }
+    }
     a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
     launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
     const int slab = Bp * N;
-    if (head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024) {
+    if (to_head) {
       // the head kernel of the next layer combines these slabs itself (one launch less on the chain)
       head_fuse = {m->partial, a.splits, slab, c, m->mask[l], m->Rh[l]};
       fuse_head = true;
@@ -2001,6 +2236,17 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
     a.pairs = 2;
     a.M = Bp; a.N = N; a.K = K;
+    if (wsk) {
+      WskArgs w{};
+      w.pr[0] = a.pr[0]; w.pr[1] = a.pr[1]; w.pairs = 2; w.M = Bp; w.N = N; w.K = K; w.B = B;
+      w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.scal = cm.scal;
+      if (cg) { w.rh = m->Rh[l - 1]; w.partT2 = cm.ws->partT2 + cm.ws->t2_off[l]; }
+      // (the T2 partial slots were carved for the reduce launch's block count: one per 1024 outputs, like the tiles here)
+      if (wsk_eligible(w) && (!cg || (Bp / 32) * (N / 32) == reduce_blocks(Bp * N, N))) {
+        launch_gemm_wsk<LAYOUT_RC>(w, st);
+        continue;
+      }
+    }
     a.splits = pick_splits((N + tn - 1) / tn, K, 2);
     if (cg) {
       // the two products land in separate slabs (each workgroup takes twice the K range of ONE pair: same count and
