@@ -125,6 +125,7 @@ SYMBOLS = {
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, c_void_p],
     ),
+    "bhg_mlp_wsk_launches": (c_int64, []),
 }
 
 _lib = None

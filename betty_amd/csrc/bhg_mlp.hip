@@ -1601,15 +1601,30 @@ __device__ __forceinline__ void wsk_loop(const GemmPair& pr, const int m0, const
     }
   };
 #pragma unroll
-  for (int d = 0; d < D; ++d) load(d, d);
+  for (int d = 0; d < D; ++d) {
+    load(d, d);
+    __builtin_amdgcn_sched_barrier(0);   // stage order = issue order (the waits count loads issued AFTER the needed ones)
+  }
   int s = 0;
-  for (; s + D <= nch; s += D) {
+  // steady state: every load is a chunk that will be used
+  for (; s + 2 * D <= nch; s += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
+      // fences: without them hipcc gathers the MFMAs of all D stages behind ONE s_waitcnt vmcnt(0) and issues the
+      // loads of all D stages at the end of the body — the ring would then hide nothing inside a wave
       compute(d);
+      __builtin_amdgcn_sched_barrier(0);
       load(d, s + D + d);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // last refills (fewer than D chunks left to fetch), then the drain
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (s + d < nch) compute(d);
+    if (s + D + d < nch) load(d, s + D + d);
+  }
+  s += D;
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (s + d < nch) compute(d);
@@ -1690,11 +1705,24 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
   }
 }
 
-// BHG_MLP_WSK: 0 = split-K launches + reduce (default until measured faster), 1 = in-workgroup split where the shape
-// allows.  Read on every call so a test can compare both arms in one process.
-inline bool wsk_enabled() {
+// BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
+// for short reductions (pairs * K <= BHG_MLP_WSK_MAXK, default 1024), where the launch and the slab round trip weigh more
+// than the operand re-reads.  Measured on the cfg-2 shapes (rocprofv3 timeline, MI355X): K = 2 x 384 -> 10.8 us against
+// 9.6 + 5.0 us (GEMM + reduce); K = 3072 / 2 x 2048 / 2 x 1536 -> 37.3 / 40.4 / 30.2 us against 27.5 / 27.4 / 26.9 us:
+// a lane's 16-B loads in MFMA layout touch 16 cache lines per instruction (64 B of each), and the vector cache's
+// address path retires about one line per 4 clocks — 8 waves x 12 loads x 16 lines x 4 clk per 32-k chunk is three times
+// the chunk's MFMA time.  Read on every call so a test can compare both arms in one process.
+inline int wsk_mode(bool fused_cg) {
   const char* e = getenv("BHG_MLP_WSK");
-  return e && atoi(e) != 0;
+  // default: short reductions of the fused CG solver only — the un-fused arm and the Neumann solver (whose fused and
+  // un-fused arms are bitwise equal, a tested property) keep one GEMM path; an explicit value applies everywhere
+  return e ? atoi(e) : (fused_cg ? 2 : 0);
+}
+inline bool wsk_wanted(int mode, int pairs, int K) {
+  if (mode == 1) return true;
+  if (mode != 2) return false;
+  const char* e = getenv("BHG_MLP_WSK_MAXK");
+  return pairs * K <= (e ? atoi(e) : 1024);
 }
 inline int wsk_depth() {
   const char* e = getenv("BHG_MLP_WSK_DEPTH");
@@ -1708,9 +1736,11 @@ inline bool wsk_eligible(const WskArgs& a) {
   for (int i = 0; i < a.pairs; ++i) ok = ok && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
   return ok;
 }
+int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st) {
   WskArgs a = a_in;
+  ++g_wsk_launches;
   a.ntm = a.M / 32;
   a.ntn = a.N / 32;
   bool bf = false;
@@ -1718,8 +1748,12 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st) {
   const dim3 grid(a.ntm * a.ntn), block(64 * kWskWaves);
   const int d = wsk_depth();
 #define BHG_WSK(BFV, DV) hipLaunchKernelGGL((k_gemm_wsk<LB, BFV, DV>), grid, block, 0, st, a)
-  if (bf) { if (d == 2) BHG_WSK(true, 2); else BHG_WSK(true, 3); }
-  else    { if (d == 2) BHG_WSK(false, 2); else BHG_WSK(false, 3); }
+  if (bf) {
+    // (N-contiguous B with the lazy direction holds 48 registers per stage: three stages would spill)
+    if (d == 2 || LB == LAYOUT_RC) BHG_WSK(true, 2); else BHG_WSK(true, LB == LAYOUT_RC ? 2 : 3);
+  } else {
+    if (d == 2) BHG_WSK(false, 2); else BHG_WSK(false, 3);
+  }
 #undef BHG_WSK
 }
 
@@ -2047,7 +2081,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   SideState& ss = *ssp;
   hipStream_t side = ss.side;
   const int tn = skinny_tile_n();
-  const bool wsk = wsk_enabled();
+  const int wsk = wsk_mode(cg);
 
   FuseArgs fbase{};
   fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
@@ -2097,7 +2131,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     if (l > 0) { a.pr[1] = {m->Rh[l - 1], m->W[l], K, K}; a.pairs = 2; }  // Rh_{l-1} W_l^T
     a.M = Bp; a.N = N; a.K = K;
     const bool to_head = head && l == L - 2 && !no_fuse && (N & 3) == 0 && (size_t)N * sizeof(float) <= 64 * 1024;
-    if (wsk && !to_head && l + 1 < L) {
+    if (wsk_wanted(wsk, a.pairs, K) && !to_head && l + 1 < L) {
       // in-workgroup split-K: the 32 x 32 tile is summed, biased and masked before it leaves the chip (no reduce launch)
       WskArgs w{};
       w.pr[0] = a.pr[0]; w.pr[1] = a.pr[1]; w.pairs = a.pairs; w.M = Bp; w.N = N; w.K = K; w.B = B;
@@ -2236,7 +2270,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
     a.pairs = 2;
     a.M = Bp; a.N = N; a.K = K;
-    if (wsk) {
+    if (wsk_wanted(wsk, 2, K)) {
       WskArgs w{};
       w.pr[0] = a.pr[0]; w.pr[1] = a.pr[1]; w.pairs = 2; w.M = Bp; w.N = N; w.K = K; w.B = B;
       w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.scal = cm.scal;
@@ -2390,6 +2424,8 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
 }
 
 // ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
+int64_t bhg_mlp_wsk_launches(void) { return bhg::g_wsk_launches; }
+
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
   static const bool off = getenv("BHG_MLP_NO_FUSED_SOLVE") != nullptr;   // A/B switch: callers fall back to HVP + recurrence kernel
   return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m);

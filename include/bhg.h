@@ -257,6 +257,10 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
  * Rz(x) = sum_k alpha_k Rz(p_k) from the Rz every iteration's head kernel computes anyway.                          */
 int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff, float cg_alpha, void* fws,
                            size_t fws_bytes, void* stream);
+/* Test / measurement hook: how many of the chain's skinny GEMMs this process launched in the in-workgroup split-K form
+ * (k_gemm_wsk: a final 32 x 32 tile per workgroup, no partial slabs, no reduce launch; env BHG_MLP_WSK selects where it
+ * is used: 0 nowhere, 1 wherever the shape allows, 2 short reductions only — the fused CG solver's default).      */
+int64_t bhg_mlp_wsk_launches(void);
 
 #ifdef __cplusplus
 }

@@ -589,6 +589,54 @@ def test_fused_solver_full_size_cfg2():
         assert rel <= (1e-4 if algo == "cg" else 1e-6), (algo, rel)
 
 
+@pytest.mark.parametrize(
+    "dims,B",
+    [([256, 384, 128, 10], 100), ([512, 256, 256, 64, 10], 128), ([256, 128, 64, 10], 64), ([768, 64, 32, 10], 37)],
+    ids=lambda v: str(v),
+)
+def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
+    """k_gemm_wsk (a final 32 x 32 tile per workgroup: K split over the workgroup's waves, sum + bias + mask [+ the T2
+    partial of the fused CG step length] before anything leaves the chip) against the split-K launches + reduce
+    kernels: the HVP's outputs (un-fused chain, K-contiguous and N-contiguous weight operands, one and two operand
+    pairs) and a fused CG solve (lazy direction formed in the loaders, T2 from the tile epilogue).  The launch counter
+    proves the arm under test really ran."""
+    lib = _native.load()
+    outs, sols = {}, {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("BHG_MLP_WSK", arm)
+        n0 = lib.bhg_mlp_wsk_launches()
+        curr, prev, direction, provider = _mlp_problem(dims, B, ridge=0.05, seed=sum(dims) + B)
+        outs[arm] = [t.clone() for t in provider("hip").prepare()(direction)]
+        sols[arm] = _run_solver("cg", dims, B, 0.05, 4, sum(dims) + B, True)
+        n1 = lib.bhg_mlp_wsk_launches()
+        assert (n1 > n0) == (arm == "1"), (arm, n0, n1)
+    for a, b in zip(outs["1"], outs["0"]):
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-5 * scale   # same products, different summation tree
+    rel, _ = rel_err(sols["1"][0], sols["0"][0])
+    assert rel <= 5e-5, rel
+    x1, x0 = sols["1"][1][0].astype(np.float64), sols["0"][1][0].astype(np.float64)
+    assert np.linalg.norm(x1 - x0) <= 5e-5 * np.linalg.norm(x0)
+    # bit-reproducible (fixed-order sums in LDS, no atomics)
+    monkeypatch.setenv("BHG_MLP_WSK", "1")
+    again = _run_solver("cg", dims, B, 0.05, 4, sum(dims) + B, True)
+    assert all(np.array_equal(u, v) for u, v in zip(again[1], sols["1"][1]))
+
+
+def test_wsk_is_the_fused_cg_default_for_short_reductions_only(monkeypatch):
+    """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k, the
+    un-fused chain and the Neumann solver never do (their fused / un-fused arms stay bitwise comparable)."""
+    monkeypatch.delenv("BHG_MLP_WSK", raising=False)
+    lib = _native.load()
+    dims, B = [256, 384, 128, 10], 100     # per iteration: R-forward of layer 0 (256 k) and R-backward into it (2 x 128 k)
+    n0 = lib.bhg_mlp_wsk_launches()
+    _run_solver("neumann", dims, B, 0.05, 3, 11, True)
+    _run_solver("cg", dims, B, 0.05, 3, 11, False)
+    assert lib.bhg_mlp_wsk_launches() == n0
+    _run_solver("cg", dims, B, 0.05, 3, 11, True)
+    assert lib.bhg_mlp_wsk_launches() == n0 + 2 * 3
+
+
 def test_cg_variants_may_alternate_inside_a_solve(be):
     """A streamed iteration credits the resident kernel's arrival counter (k_cg_dir), so the public ABI's explicit
     variant argument may change between iterations: stream/resident alternating == all-stream."""
