@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ p
         // Batches of 8 slabs: all 8 loads (plus bias and mask) are issued before the first add, so a
         // reduce costs one or two L2 round trips instead of `splits` dependent ones.  Lanes past the
         // last slab re-read it (an L1 hit) and are not added; the summation order stays s = 0, 1, ...
-        constexpr int NB = 8;
+        constexpr int NB = 8;    // (measured: 16 in flight — one round trip for the benchmark's 12-16 slabs — is SLOWER, 5.5-6.1 vs 4.9 us)
         const float* p0 = part + i * VEC;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
@@ -1463,7 +1463,11 @@ static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments
 // together and then all in the epilogue.  PRE (first half tile's state requested under the last stage's MFMAs, no
 // redundant re-load of the last stage) buys 2 us.  A five-workgroups-per-CU instance (34-row stages, C staged 64 rows
 // at a time, quarter-tile pipelining: 1224 tiles = one resident wave) was built and measured SLOWER (63 us; 79 us with
-// the register spills of the pipelined form), so four it stays.
+// the register spills of the pipelined form), so four it stays.  So was a whole-tile prefetch (r and the previous
+// direction of all 128 rows requested behind the last operand load, x behind the last LDS store; 168 VGPRs, three
+// workgroups per CU): CG 277 vs 294 steps/s, Neumann 616 vs 619 — the reads were never what the matrix phase delayed;
+// the tile's WRITES cannot start before its MFMAs end, and with 1.3 rounds of workgroups there is no steady state in
+// which one workgroup's stores run under another's matrix phase.
 template <int MODE, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
   // the small blocks borrow their 1 KiB of reduction scratch from the dynamic LDS of the MFMA tiles, and the register
