@@ -87,13 +87,13 @@ class Problem:
                 p.grad = g if p.grad is None else p.grad + g
 
 
-def declare_structure(curr, impl, fused=True):
+def declare_structure(curr, impl, fused=True, keep_solution=False):
     """Opt the inner problem into the analytic MFMA HVP (betty_amd/hypergradient/structured.py)."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
     curr.hypergradient_structure = lambda prev: WeightedCEMLP(
         curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=RIDGE, impl=impl,
-        fused=fused,
+        fused=fused, keep_solution=keep_solution,
     )
 
 
@@ -242,6 +242,9 @@ def main():
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
     ap.add_argument("--no-fuse", action="store_true",
                     help="analytic HVP only: K x (HVP kernels + recurrence kernel) instead of the one-pass fused solver (A/B)")
+    ap.add_argument("--keep-solution", action="store_true",
+                    help="fused CG solver: materialise the N-sized solution vector x (default: the hypergradient comes "
+                         "from the accumulated Rz(x), x is never written)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
@@ -290,7 +293,7 @@ def main():
         curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
         jvp_fn = hg.jvp_fn_mapping[args.algo]
     if args.hvp == "analytic":
-        declare_structure(curr, "hip", fused=not args.no_fuse)
+        declare_structure(curr, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution)
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
     N = sum(p.numel() for p in curr.parameters())
@@ -440,6 +443,9 @@ def main():
                         "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp) + recurrence kernel" if args.hvp == "analytic" else
                         "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else "pytorch-rocm autograd double backward"),
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
+                "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else
+                                    "not materialised: the mixed second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), "
+                                    "accumulated from batch-sized factors; same hypergradient bit for bit"),
                 "parallelism": ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world)
                 if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,

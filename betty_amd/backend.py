@@ -119,7 +119,7 @@ class HipBackend:
         ts = self._prep(vector, layout)
         tab, _keep = self._table(ts)
         _native.check(
-            self.lib.bhg_cg_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, x.data_ptr(),
+            self.lib.bhg_cg_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, None if x is None else x.data_ptr(),
                                  r.data_ptr(), p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
             "bhg_cg_init",
         )

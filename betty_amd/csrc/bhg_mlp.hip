@@ -1024,10 +1024,10 @@ __device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz,
     } else {
       const float hv = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
       const int64_t off = a.foff[l] + col;
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off], nd = fz.d[off];
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = fz.d[off];
       fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), hv, nd, na, nb, racc);
       fz.a[off] = na;
-      fz.b[off] = nb;
+      if (fz.b) fz.b[off] = nb;
       if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
     }
   }
@@ -1423,10 +1423,10 @@ __device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const F
       if (rho2 != 0.f) v += rho2 * V[off];
       out[off] = v;
     } else {
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b[off], nd = fz.d[off];
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = fz.d[off];
       fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), v, nd, na, nb, racc);
       fz.a[off] = na;
-      fz.b[off] = nb;
+      if (fz.b) fz.b[off] = nb;
       if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
     }
   }
@@ -2096,10 +2096,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     FuseArgs f = fbase;
     if (cm.mode != FUSE_NONE) {
       const int64_t o = cm.starts[tensor];
-      f.a = cm.fa + o; f.b = cm.fb + o; f.d = cm.fd + o;
+      f.a = cm.fa + o; f.b = cm.fb ? cm.fb + o : nullptr; f.d = cm.fd + o;
       // lazy direction: only the MFMA layers' weight slices (the small slices were updated by k_cg_beta)
       f.lazy = cm.lazy && (tensor & 1) == 0 && !(head && tensor == 2 * (L - 1));
       f.x_mode = (f.lazy || cm.mode == FUSE_NEUMANN) ? cm.x_mode : 0;
+      if (!cm.fb) f.x_mode = 1;   // fused CG without a solution vector: nothing reads or writes x
     }
     f.part_base = part_base;
     return f;
@@ -2238,6 +2239,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   }
   FuseArgs bias_fz = fbase;
   bias_fz.a = cm.fa; bias_fz.b = cm.fb; bias_fz.d = cm.fd; bias_fz.part_base = part_base_bias;   // offsets travel in ba.foff
+  if (cm.mode != FUSE_NONE && !cm.fb) bias_fz.x_mode = 1;
   auto launch_bias = [&](hipStream_t s) {
     if (cm.mode == FUSE_CG) hipLaunchKernelGGL(k_bias_hvp<FUSE_CG>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
     else if (cm.mode == FUSE_NEUMANN) hipLaunchKernelGGL(k_bias_hvp<FUSE_NEUMANN>, dim3(bias_blk), dim3(256), 0, s, ba, bias_fz);
@@ -2456,7 +2458,11 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
                      const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
                      void* fws, size_t fws_bytes, void* stream) {
   if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
-  BHG_REQUIRE(x && r && p && ws && chunks_dev, "NULL argument");
+  // x == NULL: the N-sized solution vector is not materialised.  For this structure the mixed second derivative only
+  // needs Rz(x) = sum_k alpha_k Rz(p_k), which k_cg_alpha accumulates from the batch-sized Rz of every direction
+  // (bhg_mlp_cg_mixed_coeff), so a caller that wants the hypergradient and not x itself saves x's share of the
+  // recurrence traffic (8*N bytes every other iteration) and its zeroing in bhg_cg_init.
+  BHG_REQUIRE(r && p && ws && chunks_dev, "NULL argument");
   BHG_REQUIRE(K >= 0 && n_chunks > 0, "bad size");
   if (K == 0) return BHG_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2511,6 +2517,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     // x is read and written every other iteration (FuseArgs.x_mode): even iterations defer, odd ones catch up
     static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
+    if (!x) cm.x_mode = 1;
     cm.first = k == 0;
     cm.kpar = k & 1;
     if (int rc = run_chain(m, dir, cm, st)) return rc;

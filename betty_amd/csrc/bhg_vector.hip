@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_init(PtrTab tab, const bhg_chun
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) {
       const int e = 4 * (threadIdx.x + kThreads * i);
-      st4(x + ck.flat_off, e, ck.len, zero);
+      if (x) st4(x + ck.flat_off, e, ck.len, zero);   // x == NULL: the caller does not materialise the solution vector
       st4(r + ck.flat_off, e, ck.len, t[i]);
       st4(p + ck.flat_off, e, ck.len, t[i]);
       acc += (double)t[i].x * t[i].x + (double)t[i].y * t[i].y + (double)t[i].z * t[i].z +
@@ -909,7 +909,7 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
   BHG_COMMON_CHECKS(vec);
   BHG_REQUIRE(ws, "workspace is NULL");
   if (n_chunks == 0) return BHG_OK;
-  BHG_REQUIRE(x && r && p, "state vector is NULL");
+  BHG_REQUIRE(r && p, "state vector is NULL");   // x may be NULL (see bhg_mlp_cg_solve)
   hipStream_t st = static_cast<hipStream_t>(stream);
   PtrTab tab;
   if (int rc = make_table(&tab, vec, T, ws, 0, st)) return rc;

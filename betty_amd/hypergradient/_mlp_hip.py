@@ -199,11 +199,13 @@ class HipMLPState:
         starts = (ctypes.c_int64 * len(layout.starts))(*layout.starts)
         return buf.fws, starts
 
-    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float) -> None:
-        """cg.py:38-56 for this structure: K x (HVP chain with fused r/x update + direction update)."""
+    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True) -> None:
+        """cg.py:38-56 for this structure: K x (HVP chain with fused r/x update + direction update).
+        keep_x=False: the library gets x = NULL and never reads or writes the solution vector (its views still
+        identify the solve for mixed_coeff, which works from the accumulated Rz(x))."""
         fws, starts = self._fused_args(layout)
         _native.check(
-            self.lib.bhg_mlp_cg_solve(ctypes.byref(self.desc), x.data_ptr(), r.data_ptr(), p.data_ptr(), starts,
+            self.lib.bhg_mlp_cg_solve(ctypes.byref(self.desc), x.data_ptr() if keep_x else None, r.data_ptr(), p.data_ptr(), starts,
                                       layout.chunks_dev.data_ptr(), layout.n_chunks, int(K), float(cg_alpha), float(shift),
                                       layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
             "bhg_mlp_cg_solve",

@@ -32,16 +32,20 @@ def cg(vector, curr, prev, sync):
         in_grad = None
         hvp_fn = provider.prepare()
 
-    layout = be.layout(vector)
-    x, r, p = layout.state(3)
-    be.cg_init(layout, vector, x, r, p)  # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
-    p_views = layout.views(p, vector)
-
     K = int(config.cg_iterations)
-    # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
-    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.cg_alpha)
     fused = getattr(provider, "fused_cg", None)
+    layout = be.layout(vector)
+    x, r, p = layout.state(3)
+    # a provider whose fused solver derives the mixed derivative from batch-sized factors never touches x (see
+    # WeightedCEMLP.keep_solution): then x is not even zeroed
+    skips = getattr(provider, "fused_cg_skips_solution", None)
+    skip_x = bool(fused is not None and alpha != 0.0 and skips is not None and skips(layout, K))
+    be.cg_init(layout, vector, None if skip_x else x, r, p)  # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
+    p_views = layout.views(p, vector)
+
+    # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
+    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     if fused is not None and alpha != 0.0 and fused(layout, x, r, p, K, alpha):
         pass  # the provider's own kernels ran all K iterations (HVP outputs consumed on chip, no N-sized H p)
     else:

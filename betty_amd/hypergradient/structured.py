@@ -67,7 +67,7 @@ class WeightedCEMLP:
     """
 
     def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
-                 batch=None, impl: Optional[str] = None, fused: bool = True):
+                 batch=None, impl: Optional[str] = None, fused: bool = True, keep_solution: bool = False):
         self.curr, self.prev = curr, prev
         self.layers = list(layers)
         self.weight_fn = weight_fn
@@ -80,6 +80,11 @@ class WeightedCEMLP:
         # fused=False keeps the K loop as K x (HVP kernels + recurrence kernel) — the A/B arm of the tests and of
         # ``bench.py --no-fuse``; the product default lets the HVP's output kernels apply the recurrence themselves
         self.fused = bool(fused)
+        # The fused CG solver does not need the N-sized solution x to produce the hypergradient: the mixed second
+        # derivative of this structure only needs Rz(x) = sum_k alpha_k Rz(p_k), a batch x classes array the solver
+        # accumulates from the Rz every iteration's head kernel computes anyway.  keep_solution=True materialises x
+        # all the same (x <- x + alpha p inside the output kernels' epilogues, cg.py:49) for callers that want to read it.
+        self.keep_solution = bool(keep_solution)
         params = list(curr.parameters())
         expect = []
         for lin in self.layers:
@@ -104,11 +109,18 @@ class WeightedCEMLP:
     # Optional protocol extension: a provider whose HVP kernels can apply the recurrence themselves runs the whole K
     # loop ("one pass": no N-sized H*direction vector).  Both return False when the fused path does not apply and the
     # caller falls back to K x (hvp_fn + recurrence kernel).
-    def fused_cg(self, layout, x, r, p, K: int, cg_alpha: float) -> bool:
+    def fused_cg_ready(self, layout, K: int) -> bool:
         st = self._state
-        if K <= 0 or not self.fused or not hasattr(st, "cg_solve") or not st.fused_supported(layout):
+        return K > 0 and self.fused and hasattr(st, "cg_solve") and st.fused_supported(layout)
+
+    def fused_cg_skips_solution(self, layout, K: int) -> bool:
+        """True when fused_cg will run AND leaves x untouched (the caller may then skip zeroing it)."""
+        return (not self.keep_solution) and self.fused_cg_ready(layout, K)
+
+    def fused_cg(self, layout, x, r, p, K: int, cg_alpha: float) -> bool:
+        if not self.fused_cg_ready(layout, K):
             return False
-        st.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift)
+        self._state.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift, keep_x=self.keep_solution)
         return True
 
     def fused_neumann(self, layout, v, p, K: int, alpha: float) -> bool:

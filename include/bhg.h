@@ -243,6 +243,8 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
  *   fws: device scratch of bhg_mlp_fused_ws_bytes(m) bytes.
  * bhg_mlp_cg_solve: call bhg_cg_init(vec, ..., x, r, p, ws, stream) first (x = 0, r = p = vec, r.r partials in ws);
  *   on return x = -cg_alpha * x_K (cg.py:56 and the negation of cg.py:59/68 folded into the last iteration).
+ *   x may be NULL in both calls: the N-sized solution is then neither zeroed, read nor written — for this structure the
+ *   hypergradient only needs Rz(x), which the solver accumulates from batch-sized factors (bhg_mlp_cg_mixed_coeff).
  * bhg_mlp_neumann_solve: call bhg_neumann_init(vec, ..., v0, p, ...) first; v0 / v1 ping-pong as the direction (the
  *   R-backward GEMMs of an HVP still read v while its epilogues write v'); on return p = -alpha * p_K.              */
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m);

@@ -520,7 +520,7 @@ def _run_solver(algo, dims, B, ridge, K, seed, fused, alpha=None):
         Config(type="neumann", neumann_iterations=K, neumann_alpha=0.05 if alpha is None else alpha)
     curr.hypergradient_structure = lambda prev_: WeightedCEMLP(
         curr, prev_, layers=list(curr.module.layers), weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=ridge,
-        impl="hip", fused=fused)
+        impl="hip", fused=fused, keep_solution=True)   # these tests read the flat solution vector back
     vec = [0.1 * d for d in direction]
     out = hg.jvp_fn_mapping[algo](vec, curr, prev, False)
     lay = get_backend().layout(vec)
@@ -547,6 +547,38 @@ def test_fused_solver_matches_unfused(algo, dims, B, K):
     assert np.linalg.norm(x_f - x_u) <= 5e-5 * np.linalg.norm(x_u)
     if algo == "neumann":   # no reduction anywhere in the Neumann recurrence: identical tiles, identical roundings
         assert np.array_equal(st_f[0], st_u[0])
+
+
+@pytest.mark.parametrize("dims,B,K", [([256, 384, 128, 10], 100, 5), ([70, 130, 36, 10], 100, 4), ([3072, 2048, 1536, 384, 10], 100, 20)],
+                         ids=lambda v: str(v))
+def test_fused_cg_without_a_solution_vector(dims, B, K, be):
+    """The product default: the fused CG solver is handed x = NULL (WeightedCEMLP.keep_solution=False) — the mixed
+    second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), accumulated from batch-sized factors, so the N-sized
+    solution is never zeroed, read or written.  The hypergradient is BIT-identical to the run that materialises x, and
+    the x buffer of the layout is provably untouched (filled with NaN before the call, still all NaN after it)."""
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    outs = {}
+    for keep in (True, False):
+        curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=sum(dims) + B + K)
+        curr.config = Config(type="cg", cg_iterations=K, cg_alpha=1.0)
+        curr.hypergradient_structure = lambda prev_, keep=keep, curr=curr: WeightedCEMLP(
+            curr, prev_, layers=list(curr.module.layers), weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=0.05,
+            impl="hip", fused=True, keep_solution=keep)
+        vec = [0.1 * d for d in direction]
+        lay = be.layout(vec)
+        x = lay.state(3)[0]
+        x.fill_(float("nan"))
+        try:
+            outs[keep] = [t.clone() for t in hg.jvp_fn_mapping["cg"](vec, curr, prev, False)]
+            if keep:
+                assert torch.isfinite(x[lay.starts[0]: lay.starts[0] + vec[0].numel()]).all()
+            else:
+                assert torch.isnan(x).all(), "x must not be touched"
+        finally:
+            x.zero_()   # layouts (and their state buffers, zero padding included) are cached per shape list
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_fused_cg_scalars_match_unfused(be):
