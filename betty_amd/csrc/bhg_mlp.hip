@@ -1456,7 +1456,11 @@ struct OuterAllArgs {
 };
 static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
 // (Measured, not kept: every workgroup of this kernel deriving the step length itself from the batch-sized partials
-//  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.)
+//  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.  Nor an
+//  "alpha block": block 0 of this launch doing k_cg_alpha's work while all other workgroups run their MFMA phase, the
+//  epilogues picking the result up from 64 replicated 8-byte {tag : alpha} granules with relaxed agent-scope loads — no
+//  fence, no hot word, correct, and 301.7 vs 300.5 steps/s: the step length's dependent loads take ~4 us under the
+//  launch's own operand burst, the first tiles' epilogues wait for them, and the launch grows by what it saved.)
 // Where its time goes (CG 56 us / Neumann 41 us at the benchmark, state traffic 200 MB / 120 MB): the two fit
 // T = 18 us + bytes / 5.3 TB/s, i.e. the MFMA phase (17.5 us is the fp32 matrix-pipe floor of the 4 GFLOP) and the
 // streaming of the state slices ADD UP — the four workgroups of a CU start together, so they all sit in the MFMA phase
