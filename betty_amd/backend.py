@@ -101,7 +101,7 @@ class HipBackend:
         tab, _keep = self._table(ts)
         _native.check(
             self.lib.bhg_neumann_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, v.data_ptr(),
-                                      p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
+                                      None if p is None else p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
             "bhg_neumann_init",
         )
 

@@ -1074,7 +1074,8 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
                                                       const float* __restrict__ mask_prev,
                                                       float* __restrict__ rd_prev, HeadFuse fz,
                                                       double* __restrict__ partT1, double* __restrict__ partT2h,
-                                                      float* __restrict__ rz_out) {
+                                                      float* __restrict__ rz_out, double* __restrict__ rzx_acc,
+                                                      int rzx_first) {
   extern __shared__ __attribute__((aligned(16))) float srow[];   // FUSED: the row of Rh_{L-2}, K floats
   // partT1 / partT2h != NULL (HEAD_JVP, fused CG solver): this sample row's share of p.Hp (see k_cg_alpha):
   //   partT1[b]  = sum_c Rz[b][c] * Rd_L[b][c]                          (the Gauss-Newton part)
@@ -1216,6 +1217,8 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
   if (mode == HEAD_JVP) {
     float p = 0.f, sdv = 0.f, dt = 0.f;
     if (rz_out && t < C) rz_out[(int64_t)b * C + t] = rz[t];   // Rz_b(direction): accumulated into Rz(x) by k_cg_alpha
+    // fused Neumann solver without an accumulator vector: sum_k Rz_b(v_k), one owner per sample row (deterministic)
+    if (rzx_acc && t < C) rzx_acc[(int64_t)b * C + t] = (rzx_first ? 0.0 : rzx_acc[(int64_t)b * C + t]) + (double)rz[t];
     if (t < C) {
       if (PF) { p = pf_p; sdv = pf_sd; dt = pf_dt; }
       else {
@@ -1324,19 +1327,19 @@ void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float*
                          const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
                          const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
                          float* rd_prev, const HeadFuse* fuse = nullptr, double* partT1 = nullptr,
-                         double* partT2h = nullptr, float* rz_out = nullptr) {
+                         double* partT2h = nullptr, float* rz_out = nullptr, double* rzx_acc = nullptr, int rzx_first = 0) {
   // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
   HeadFuse fz{};
   if (fuse) fz = *fuse;
   const size_t lds = fuse ? (size_t)K * sizeof(float) : 0;
 #define BHG_HEAD(RH, J, F)                                                                                              \
   hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
-                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out)
+                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out, rzx_acc, rzx_first)
   static const bool no_pf = getenv("BHG_HEAD_NO_PREFETCH") != nullptr;   // A/B switch
   const bool pf = !no_pf && fuse && C <= 12 && K <= 512 && mode == HEAD_JVP && rd_prev && delta_top && mask_prev;
   if (pf) {
     hipLaunchKernelGGL((k_head_forward<true, 3, true, true>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C,
-                       B, mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out);
+                       B, mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out, rzx_acc, rzx_first);
   } else if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
   else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
   else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
@@ -1838,17 +1841,22 @@ int pick_splits(int tiles, int K, int pairs) {
 }
 
 // coeff[b] = scale * (prob_b - onehot(y_b)) . RzX_b / B   (mixed-derivative coefficient from the accumulated Rz(x))
+//   add_scale != 0: coeff[b] = that + add_scale * coeff[b]  (the accumulator-free Neumann solve: the last direction's share
+//   is already in coeff);  rzx == NULL counts as zero.
 __global__ __launch_bounds__(kThreads) void k_coeff_from_rzx(const double* __restrict__ rzx, const float* __restrict__ prob,
                                                              const int64_t* __restrict__ labels, float* __restrict__ coeff,
-                                                             int rows, int C, int B, float scale) {
+                                                             int rows, int C, int B, float scale, float add_scale) {
   const int b = blockIdx.x * kThreads + threadIdx.x;
   if (b >= rows) return;
   float out = 0.f;
   if (b < B) {
     const int y = (int)labels[b];
     double acc = 0.0;
-    for (int c = 0; c < C; ++c) acc += ((double)prob[(int64_t)b * C + c] - (c == y ? 1.0 : 0.0)) * rzx[(int64_t)b * C + c];
-    out = (float)((double)scale * acc / (double)B);
+    if (rzx)
+      for (int c = 0; c < C; ++c) acc += ((double)prob[(int64_t)b * C + c] - (c == y ? 1.0 : 0.0)) * rzx[(int64_t)b * C + c];
+    double o = (double)scale * acc / (double)B;
+    if (add_scale != 0.f) o += (double)add_scale * (double)coeff[b];
+    out = (float)o;
   }
   coeff[b] = out;
 }
@@ -2061,6 +2069,7 @@ struct ChainMode {
   int x_mode;                   // see FuseArgs.x_mode (applies to the lazy slices only)
   int first;                    // first iteration of a solve (Rz(x) accumulator is set, not added to)
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
+  double* rzx_acc;              // FUSE_NEUMANN without an accumulator vector: sum_k Rz(v_k) lands here (head kernel)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2129,7 +2138,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
                           m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr, l > 0 ? (const float*)m->delta[l] : nullptr,
                           l > 0 ? (const float*)m->mask[l - 1] : nullptr, l > 0 ? m->Rd[l - 1] : nullptr,
                           fuse_head ? &head_fuse : nullptr, cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr,
-                          cg ? cm.ws->rz : nullptr);
+                          cg ? cm.ws->rz : nullptr, cm.rzx_acc, cm.first);
       continue;
     }
     GemmArgs a{};
@@ -2436,6 +2445,20 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
 // ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
 int64_t bhg_mlp_wsk_launches(void) { return bhg::g_wsk_launches; }
 
+int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff, float alpha,
+                                int K, void* fws, size_t fws_bytes, void* stream) {
+  // coefficient of the accumulator-free Neumann solve: p_final = -alpha * sum_{k=0..K} v_k  (neumann.py:64,66 and the
+  // negation of 45/54)  =>  coeff = -alpha * ( coeff(v_K)  +  (prob - onehot) . sum_{k<K} Rz(v_k) / B )
+  BHG_REQUIRE(fws && fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  if (int rc = bhg_mlp_mixed_coeff(m, v_last, labels, coeff, stream)) return rc;   // coeff(v_K): one R-forward
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  hipLaunchKernelGGL(k_coeff_from_rzx, dim3((m->Bp + kThreads - 1) / kThreads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     K > 0 ? (const double*)w.rzx : (const double*)nullptr, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -alpha, -alpha);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
   static const bool off = getenv("BHG_MLP_NO_FUSED_SOLVE") != nullptr;   // A/B switch: callers fall back to HVP + recurrence kernel
   return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m);
@@ -2538,9 +2561,16 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K, float alpha,
                           float hvp_shift, void* fws, size_t fws_bytes, void* stream) {
   if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
-  BHG_REQUIRE(v0 && v1 && p, "NULL argument");
+  // p == NULL: the N-sized accumulator is not materialised.  The mixed second derivative is linear in the direction and
+  // only needs Rz(p_K) = sum_{k=0..K} Rz(v_k): the head kernel of iteration k leaves Rz(v_k) anyway (k < K, summed into the
+  // workspace), and bhg_mlp_neumann_mixed_coeff adds the last term with the one R-forward pass the mixed coefficient
+  // costs in any case (in direction v_K instead of p_K).
+  BHG_REQUIRE(v0 && v1, "NULL argument");
   BHG_REQUIRE(K >= 0, "bad size");
+  BHG_REQUIRE(p || use_head(m), "the accumulator-free Neumann solver needs the narrow-head kernels");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
     float* vout = (k & 1) ? v0 : v1;
@@ -2557,6 +2587,7 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     // the accumulator p is read and written every OTHER iteration (FuseArgs.x_mode): even iterations defer, odd catch up
     static const bool p_every = getenv("BHG_NEUMANN_P_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = p_every ? 0 : ((k & 1) ? 2 : (k + 1 < K ? 1 : 0));
+    if (!p) { cm.x_mode = 1; cm.rzx_acc = w.rzx; cm.first = k == 0; }
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   }
@@ -2572,7 +2603,7 @@ int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff
   carve_fused_ws(m, fws, &w);
   // x_final = -cg_alpha * sum_k alpha_k p_k  (cg.py:56 and the negation of 59/68)  =>  Rz(x_final) = -cg_alpha * RzX
   hipLaunchKernelGGL(k_coeff_from_rzx, dim3((m->Bp + kThreads - 1) / kThreads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     (const double*)w.rzx, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -cg_alpha);
+                     (const double*)w.rzx, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -cg_alpha, 0.f);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void k_neumann_init(PtrTab tab, const bhg
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) {
       st4(v + ck.flat_off, 4 * (threadIdx.x + kThreads * i), ck.len, t[i]);
-      st4(p + ck.flat_off, 4 * (threadIdx.x + kThreads * i), ck.len, t[i]);
+      if (p) st4(p + ck.flat_off, 4 * (threadIdx.x + kThreads * i), ck.len, t[i]);   // p == NULL: see bhg_mlp_neumann_solve
     }
   }
 }
@@ -878,7 +878,7 @@ int bhg_neumann_init(const void* const* vec, int T, const bhg_chunk* chunks_dev,
                      float* p, void* ws, void* stream) {
   BHG_COMMON_CHECKS(vec);
   if (n_chunks == 0) return BHG_OK;
-  BHG_REQUIRE(v && p, "state vector is NULL");
+  BHG_REQUIRE(v, "state vector is NULL");   // p may be NULL (accumulator-free fused solve)
   hipStream_t st = static_cast<hipStream_t>(stream);
   PtrTab tab;
   if (int rc = make_table(&tab, vec, T, ws, 0, st)) return rc;

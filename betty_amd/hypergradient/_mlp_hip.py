@@ -169,6 +169,7 @@ class HipMLPState:
         # validate and build the pointer table once per distinct tensor set (the cache holds the tensors, so
         # their ids cannot be recycled while it is alive).
         self._rzx = None   # a hand-driven HVP invalidates the accumulated Rz(x) of an earlier fused solve
+        self._nrz = None
         key = tuple(map(id, direction_views))
         cached = getattr(self, "_dir_cache", None)
         if cached is None or cached[0] != key:
@@ -212,19 +213,37 @@ class HipMLPState:
         )
         # the solver accumulated Rz(x) on its way: mixed_coeff() of exactly this solution needs no R-forward pass
         self._rzx = (float(cg_alpha), x.data_ptr(), layout)
+        self._nrz = None
 
-    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float) -> None:
-        """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'."""
+    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> None:
+        """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'.
+        keep_p=False: the library gets p = NULL; mixed_coeff() of this solve is then formed from the Rz sums the head
+        kernel collected plus one R-forward of the last direction."""
         fws, starts = self._fused_args(layout)
         _native.check(
-            self.lib.bhg_mlp_neumann_solve(ctypes.byref(self.desc), v0.data_ptr(), v1.data_ptr(), p.data_ptr(), starts, int(K),
-                                           float(alpha), float(shift), fws.data_ptr(), fws.numel(), _stream()),
+            self.lib.bhg_mlp_neumann_solve(ctypes.byref(self.desc), v0.data_ptr(), v1.data_ptr(), p.data_ptr() if keep_p else None,
+                                           starts, int(K), float(alpha), float(shift), fws.data_ptr(), fws.numel(), _stream()),
             "bhg_mlp_neumann_solve",
         )
+        self._rzx = None
+        # v_K sits in v0 after an even number of iterations, in v1 after an odd one
+        self._nrz = None if keep_p else (float(alpha), int(K), p.data_ptr(), layout, v0 if K % 2 == 0 else v1)
 
     def mixed_coeff(self, dir_views):
         """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step."""
         buf, B = self.buf, self.B
+        nrz = getattr(self, "_nrz", None)
+        if nrz is not None and len(dir_views) > 0 and dir_views[0].data_ptr() == nrz[2] + 4 * nrz[3].starts[0]:
+            # `dir_views` name the (never written) accumulator of the fused Neumann solve that just ran
+            lay, v_last = nrz[3], nrz[4]
+            views = [v_last[s: s + n] for s, n in zip(lay.starts, lay.numels)]
+            tab, _keep = self._dir_table(views)
+            _native.check(
+                self.lib.bhg_mlp_neumann_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(),
+                                                     nrz[0], nrz[1], buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                "bhg_mlp_neumann_mixed_coeff",
+            )
+            return buf.coeff[:B].clone()
         rzx = getattr(self, "_rzx", None)
         if rzx is not None and len(dir_views) > 0 and dir_views[0].data_ptr() == rzx[1] + 4 * rzx[2].starts[0]:
             # `dir_views` are the views of the flat solution the fused CG solver just produced

@@ -27,15 +27,18 @@ def neumann(vector, curr, prev, sync):
         in_grad = None
         hvp_fn = provider.prepare()
 
-    layout = be.layout(vector)
-    v, p = layout.state(2)
-    be.neumann_init(layout, vector, v, p)  # p = v   (neumann.py:60)
-    v_views = layout.views(v, vector)
-
     K = int(config.neumann_iterations)
-    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     alpha = float(config.neumann_alpha)
     fused = getattr(provider, "fused_neumann", None)
+    layout = be.layout(vector)
+    v, p = layout.state(2)
+    # a provider whose fused solver derives the mixed derivative from batch-sized factors never touches the accumulator
+    skips = getattr(provider, "fused_neumann_skips_solution", None)
+    skip_p = bool(fused is not None and alpha != 0.0 and skips is not None and skips(layout, K))
+    be.neumann_init(layout, vector, v, None if skip_p else p)  # p = v   (neumann.py:60)
+    v_views = layout.views(v, vector)
+
+    shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
     if fused is not None and alpha != 0.0 and fused(layout, v, p, K, alpha):
         pass  # the provider's own kernels ran all K iterations (v ping-pongs with a third flat vector of the layout)
     else:

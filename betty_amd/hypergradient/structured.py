@@ -123,13 +123,21 @@ class WeightedCEMLP:
         self._state.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift, keep_x=self.keep_solution)
         return True
 
-    def fused_neumann(self, layout, v, p, K: int, alpha: float) -> bool:
+    def fused_neumann_ready(self, layout, K: int) -> bool:
         st = self._state
-        if K <= 0 or not self.fused or not hasattr(st, "neumann_solve") or not st.fused_supported(layout):
+        return K > 0 and self.fused and hasattr(st, "neumann_solve") and st.fused_supported(layout)
+
+    def fused_neumann_skips_solution(self, layout, K: int) -> bool:
+        """True when fused_neumann will run AND leaves the accumulator p untouched (keep_solution=False): the mixed
+        derivative then comes from sum_k Rz(v_k), collected by the head kernel, plus one R-forward of the last v."""
+        return (not self.keep_solution) and self.fused_neumann_ready(layout, K)
+
+    def fused_neumann(self, layout, v, p, K: int, alpha: float) -> bool:
+        if not self.fused_neumann_ready(layout, K):
             return False
         # second direction buffer: the R-backward GEMMs of an HVP still read v while its epilogues write v'
         v_alt = next(t for t in layout.state(3) if t is not v and t is not p)
-        st.neumann_solve(layout, v, v_alt, p, K, alpha, self.hvp_shift)
+        self._state.neumann_solve(layout, v, v_alt, p, K, alpha, self.hvp_shift, keep_p=self.keep_solution)
         return True
 
     def mixed_vjp(self, neg_x_views, sync: bool):

@@ -263,6 +263,13 @@ int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff
  * (k_gemm_wsk: a final 32 x 32 tile per workgroup, no partial slabs, no reduce launch; env BHG_MLP_WSK selects where it
  * is used: 0 nowhere, 1 wherever the shape allows, 2 short reductions only — the fused CG solver's default).      */
 int64_t bhg_mlp_wsk_launches(void);
+/* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
+ * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
+ * in direction v_K (`v_last`: the 2L slices of the direction buffer that holds v_K — v0 for even K, v1 for odd K) into the
+ * mixed-derivative coefficient of p_final = -alpha * sum_{k=0..K} v_k  (the quantity bhg_mlp_mixed_coeff returns for a
+ * materialised p).                                                                                                      */
+int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff,
+                                float alpha, int K, void* fws, size_t fws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
