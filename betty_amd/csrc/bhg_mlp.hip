@@ -1463,7 +1463,12 @@ static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments
 //  "alpha block": block 0 of this launch doing k_cg_alpha's work while all other workgroups run their MFMA phase, the
 //  epilogues picking the result up from 64 replicated 8-byte {tag : alpha} granules with relaxed agent-scope loads — no
 //  fence, no hot word, correct, and 301.7 vs 300.5 steps/s: the step length's dependent loads take ~4 us under the
-//  launch's own operand burst, the first tiles' epilogues wait for them, and the launch grows by what it saved.)
+//  launch's own operand burst, the first tiles' epilogues wait for them, and the launch grows by what it saved.
+//  Nor a tile QUEUE: 768 / 1024 resident workgroups popping tile numbers from one agent-scope counter (self-rewinding:
+//  the workgroup that draws number total + grid - 1 knows nobody pops again), largest-layer-first or two-pair-tiles-
+//  first: 264 / 260 / 256 vs 301 steps/s (CG), 575-582 vs 626 (Neumann) — the loop around the tile bodies alone costs
+//  8 % (the compiler no longer keeps the per-tile descriptors in SGPRs), and a popped second tile starts cold where a
+//  freshly dispatched workgroup's first loads are already in flight when its predecessor drains.)
 // Where its time goes (CG 56 us / Neumann 41 us at the benchmark, state traffic 200 MB / 120 MB): the two fit
 // T = 18 us + bytes / 5.3 TB/s, i.e. the MFMA phase (17.5 us is the fp32 matrix-pipe floor of the 4 GFLOP) and the
 // streaming of the state slices ADD UP — the four workgroups of a CU start together, so they all sit in the MFMA phase
