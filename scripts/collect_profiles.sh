@@ -13,7 +13,7 @@ c $g/timeline_neumann_fused.txt $p/r02_timeline_neumann_fused.txt
 c $g/outside_fused.txt $p/r02_outside_the_k_loop.txt
 c $g/pmc/r02_pmc_traffic.json $p/r02_pmc_traffic.json
 c $g/pmc/r02_mfma_busy.json $p/r02_mfma_busy.json
-for t in cg_nofuse cg_autograd neumann_fused neumann_nofuse darts cg_global_ws1; do c $g/bench_$t.json $p/r02_bench_$t.json; done
+for t in cg_nofuse cg_keep_solution neumann_keep_solution cg_autograd neumann_fused neumann_nofuse darts cg_global_ws1; do c $g/bench_$t.json $p/r02_bench_$t.json; done
 c $g/bench_kernels_N10M_cached.json $p/r02_bench_kernels_N10M_cached.json
 c $g/bench_kernels_N10M_cache_defeated.json $p/r02_bench_kernels_N10M_cache_defeated.json
 c $g/bench_kernels_N120M.json $p/r02_bench_kernels_N120M.json

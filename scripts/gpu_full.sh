@@ -19,6 +19,8 @@ except Exception as e:
 PY
 }
 run cg_nofuse --algo cg --no-fuse
+run cg_keep_solution --algo cg --keep-solution
+run neumann_keep_solution --algo neumann --cg-iters 10 --keep-solution
 run cg_autograd --algo cg --hvp autograd --steps 20
 run neumann_fused --algo neumann --cg-iters 10
 run neumann_nofuse --algo neumann --cg-iters 10 --no-fuse

@@ -659,7 +659,8 @@ def test_fused_solver_full_size_cfg2():
 
 @pytest.mark.parametrize(
     "dims,B",
-    [([256, 384, 128, 10], 100), ([512, 256, 256, 64, 10], 128), ([256, 128, 64, 10], 64), ([768, 64, 32, 10], 37)],
+    [([256, 384, 128, 10], 100), ([512, 256, 256, 64, 10], 128), ([256, 128, 64, 10], 64), ([768, 64, 32, 10], 37),
+     ([256, 256, 256, 256, 128, 10], 100), ([512, 256, 64, 10], 200)],
     ids=lambda v: str(v),
 )
 def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
