@@ -1682,6 +1682,16 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  // epilogue operands of this thread's two outputs: requested before the K loop, they land under it
+  float e_mask[2], e_rh[2], e_bias[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = threadIdx.x + 64 * kWskWaves * u;
+    const int64_t idx = (int64_t)(m0 + (e >> 5)) * a.N + n0 + (e & 31);
+    e_mask[u] = a.mask ? a.mask[idx] : 1.f;
+    e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
+    e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
+  }
   if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc);
   else wsk_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc);
 
@@ -1698,16 +1708,17 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
   __syncthreads();
   double t2 = 0.0;
 #pragma unroll
-  for (int e = threadIdx.x; e < 32 * 32; e += 64 * kWskWaves) {
+  for (int u = 0; u < 2; ++u) {
+    const int e = threadIdx.x + 64 * kWskWaves * u;
     const int row = e >> 5, col = e & 31;
     const int m = m0 + row, n = n0 + col;
     const int64_t idx = (int64_t)m * a.N + n;
     float v = 0.f;
     for (int w = 0; w < nwp; ++w) v += sP[w][row][col];
-    if (a.partT2 && m < a.B) t2 += (double)v * (double)a.rh[idx];
+    if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
     for (int w = nwp; w < kWskWaves; ++w) v += sP[w][row][col];
-    if (a.bias) v += a.bias[n];
-    if (a.mask) v *= a.mask[idx];
+    if (a.bias) v += e_bias[u];
+    if (a.mask) v *= e_mask[u];
     a.out[idx] = m < a.B ? v : 0.f;
   }
   if (a.partT2) {
