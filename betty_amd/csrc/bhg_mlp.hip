@@ -2088,6 +2088,7 @@ struct ChainMode {
   int first;                    // first iteration of a solve (Rz(x) accumulator is set, not added to)
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
   double* rzx_acc;              // FUSE_NEUMANN without an accumulator vector: sum_k Rz(v_k) lands here (head kernel)
+  int skip_outputs;             // FUSE_CG: stop after the step length (see bhg_mlp_cg_solve)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2345,6 +2346,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   if (single) {
     // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
     if (cg) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
+      BHG_HIP_CHECK(hipGetLastError());
+      return BHG_OK;
+    }
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
@@ -2563,6 +2568,9 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
     if (!x) cm.x_mode = 1;
+    // Without a solution vector the LAST iteration ends with its step length: alpha_{K-1} completes Rz(x) (k_cg_alpha), and
+    // nothing reads the residual, the direction or x of cg.py:49-53 after it — the weight-shaped outputs are not computed.
+    cm.skip_outputs = (!x && k == K - 1) ? 1 : 0;
     cm.first = k == 0;
     cm.kpar = k & 1;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
