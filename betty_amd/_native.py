@@ -109,6 +109,7 @@ SYMBOLS = {
     ),
     "bhg_mlp_partial_floats": (c_size_t, [POINTER(Mlp)]),
     "bhg_mlp_hvp": (c_int, [POINTER(Mlp), _PP, _PP, c_void_p]),
+    "bhg_mlp_hvp_mode": (c_int, [POINTER(Mlp), _PP, _PP, c_int, c_void_p]),
     "bhg_mlp_supports_native_prepare": (c_int, [POINTER(Mlp)]),
     "bhg_mlp_forward": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_void_p]),
     "bhg_mlp_backward": (c_int, [POINTER(Mlp), c_void_p, c_void_p]),

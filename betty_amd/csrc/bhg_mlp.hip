@@ -1648,9 +1648,112 @@ __device__ __forceinline__ void wsk_loop(const GemmPair& pr, const int m0, const
     if (s + d < nch) compute(d);
 }
 
-template <int LB, bool BF, int D>
+// The same K loop with COALESCED global loads (8 lanes per 128-B row segment: 8 full cache lines per instruction instead of
+// 16 half lines) staged through a wave-private LDS tile (written and read back by the same wave, in order: no barrier)
+// into the MFMA layout — the transposition the direct form asks of the vector cache's address path is done by LDS.
+// Long reductions: 27.8 / 31.1 / 24.8 us against the direct form's 37.3 / 40.4 / 30.2 us (cfg-2 shapes); only the
+// R-backward into layer 0 beats split-K + reduce (26.9 us).  Two register stages (three spill).
+constexpr int kWslPad = 36;                              // LDS row stride (floats): 16-B aligned rows, conflict-free 16-lane groups
+constexpr int kWslWaveFloats = 2 * 32 * kWslPad;         // A tile + B tile of one wave
+template <int LB, bool MIX, int D>
+__device__ __forceinline__ void wsl_loop(const GemmPair& pr, const int m0, const int n0, const int kbeg, const int nch,
+                                         const float bs, f32x4 (&acc)[2][2], float* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int lr = lane >> 3, lq = lane & 7;               // loader: row (of 8 per instruction), 16-B piece of the row
+  float* sA = lds;
+  float* sB = lds + 32 * kWslPad;
+  const float* gA = pr.A + (int64_t)(m0 + lr) * pr.lda + kbeg + 4 * lq;
+  const float* gB;
+  const float* gQ;
+  if (LB == LAYOUT_KC) {
+    gB = pr.B + (int64_t)(n0 + lr) * pr.ldb + kbeg + 4 * lq;
+    gQ = pr.B2 + (int64_t)(n0 + lr) * pr.ldb + kbeg + 4 * lq;
+  } else {
+    gB = pr.B + (int64_t)(kbeg + lr) * pr.ldb + n0 + 4 * lq;
+    gQ = pr.B2 + (int64_t)(kbeg + lr) * pr.ldb + n0 + 4 * lq;
+  }
+  const int64_t a8 = (int64_t)8 * pr.lda, b8 = (int64_t)8 * pr.ldb;
+  f32x4 ra[D][4], rb[D][4], rq[D][4];
+  auto load = [&](const int d, int ch) {
+    ch = min(ch, nch - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[d][i] = *reinterpret_cast<const f32x4*>(gA + i * a8 + ch * 32);
+      const int64_t ob = LB == LAYOUT_KC ? i * b8 + ch * 32 : (int64_t)(ch * 32 + 8 * i) * pr.ldb;
+      rb[d][i] = *reinterpret_cast<const f32x4*>(gB + ob);
+      if (MIX) rq[d][i] = *reinterpret_cast<const f32x4*>(gQ + ob);
+    }
+  };
+  auto compute = [&](const int d) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 b = rb[d][i];
+      if (MIX) {   // p = r' + (beta * p_old): the two roundings of k_cg_pdir
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = __fadd_rn(b[c], __fmul_rn(bs, rq[d][i][c]));
+      }
+      *reinterpret_cast<f32x4*>(sA + (8 * i + lr) * kWslPad + 4 * lq) = ra[d][i];
+      *reinterpret_cast<f32x4*>(sB + (8 * i + lr) * kWslPad + 4 * lq) = b;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sA + li * kWslPad + 16 * h + 4 * lk);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(sA + (16 + li) * kWslPad + 16 * h + 4 * lk);
+      float b0[4], b1[4];
+      if (LB == LAYOUT_KC) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sB + li * kWslPad + 16 * h + 4 * lk);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sB + (16 + li) * kWslPad + 16 * h + 4 * lk);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b0[c] = v0[c]; b1[c] = v1[c]; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          b0[c] = sB[(16 * h + 4 * lk + c) * kWslPad + li];
+          b1[c] = sB[(16 * h + 4 * lk + c) * kWslPad + 16 + li];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    load(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int s = 0;
+  for (; s + 2 * D <= nch; s += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(d);
+      __builtin_amdgcn_sched_barrier(0);
+      load(d, s + D + d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (s + d < nch) compute(d);
+    if (s + D + d < nch) load(d, s + D + d);
+  }
+  s += D;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (s + d < nch) compute(d);
+}
+
+template <int LB, bool BF, int D, bool LDSV = false>
 __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
-  __shared__ float sP[kWskWaves][32][kWskPad];
+  // LDSV: dynamic LDS = 8 wave-private staging tiles (73.7 KB); the partial-tile exchange aliases them after the loop
+  extern __shared__ __attribute__((aligned(16))) float wsl_smem[];
+  __shared__ float sP_static[LDSV ? 1 : kWskWaves * 32 * kWskPad];
+  float (*sP)[32][kWskPad] = reinterpret_cast<float (*)[32][kWskPad]>(LDSV ? wsl_smem : sP_static);
   __shared__ double red[kWskWaves];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1692,7 +1795,12 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
     e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
     e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
   }
-  if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc);
+  if (LDSV) {
+    float* my = wsl_smem + wave * kWslWaveFloats;
+    if (BF && pr.mix) wsl_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc, my);
+    else wsl_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc, my);
+    __syncthreads();   // every wave is done with its staging tile before the partial tiles overwrite them
+  } else if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc);
   else wsk_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc);
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -1702,7 +1810,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = LB == LAYOUT_KC ? 16 * cb + li : 2 * li + cb;
+        const int col = (LB == LAYOUT_KC || LDSV) ? 16 * cb + li : 2 * li + cb;
         sP[wave][16 * rb + 4 * lk + r][col] = acc[rb][cb][r];
       }
   __syncthreads();
@@ -1741,15 +1849,19 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
 // a lane's 16-B loads in MFMA layout touch 16 cache lines per instruction (64 B of each), and the vector cache's
 // address path retires about one line per 4 clocks — 8 waves x 12 loads x 16 lines x 4 clk per 32-k chunk is three times
 // the chunk's MFMA time.  Read on every call so a test can compare both arms in one process.
-inline int wsk_mode(bool fused_cg) {
+inline int wsk_mode(int chain_mode, int unfused_hint) {
   const char* e = getenv("BHG_MLP_WSK");
-  // default: short reductions of the fused CG solver only — the un-fused arm and the Neumann solver (whose fused and
-  // un-fused arms are bitwise equal, a tested property) keep one GEMM path; an explicit value applies everywhere
-  return e ? atoi(e) : (fused_cg ? 2 : 0);
+  if (e) return atoi(e);   // an explicit value applies everywhere
+  // defaults: fused CG solver 2 (short reductions; the staged form of mode 3 is +0.75 % there but draws 2.3e-4 from the fp64
+  // truth in the CG-20 noise lottery); the Neumann solver — no reduction, no chaos — 3 in BOTH of its arms
+  // (the un-fused arm asks for it through bhg_mlp_hvp_mode, so fused and un-fused stay bitwise equal); everything else 0
+  if (chain_mode == FUSE_CG) return 2;
+  if (chain_mode == FUSE_NEUMANN) return 3;
+  return unfused_hint;
 }
 inline bool wsk_wanted(int mode, int pairs, int K) {
   if (mode == 1) return true;
-  if (mode != 2) return false;
+  if (mode != 2 && mode != 3) return false;
   const char* e = getenv("BHG_MLP_WSK_MAXK");
   return pairs * K <= (e ? atoi(e) : 1024);
 }
@@ -1767,7 +1879,7 @@ inline bool wsk_eligible(const WskArgs& a) {
 }
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 template <int LB>
-void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st) {
+void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
   ++g_wsk_launches;
   a.ntm = a.M / 32;
@@ -1776,6 +1888,19 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st) {
   for (int i = 0; i < a.pairs; ++i) bf = bf || a.pr[i].mix != 0;
   const dim3 grid(a.ntm * a.ntn), block(64 * kWskWaves);
   const int d = wsk_depth();
+  static const bool force_staged = getenv("BHG_MLP_WSK_LDS") != nullptr && atoi(getenv("BHG_MLP_WSK_LDS")) != 0;
+  if (staged || force_staged) {   // LDS-staged form (two register stages: three spill)
+    const int lds = (int)(sizeof(float) * kWslWaveFloats * kWskWaves);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_done = true;
+    }
+    if (bf) hipLaunchKernelGGL((k_gemm_wsk<LB, true, 2, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_gemm_wsk<LB, false, 2, true>), grid, block, lds, st, a);
+    return;
+  }
 #define BHG_WSK(BFV, DV) hipLaunchKernelGGL((k_gemm_wsk<LB, BFV, DV>), grid, block, 0, st, a)
   if (bf) {
     // (N-contiguous B with the lazy direction holds 48 registers per stage: three stages would spill)
@@ -2089,6 +2214,7 @@ struct ChainMode {
   int lazy;                     // the direction at fd is the previous one; this iteration's is fa + beta * fd
   double* rzx_acc;              // FUSE_NEUMANN without an accumulator vector: sum_k Rz(v_k) lands here (head kernel)
   int skip_outputs;             // FUSE_CG: stop after the step length (see bhg_mlp_cg_solve)
+  int gemm_mode;                // FUSE_NONE: BHG_MLP_WSK-style mode asked for by the caller (bhg_mlp_hvp_mode)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2117,7 +2243,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   SideState& ss = *ssp;
   hipStream_t side = ss.side;
   const int tn = skinny_tile_n();
-  const int wsk = wsk_mode(cg);
+  const int wsk = wsk_mode(cm.mode, cm.gemm_mode);
 
   FuseArgs fbase{};
   fbase.scal = cm.scal; fbase.part = cm.partRR_new; fbase.alpha = cm.alpha; fbase.shift = cm.shift;
@@ -2308,14 +2434,15 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     a.pr[1] = {m->Rd[l], m->W[l], K, N};
     a.pairs = 2;
     a.M = Bp; a.N = N; a.K = K;
-    if (wsk_wanted(wsk, 2, K)) {
+    const bool wsk_short = wsk_wanted(wsk, 2, K);
+    if (wsk_short || wsk == 3) {   // mode 3: long R-backward reductions in the LDS-staged form
       WskArgs w{};
       w.pr[0] = a.pr[0]; w.pr[1] = a.pr[1]; w.pairs = 2; w.M = Bp; w.N = N; w.K = K; w.B = B;
       w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.scal = cm.scal;
       if (cg) { w.rh = m->Rh[l - 1]; w.partT2 = cm.ws->partT2 + cm.ws->t2_off[l]; }
       // (the T2 partial slots were carved for the reduce launch's block count: one per 1024 outputs, like the tiles here)
       if (wsk_eligible(w) && (!cg || (Bp / 32) * (N / 32) == reduce_blocks(Bp * N, N))) {
-        launch_gemm_wsk<LAYOUT_RC>(w, st);
+        launch_gemm_wsk<LAYOUT_RC>(w, st, !wsk_short);
         continue;
       }
     }
@@ -2450,7 +2577,12 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m) {
 }
 
 int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream) {
+  return bhg_mlp_hvp_mode(m, dir, out, 0, stream);
+}
+
+int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out, int gemm_mode, void* stream) {
   if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(gemm_mode >= 0 && gemm_mode <= 3, "gemm_mode is 0 .. 3");
   BHG_REQUIRE(dir && out, "NULL argument");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2460,6 +2592,7 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
   ChainMode cm{};
   cm.mode = FUSE_NONE;
   cm.out = out;
+  cm.gemm_mode = gemm_mode;
   if (int rc = run_chain(m, dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(t_b, st));
   return BHG_OK;

@@ -178,7 +178,9 @@ class HipMLPState:
             # only a table that names the CALLER's tensors may be reused: a converted clone goes stale as soon as
             # the caller changes the direction in place
             self._dir_cache = cached if all(a is b for a, b in zip(keep[0], direction_views)) else None
-        _native.check(self.lib.bhg_mlp_hvp(ctypes.byref(self.desc), cached[1], self._out_tab, _stream()), "bhg_mlp_hvp")
+        # the un-fused Neumann loop asks for the GEMM forms the fused Neumann solver uses (bitwise-equal arms)
+        mode = 3 if getattr(getattr(self.spec.curr, "config", None), "type", None) == "neumann" else 0
+        _native.check(self.lib.bhg_mlp_hvp_mode(ctypes.byref(self.desc), cached[1], self._out_tab, mode, _stream()), "bhg_mlp_hvp_mode")
         return self.out
 
     # ---- fused solvers (csrc/bhg_mlp.hip: bhg_mlp_cg_solve / bhg_mlp_neumann_solve) -----------------------------------

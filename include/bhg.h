@@ -219,6 +219,10 @@ size_t bhg_mlp_partial_floats(const bhg_mlp* m);
 /* dir / out: host arrays of 2L device pointers [V_0, c_0, V_1, c_1, ...] / [H(W_0), H(b_0), ...]
  * (contiguous fp32, 16-byte aligned; out tensors are fully overwritten).                         */
 int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void* stream);
+/* The same with the caller's choice of the skinny GEMMs' form (values of BHG_MLP_WSK: 0 split-K launches + reduce, 1 / 2 /
+ * 3 in-workgroup split-K everywhere / for short reductions / plus the LDS-staged form for the long R-backward).  The
+ * un-fused Neumann loop passes 3 — what the fused Neumann solver uses — so the two arms stay bitwise comparable.     */
+int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out, int gemm_mode, void* stream);
 
 /* Once-per-step passes on the same descriptor (narrow classifier head: dims[L] <= 32, dims[L-1] % 4 == 0;
  * bhg_mlp_supports_native_prepare tells).  They write the direction-independent buffers the HVP reads:

@@ -692,18 +692,30 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
     assert all(np.array_equal(u, v) for u, v in zip(again[1], sols["1"][1]))
 
 
-def test_wsk_is_the_fused_cg_default_for_short_reductions_only(monkeypatch):
-    """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k, the
-    un-fused chain and the Neumann solver never do (their fused / un-fused arms stay bitwise comparable)."""
+def test_wsk_defaults_per_solver(monkeypatch):
+    """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k (mode 2); the
+    un-fused CG chain never does; the Neumann solver uses mode 3 (short reductions direct, long R-backward LDS-staged)
+    in BOTH arms — the un-fused loop asks for it through bhg_mlp_hvp_mode — so they stay bitwise equal."""
     monkeypatch.delenv("BHG_MLP_WSK", raising=False)
     lib = _native.load()
     dims, B = [256, 384, 128, 10], 100     # per iteration: R-forward of layer 0 (256 k) and R-backward into it (2 x 128 k)
     n0 = lib.bhg_mlp_wsk_launches()
-    _run_solver("neumann", dims, B, 0.05, 3, 11, True)
     _run_solver("cg", dims, B, 0.05, 3, 11, False)
     assert lib.bhg_mlp_wsk_launches() == n0
     _run_solver("cg", dims, B, 0.05, 3, 11, True)
-    assert lib.bhg_mlp_wsk_launches() == n0 + 2 * 3
+    n1 = lib.bhg_mlp_wsk_launches()
+    assert n1 == n0 + 2 * 3
+    _, st_f = _run_solver("neumann", dims, B, 0.05, 3, 11, True)
+    n2 = lib.bhg_mlp_wsk_launches()
+    _, st_u = _run_solver("neumann", dims, B, 0.05, 3, 11, False)
+    n3 = lib.bhg_mlp_wsk_launches()
+    assert n2 - n1 == 2 * 3 and n3 - n2 == 2 * 3
+    assert np.array_equal(st_f[0], st_u[0])
+    # a long R-backward reduction (2 x 1024 k) in the Neumann solver: the LDS-staged form, still bitwise equal to the un-fused arm
+    dims2 = [256, 1024, 1024, 10]
+    _, s_f = _run_solver("neumann", dims2, B, 0.05, 2, 12, True)
+    _, s_u = _run_solver("neumann", dims2, B, 0.05, 2, 12, False)
+    assert np.array_equal(s_f[0], s_u[0])
 
 
 def test_cg_variants_may_alternate_inside_a_solve(be):
