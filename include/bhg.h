@@ -265,7 +265,8 @@ int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff
                            size_t fws_bytes, void* stream);
 /* Test / measurement hook: how many of the chain's skinny GEMMs this process launched in the in-workgroup split-K form
  * (k_gemm_wsk: a final 32 x 32 tile per workgroup, no partial slabs, no reduce launch; env BHG_MLP_WSK selects where it
- * is used: 0 nowhere, 1 wherever the shape allows, 2 short reductions only — the fused CG solver's default).      */
+ * is used: 0 nowhere, 1 wherever the shape allows, 2 short reductions only — the fused CG solver's default —, 3 the
+ * same plus the LDS-staged form for the long R-backward reduction — the Neumann solver's default).              */
 int64_t bhg_mlp_wsk_launches(void);
 /* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
  * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
