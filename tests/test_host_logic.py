@@ -243,3 +243,81 @@ def test_step_length_identity_of_the_fused_cg_solver_fp64(dims, B):
     pp = sum((q * q).sum() for q in p)
     factored = t1 + t2 + prov.hvp_shift * pp
     assert abs(float(direct - factored)) <= 1e-12 * abs(float(direct))
+
+
+# ------------------------------------------------------------------------------------------------
+# solution-free protocol of the structured providers (host orchestration only; the kernels behind it are
+# tested on the GPU: test_fused_cg_without_a_solution_vector, test_fused_neumann_without_an_accumulator_vector)
+# ------------------------------------------------------------------------------------------------
+class _RecordingBackend:
+    """Records what cg() / neumann() hand to the backend; the state vectors are plain CPU tensors."""
+
+    def __init__(self):
+        self.calls = []
+
+    def layout(self, tensors):
+        from betty_amd.flat import layout_for
+
+        return layout_for(tensors)
+
+    def cg_init(self, layout, vector, x, r, p):
+        self.calls.append(("cg_init", x is None))
+
+    def neumann_init(self, layout, vector, v, p):
+        self.calls.append(("neumann_init", p is None))
+
+    def after_cg(self, layout):
+        self.calls.append(("after_cg",))
+
+
+class _FakeFusedProvider:
+    """A structured provider whose fused solvers exist and, depending on `free`, leave the solution untouched."""
+
+    hvp_shift = 0.0
+
+    def __init__(self, prev, free, ready=True):
+        self.prev, self.free, self.ready, self.seen = prev, free, ready, []
+
+    def prepare(self):
+        return lambda views: (_ for _ in ()).throw(AssertionError("the un-fused loop must not run"))
+
+    def fused_cg_skips_solution(self, layout, K):
+        return self.free and self.ready
+
+    def fused_neumann_skips_solution(self, layout, K):
+        return self.free and self.ready
+
+    def fused_cg(self, layout, x, r, p, K, alpha):
+        self.seen.append(("fused_cg", K, alpha))
+        return self.ready
+
+    def fused_neumann(self, layout, v, p, K, alpha):
+        self.seen.append(("fused_neumann", K, alpha))
+        return self.ready
+
+    def mixed_vjp(self, views, sync):
+        self.seen.append(("mixed_vjp", [tuple(v.shape) for v in views], sync))
+        return [torch.zeros_like(q) for q in self.prev.trainable_parameters()]
+
+
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+@pytest.mark.parametrize("free", [True, False])
+def test_solution_free_protocol_of_structured_providers(algo, free):
+    """cg() / neumann() skip zeroing (and never pass) the solution / accumulator vector exactly when the provider's fused
+    solver declares it leaves that vector untouched; the provider's mixed_vjp still receives views shaped like the
+    inner parameters (they NAME the solve; a solution-free provider does not read them)."""
+    inner, upper = zoo.MLP([6, 5, 3]), zoo.MWN(4)
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    cfg = Config(type=algo, cg_iterations=3, neumann_iterations=3, cg_alpha=1.0, neumann_alpha=0.1)
+    curr = zoo.StubProblem("inner", inner, config=cfg)
+    provider = _FakeFusedProvider(prev, free)
+    curr.hypergradient_structure = lambda prev_: provider
+    vector = [torch.randn_like(p) for p in inner.parameters()]
+    be = _RecordingBackend()
+    with use_backend(be):
+        out = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
+    assert len(out) == len(list(prev.trainable_parameters()))
+    assert be.calls[0] == (f"{algo}_init", free)
+    assert provider.seen[0][0] == f"fused_{algo}" and provider.seen[0][1] == 3
+    kind, shapes, sync = provider.seen[-1]
+    assert kind == "mixed_vjp" and sync is False and shapes == [tuple(p.shape) for p in inner.parameters()]
