@@ -92,23 +92,25 @@ def declare_structure(curr, impl, fused=True, keep_solution=False):
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
     curr.hypergradient_structure = lambda prev: WeightedCEMLP(
-        curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=RIDGE, impl=impl,
+        curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=curr.ridge, impl=impl,
         fused=fused, keep_solution=keep_solution,
     )
 
 
-def make_loss(upper):
+def make_loss(upper, ridge=RIDGE):
     def loss(self, batch):
         x, y = batch
         ce = F.cross_entropy(self.fwd(x), y, reduction="none")
         w = upper.fwd(ce.detach().reshape(-1, 1)).reshape(-1)
         out = torch.mean(w * ce)
-        return out + RIDGE * sum((p * p).sum() for p in self.module.parameters())
+        return out + ridge * sum((p * p).sum() for p in self.module.parameters())
 
     return loss
 
 
-def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg", data_seed=None):
+def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg", data_seed=None, ridge=RIDGE):
+    """ridge = RIDGE is the metric workload; tests/golden/cfg2_full.npz also pins a well-conditioned
+    variant of the same shapes (ridge = RIDGE_WELL, see tests/golden/make_cfg2_golden.py)."""
     torch.manual_seed(seed)
     inner = InnerMLP().to(device=device, dtype=dtype)
     mwn = MWN(100).to(device=device, dtype=dtype)
@@ -130,7 +132,8 @@ def build(device, seed, dtype=torch.float32, ddp=False, K=20, algo="cg", data_se
         "neumann": Config(type="neumann", neumann_iterations=K, neumann_alpha=0.1),
         "darts": Config(type="darts", darts_alpha=0.01),
     }[algo]
-    curr = Problem("inner", inner, cfg, loss_fn=make_loss(prev), batch=(x, y))
+    curr = Problem("inner", inner, cfg, loss_fn=make_loss(prev, ridge), batch=(x, y))
+    curr.ridge = ridge
     return curr, prev, vector
 
 
@@ -302,7 +305,7 @@ def main():
     fused = args.hvp == "analytic" and not args.no_fuse and args.algo in ("cg", "neumann") and args.mode == "replica"
     # the predicate bhg_cg_step itself uses (capacity AND the residency census)
     resident = (not fused) and (args.variant == "resident" or (
-        args.variant == "auto" and layout.n_chunks <= be.lib.bhg_cg_resident_capacity_chunks() and bool(be.lib.bhg_cg_resident_ok())))
+        args.variant == "auto" and bool(be.lib.bhg_cg_resident_usable(int(layout.n_chunks)))))
 
     # per-launch timing: HIP events attached to the kernels / launch groups themselves on the launch stream
     # (hipExtLaunchKernelGGL / hipEventRecord inside libbhg; bhg_timing_enable/read in include/bhg.h)

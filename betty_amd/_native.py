@@ -90,6 +90,7 @@ SYMBOLS = {
     "bhg_cg_partials_count": (c_int, []),
     "bhg_cg_resident_capacity_chunks": (c_int, []),
     "bhg_cg_resident_ok": (c_int, []),
+    "bhg_cg_resident_usable": (c_int, [c_int]),
     "bhg_cg_scalars_dev": (c_void_p, [c_void_p]),
     "bhg_cg_timeout_flag_dev": (c_void_p, [c_void_p]),
     "bhg_scale_flat": (c_int, [c_void_p, c_int64, c_float, c_void_p]),

@@ -146,8 +146,8 @@ class HipBackend:
             return layout._cg_variant
         v = self.cg_variant if variant is None else variant
         if v == _native.BHG_CG_AUTO:
-            cap = int(self.lib.bhg_cg_resident_capacity_chunks())
-            resident = 0 < layout.n_chunks <= cap and self.collectives_in_flight == 0 and bool(self.lib.bhg_cg_resident_ok())
+            # the library's own AUTO predicate (capacity, residency census, LDS grant for the larger instances)
+            resident = self.collectives_in_flight == 0 and bool(self.lib.bhg_cg_resident_usable(int(layout.n_chunks)))
             v = _native.BHG_CG_RESIDENT if resident else _native.BHG_CG_STREAM
         layout._cg_variant = v
         return v

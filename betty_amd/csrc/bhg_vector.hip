@@ -14,6 +14,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "bhg_common.hpp"
 
 namespace bhg {
@@ -930,6 +932,32 @@ static unsigned spin_limit() {
   return v;
 }
 
+// The LDS-assisted and hybrid resident instances park direction slices in 144 KiB of dynamic LDS per workgroup.  Probed
+// once per device (mutex-guarded: the first CG steps of two host threads may race): the attribute must be granted for
+// both instances AND the device must report that much LDS per workgroup.
+static bool resident_lds_instances_ok() {
+  static std::mutex mu;
+  static signed char per_device[kMaxDevices];   // 0 unknown, 1 ok, -1 unavailable
+  const int dev = current_device();
+  if (dev < 0 || dev >= kMaxDevices) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (per_device[dev] == 0) {
+    constexpr size_t lds = (size_t)kResLds * kResV * kResThreads * sizeof(float4);
+    int max_lds = 0;
+    bool ok = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && optin > max_lds) max_lds = optin;
+    ok = ok && (size_t)max_lds >= lds;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResMaxLds, kResLds, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResHyb, kResLds, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    per_device[dev] = ok ? 1 : -1;
+  }
+  return per_device[dev] == 1;
+}
+
 int bhg_cg_resident_capacity_chunks(void) { return num_cus() * 2 * kResHyb; }
 
 // One-time residency census (MI355X_MICROARCH.md "Residency and cooperative launch": size grid-barrier
@@ -972,6 +1000,15 @@ int bhg_cg_resident_ok(void) {
   return cached = ok;
 }
 
+int bhg_cg_resident_usable(int n_chunks) {
+  const int cap = bhg_cg_resident_capacity_chunks();
+  if (n_chunks <= 0 || cap <= 0 || n_chunks > cap || !bhg_cg_resident_ok()) return 0;
+  // beyond the register-only size the resident instances need 144 KiB of dynamic LDS per workgroup: on a device or
+  // partition that does not grant it, AUTO streams instead of failing the step
+  if (n_chunks > num_cus() * kResMax && !resident_lds_instances_ok()) return 0;
+  return 1;
+}
+
 const double* bhg_cg_scalars_dev(const void* ws) {
   return reinterpret_cast<const double*>(static_cast<const char*>(ws) + kWsScal);
 }
@@ -990,8 +1027,7 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
   BHG_REQUIRE(x && r && p, "state vector is NULL");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int cap = bhg_cg_resident_capacity_chunks();
-  if (variant == BHG_CG_AUTO)
-    variant = (n_chunks <= cap && cap > 0 && bhg_cg_resident_ok()) ? BHG_CG_RESIDENT : BHG_CG_STREAM;
+  if (variant == BHG_CG_AUTO) variant = bhg_cg_resident_usable(n_chunks) ? BHG_CG_RESIDENT : BHG_CG_STREAM;
   if (variant == BHG_CG_RESIDENT && n_chunks > cap) {
     set_error("bhg_cg_step: %d chunks exceed the resident capacity of %d", n_chunks, cap);
     return BHG_ERR_CAPACITY;
@@ -1030,16 +1066,8 @@ int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int 
                             hvp_shift, (const double*)partR_old, partR_new, partP,
                             reinterpret_cast<unsigned*>(w + kWsBarrier), scal, spin_limit());
     } else {
-      static bool attr_set[kMaxDevices];
-      const int dev = current_device();
       constexpr size_t lds = (size_t)kResLds * kResV * kResThreads * sizeof(float4);
-      if (dev >= 0 && !attr_set[dev]) {
-        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResMaxLds, kResLds, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident<kResHyb, kResLds, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-      }
+      BHG_REQUIRE(resident_lds_instances_ok(), "this device does not grant the resident kernel's 144 KiB of dynamic LDS");
       if (n_chunks <= G * kResMaxLds)   // LDS-assisted instance: 9 direction slices per workgroup parked in LDS (15.7 M elements)
         hipExtLaunchKernelGGL((k_cg_resident<kResMaxLds, kResLds, false>), dim3(G), dim3(kResThreads), lds, st, timed ? ea : nullptr,
                               timed ? eb : nullptr, 0, tab, chunks_dev, n_chunks, x, r, p, cg_alpha, iter, out_scale,

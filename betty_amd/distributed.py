@@ -16,6 +16,7 @@ stream, and the averaged result is scattered back only when the optimizer needs 
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -28,18 +29,27 @@ class ExchangeHandle:
     def __init__(self, layout, flat, like, work, world, backend=None):
         self._layout, self._flat, self._like, self._work, self._world = layout, flat, like, work, world
         self._be = backend
+        self._counted = None
         if work is not None and backend is not None:
             backend.collectives_in_flight += 1   # resident CG kernel is not eligible while RCCL kernels hold CUs
+            # a handle that is dropped without wait() (an exception between issue and use) must not disable the resident
+            # kernel for the rest of the process: the finalizer gives the count back
+            self._counted = weakref.finalize(self, _release, backend)
 
     def wait(self) -> List[torch.Tensor]:
         """Block the CURRENT stream (not the host) on the collective and return the averaged tensors
-        (views of the flat buffer)."""
+        (views of the flat buffer).  The resident CG kernel becomes eligible again for launches on THIS stream
+        (ordered behind the collective by the wait); solves on other streams must wait on the handle themselves."""
         if self._work is not None:
             self._work.wait()
             self._work = None
-            if self._be is not None:
-                self._be.collectives_in_flight -= 1
+            if self._counted is not None:
+                self._counted()   # runs _release once (and detaches the finalizer)
         return self._layout.views(self._flat, self._like)
+
+
+def _release(backend):
+    backend.collectives_in_flight = max(0, backend.collectives_in_flight - 1)
 
 
 def exchange_async(grads: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None) -> ExchangeHandle:

@@ -27,8 +27,11 @@ class EngineConfig:
     # strategy "distributed" only (extension, not in the reference): an upper problem with at least this many
     # parameters exchanges its hypergradient as ONE flat asynchronous all-reduce per path (betty_amd.distributed) —
     # the exchange of path i runs on the communication stream while the CG solve of path i+1 runs — instead of
-    # through the DDP reducer's 25 MB buckets; its module is then NOT DDP-wrapped.  0 = always use DDP (reference).
-    flat_exchange_min_params: int = 1_000_000
+    # through the DDP reducer's 25 MB buckets; its module is then NOT DDP-wrapped (its parameters AND buffers are
+    # broadcast from rank 0 once, as DDP's constructor would; buffers are not re-broadcast every forward — use DDP for
+    # modules with batch-statistics layers).  0 = always use DDP — the reference's behaviour and the default; opt in
+    # with e.g. 1_000_000 for upper problems as large as the inner one (iMAML: M = N).
+    flat_exchange_min_params: int = 0
 
 
 class Engine:
@@ -80,7 +83,8 @@ class Engine:
                 p._flat_exchange = bool(strategy == "distributed" and world > 1 and thr > 0 and n_params >= thr
                                         and p.config.gradient_accumulation == 1)
                 if p._flat_exchange:
-                    p.synchronize_params(list(p.module.parameters()))   # what DDP's constructor would have broadcast
+                    # what DDP's constructor would have broadcast: parameters and buffers
+                    p.synchronize_params(list(p.module.parameters()) + [b for b in p.module.buffers() if b.is_floating_point()])
                 elif strategy == "distributed":
                     from torch.nn.parallel import DistributedDataParallel as DDP
 

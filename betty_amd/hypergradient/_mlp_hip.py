@@ -70,6 +70,21 @@ def _stream() -> int:
     return int(torch.cuda.current_stream().cuda_stream)
 
 
+class FusedSolve:
+    """Token of ONE run of a fused solver: returned by ``cg_solve`` / ``neumann_solve``, handed back to ``mixed_coeff``
+    so the state knows — by object identity, not by comparing addresses of views — that the direction it is asked about
+    is the solution of exactly that run (whose Rz the solver accumulated on its way).  A hand-driven ``hvp()`` or another
+    solve on the same state retires the token."""
+
+    __slots__ = ("kind", "alpha", "K", "layout", "v_last", "materialised")
+
+    def __init__(self, kind, alpha, K, layout, v_last=None, materialised=True):
+        self.kind, self.alpha, self.K, self.layout, self.v_last, self.materialised = kind, alpha, K, layout, v_last, materialised
+
+    def __bool__(self):
+        return True
+
+
 class HipMLPState:
     def __init__(self, spec, x, y):
         if not x.is_cuda:
@@ -168,8 +183,7 @@ class HipMLPState:
         # CG / Neumann pass the SAME view tensors every iteration (views of the persistent flat direction):
         # validate and build the pointer table once per distinct tensor set (the cache holds the tensors, so
         # their ids cannot be recycled while it is alive).
-        self._rzx = None   # a hand-driven HVP invalidates the accumulated Rz(x) of an earlier fused solve
-        self._nrz = None
+        self._solve = None   # a hand-driven HVP overwrites the workspace an earlier fused solve's token refers to
         key = tuple(map(id, direction_views))
         cached = getattr(self, "_dir_cache", None)
         if cached is None or cached[0] != key:
@@ -202,10 +216,10 @@ class HipMLPState:
         starts = (ctypes.c_int64 * len(layout.starts))(*layout.starts)
         return buf.fws, starts
 
-    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True) -> None:
+    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True) -> FusedSolve:
         """cg.py:38-56 for this structure: K x (HVP chain with fused r/x update + direction update).
-        keep_x=False: the library gets x = NULL and never reads or writes the solution vector (its views still
-        identify the solve for mixed_coeff, which works from the accumulated Rz(x))."""
+        keep_x=False: the library gets x = NULL and never reads or writes the solution vector.  Returns the token that
+        lets mixed_coeff() work from the Rz(x) the solver accumulated."""
         fws, starts = self._fused_args(layout)
         _native.check(
             self.lib.bhg_mlp_cg_solve(ctypes.byref(self.desc), x.data_ptr() if keep_x else None, r.data_ptr(), p.data_ptr(), starts,
@@ -213,11 +227,11 @@ class HipMLPState:
                                       layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
             "bhg_mlp_cg_solve",
         )
-        # the solver accumulated Rz(x) on its way: mixed_coeff() of exactly this solution needs no R-forward pass
-        self._rzx = (float(cg_alpha), x.data_ptr(), layout)
-        self._nrz = None
+        # the solver accumulated Rz(x) on its way: mixed_coeff(solve=token) of exactly this solution needs no R-forward pass
+        self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=keep_x)
+        return self._solve
 
-    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> None:
+    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> FusedSolve:
         """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'.
         keep_p=False: the library gets p = NULL; mixed_coeff() of this solve is then formed from the Rz sums the head
         kernel collected plus one R-forward of the last direction."""
@@ -227,34 +241,37 @@ class HipMLPState:
                                            starts, int(K), float(alpha), float(shift), fws.data_ptr(), fws.numel(), _stream()),
             "bhg_mlp_neumann_solve",
         )
-        self._rzx = None
         # v_K sits in v0 after an even number of iterations, in v1 after an odd one
-        self._nrz = None if keep_p else (float(alpha), int(K), p.data_ptr(), layout, v0 if K % 2 == 0 else v1)
+        self._solve = FusedSolve("neumann", float(alpha), int(K), layout, v_last=v0 if K % 2 == 0 else v1, materialised=keep_p)
+        return self._solve
 
-    def mixed_coeff(self, dir_views):
-        """c_i = (p_i - onehot_i) . Rz_i(direction) / B — one R-forward, once per step."""
+    def mixed_coeff(self, dir_views, solve: FusedSolve = None):
+        """c_i = (p_i - onehot_i) . Rz_i(direction) / B.
+        ``solve`` = the token of the fused solve whose solution is meant: the coefficient then comes from the Rz the solver
+        accumulated (no R-forward pass; the only way to ask about a solution that was never materialised).  Without a token
+        ``dir_views`` are read like any direction — one R-forward, whatever memory they live in."""
         buf, B = self.buf, self.B
-        nrz = getattr(self, "_nrz", None)
-        if nrz is not None and len(dir_views) > 0 and dir_views[0].data_ptr() == nrz[2] + 4 * nrz[3].starts[0]:
-            # `dir_views` name the (never written) accumulator of the fused Neumann solve that just ran
-            lay, v_last = nrz[3], nrz[4]
-            views = [v_last[s: s + n] for s, n in zip(lay.starts, lay.numels)]
-            tab, _keep = self._dir_table(views)
-            _native.check(
-                self.lib.bhg_mlp_neumann_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(),
-                                                     nrz[0], nrz[1], buf.fws.data_ptr(), buf.fws.numel(), _stream()),
-                "bhg_mlp_neumann_mixed_coeff",
-            )
-            return buf.coeff[:B].clone()
-        rzx = getattr(self, "_rzx", None)
-        if rzx is not None and len(dir_views) > 0 and dir_views[0].data_ptr() == rzx[1] + 4 * rzx[2].starts[0]:
-            # `dir_views` are the views of the flat solution the fused CG solver just produced
-            _native.check(
-                self.lib.bhg_mlp_cg_mixed_coeff(ctypes.byref(self.desc), buf.labels.data_ptr(), buf.coeff.data_ptr(), rzx[0],
-                                                buf.fws.data_ptr(), buf.fws.numel(), _stream()),
-                "bhg_mlp_cg_mixed_coeff",
-            )
-            return buf.coeff[:B].clone()
+        if solve is not None:
+            if solve is not getattr(self, "_solve", None):
+                raise RuntimeError("stale fused-solve token: another solve or a hand-driven HVP has reused this state's workspace")
+            if solve.kind == "neumann" and not solve.materialised:
+                lay, v_last = solve.layout, solve.v_last
+                views = [v_last[s: s + n] for s, n in zip(lay.starts, lay.numels)]
+                tab, _keep = self._dir_table(views)
+                _native.check(
+                    self.lib.bhg_mlp_neumann_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(),
+                                                         solve.alpha, solve.K, buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                    "bhg_mlp_neumann_mixed_coeff",
+                )
+                return buf.coeff[:B].clone()
+            if solve.kind == "cg":
+                _native.check(
+                    self.lib.bhg_mlp_cg_mixed_coeff(ctypes.byref(self.desc), buf.labels.data_ptr(), buf.coeff.data_ptr(), solve.alpha,
+                                                    buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                    "bhg_mlp_cg_mixed_coeff",
+                )
+                return buf.coeff[:B].clone()
+            # a materialised Neumann accumulator: read it like any direction (below)
         if buf.native_prepare:
             tab, _keep = self._dir_table(dir_views)
             _native.check(

@@ -46,7 +46,8 @@ def cg(vector, curr, prev, sync):
 
     # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
-    if fused is not None and alpha != 0.0 and fused(layout, x, r, p, K, alpha):
+    solve = fused(layout, x, r, p, K, alpha) if (fused is not None and alpha != 0.0) else False
+    if solve:
         pass  # the provider's own kernels ran all K iterations (HVP outputs consumed on chip, no N-sized H p)
     else:
         for k in range(K):
@@ -61,5 +62,7 @@ def cg(vector, curr, prev, sync):
 
     neg_x = layout.views(x, vector)
     if provider is not None:
+        if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
+            return provider.mixed_vjp(neg_x, sync, solve=solve)
         return provider.mixed_vjp(neg_x, sync)
     return mixed_vjp(in_grad, prev, neg_x, sync)

@@ -39,7 +39,8 @@ def neumann(vector, curr, prev, sync):
     v_views = layout.views(v, vector)
 
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
-    if fused is not None and alpha != 0.0 and fused(layout, v, p, K, alpha):
+    solve = fused(layout, v, p, K, alpha) if (fused is not None and alpha != 0.0) else False
+    if solve:
         pass  # the provider's own kernels ran all K iterations (v ping-pongs with a third flat vector of the layout)
     else:
         for k in range(K):
@@ -51,5 +52,7 @@ def neumann(vector, curr, prev, sync):
 
     neg_p = layout.views(p, vector)
     if provider is not None:
+        if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
+            return provider.mixed_vjp(neg_p, sync, solve=solve)
         return provider.mixed_vjp(neg_p, sync)
     return mixed_vjp(in_grad, prev, neg_p, sync)

@@ -16,6 +16,11 @@ Protocol (what cg/neumann call)::
     hvp_fn = provider.prepare()        # once per hypergradient step
     hvp    = hvp_fn(direction_views)   # K times; list aligned with curr.parameters()
     out    = provider.mixed_vjp(neg_x_views, sync)   # final hop to prev's parameters
+
+Optional "one pass" extension: ``token = provider.fused_cg(layout, x, r, p, K, alpha)`` (``fused_neumann`` alike) runs the
+whole K loop natively and returns a truthy value — ``True``, or a token object that cg/neumann hand back as
+``provider.mixed_vjp(views, sync, solve=token)`` so the provider knows the views are the solution of exactly that run
+(a provider that never materialises the solution must be told; it cannot read the views).
 """
 from __future__ import annotations
 
@@ -117,11 +122,11 @@ class WeightedCEMLP:
         """True when fused_cg will run AND leaves x untouched (the caller may then skip zeroing it)."""
         return (not self.keep_solution) and self.fused_cg_ready(layout, K)
 
-    def fused_cg(self, layout, x, r, p, K: int, cg_alpha: float) -> bool:
+    def fused_cg(self, layout, x, r, p, K: int, cg_alpha: float):
+        """False, or the token of the solve (hand it to mixed_vjp(..., solve=token))."""
         if not self.fused_cg_ready(layout, K):
             return False
-        self._state.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift, keep_x=self.keep_solution)
-        return True
+        return self._state.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift, keep_x=self.keep_solution)
 
     def fused_neumann_ready(self, layout, K: int) -> bool:
         st = self._state
@@ -132,17 +137,19 @@ class WeightedCEMLP:
         derivative then comes from sum_k Rz(v_k), collected by the head kernel, plus one R-forward of the last v."""
         return (not self.keep_solution) and self.fused_neumann_ready(layout, K)
 
-    def fused_neumann(self, layout, v, p, K: int, alpha: float) -> bool:
+    def fused_neumann(self, layout, v, p, K: int, alpha: float):
+        """False, or the token of the solve (hand it to mixed_vjp(..., solve=token))."""
         if not self.fused_neumann_ready(layout, K):
             return False
         # second direction buffer: the R-backward GEMMs of an HVP still read v while its epilogues write v'
         v_alt = next(t for t in layout.state(3) if t is not v and t is not p)
-        self._state.neumann_solve(layout, v, v_alt, p, K, alpha, self.hvp_shift, keep_p=self.keep_solution)
-        return True
+        return self._state.neumann_solve(layout, v, v_alt, p, K, alpha, self.hvp_shift, keep_p=self.keep_solution)
 
-    def mixed_vjp(self, neg_x_views, sync: bool):
+    def mixed_vjp(self, neg_x_views, sync: bool, solve=None):
+        """``solve``: token of the fused solve whose solution ``neg_x_views`` name (required when that solution was never
+        materialised); without it the views are read like any direction."""
         st = self._state
-        coeff = st.mixed_coeff(neg_x_views)  # [B]: d(g.(-x))/d s_i
+        coeff = st.mixed_coeff(neg_x_views, solve) if solve is not None else st.mixed_coeff(neg_x_views)  # [B]: d(g.(-x))/d s_i
         upper = self.prev.trainable_parameters()
         if sync:
             torch.autograd.backward(st.sample_weight, grad_tensors=coeff.reshape(st.sample_weight.shape), inputs=upper)

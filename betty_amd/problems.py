@@ -188,10 +188,12 @@ class Problem:
             retain_graph=self._config.retain_graph,
             allow_unused=self._config.allow_unused,
         )
+        # flat exchange (gas == 1 by construction): the averaged pieces must sit in .grad BEFORE the user's grad_callback,
+        # as they do in the reference (problem.py:356-360)
+        self.finish_exchanges()
         if hasattr(self, "grad_callback"):
             self.grad_callback()
         if self.gradient_accumulation_boundary():
-            self.finish_exchanges()
             self.optimizer_step()
             if hasattr(self, "param_callback"):
                 self.param_callback()
@@ -214,11 +216,19 @@ class Problem:
 
             grads = torch.autograd.grad(loss, params, create_graph=create_graph, retain_graph=retain_graph or len(paths) > 0,
                                         allow_unused=allow_unused)
-            self._queue_exchange(params, grads, exchange_async)
-            if self._config.first_order:
-                last = len(paths) - 1
-                for idx, path in enumerate(paths):
-                    self._queue_exchange(params, get_grads(loss, path, retain_graph=(idx != last), do_sync=False), exchange_async)
+            try:
+                self._queue_exchange(params, grads, exchange_async)
+                if self._config.first_order:
+                    last = len(paths) - 1
+                    for idx, path in enumerate(paths):
+                        self._queue_exchange(params, get_grads(loss, path, retain_graph=(idx != last), do_sync=False), exchange_async)
+            except BaseException:
+                # a later path raised: retire the exchanges already in flight (every rank runs the same program, so the
+                # collectives themselves still match up) so the collectives-in-flight count returns to zero
+                for _, handle in self._pending_exchange:
+                    handle.wait()
+                self._pending_exchange = []
+                raise
             return
         # direct gradient: through autograd.grad + set_grads while a hypergradient (or another
         # accumulation step) is still to come, through backward() (DDP-syncing) otherwise
@@ -238,9 +248,13 @@ class Problem:
                     self.set_grads(params, grads)
 
     def _queue_exchange(self, params, grads, exchange_async):
-        keep = [(p, g) for p, g in zip(params, grads) if g is not None]
-        if keep:
-            self._pending_exchange.append(([p for p, _ in keep], exchange_async([g for _, g in keep])))
+        # EVERY rank exchanges the FULL parameter layout: a parameter that is unused on this rank (data-dependent
+        # branch, sampled op) contributes zeros, exactly what DDP(find_unused_parameters=True) does in the reference —
+        # otherwise the ranks would issue all-reduces of different sizes
+        params = list(params)
+        if params:
+            full = [g if g is not None else torch.zeros_like(p) for p, g in zip(params, grads)]
+            self._pending_exchange.append((params, exchange_async(full)))
 
     def finish_exchanges(self):
         """Wait (on the stream, not the host) for the flat exchanges of this step and accumulate the averages."""

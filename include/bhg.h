@@ -122,6 +122,10 @@ int bhg_cg_resident_capacity_chunks(void);
  * device (needed by its grid barrier), else 0; BHG_CG_AUTO falls back to BHG_CG_STREAM when 0.
  * Synchronises the device the first time it is called. */
 int bhg_cg_resident_ok(void);
+/* The predicate BHG_CG_AUTO uses for an n_chunks-chunk vector: capacity AND the census AND — beyond the register-only
+ * size (11 chunks per CU) — a one-time probe that the device grants the LDS-assisted / hybrid instances their 144 KiB of
+ * dynamic LDS per workgroup.  0 => AUTO takes the streaming kernels. */
+int bhg_cg_resident_usable(int n_chunks);
 /* Device address (inside ws) of 8 doubles: {rr_old, pHp, alpha, rr_new, beta, 0,0,0}
  * written by the most recent bhg_cg_step on that workspace. */
 const double* bhg_cg_scalars_dev(const void* ws);

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Build-time gate: no register spills in libbhg's kernels.
+
+Reads the gfx950 code objects out of betty_amd/csrc/build/*.o (the .hip_fatbin section -> clang-offload-bundler ->
+llvm-readelf --notes) and fails when any kernel reports `.vgpr_spill_count`, `.sgpr_spill_count` > ALLOW_SGPR or a
+non-zero `.private_segment_fixed_size` (scratch).  Called by __graft_entry__.build(); prints the five fattest kernels.
+
+    python scripts/check_spills.py [--list]
+"""
+import glob
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+ALLOW_SGPR = 16   # SGPR -> VGPR-lane spills cost no memory traffic; tolerated up to a handful
+
+
+def kernels_of(obj, tmp):
+    fat = os.path.join(tmp, os.path.basename(obj) + ".fatbin")
+    co = os.path.join(tmp, os.path.basename(obj) + ".co")
+    r = subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True)
+    if r.returncode != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+        return []   # host-only object
+    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}",
+                           f"--input={fat}", f"--output={co}"])
+    notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co], text=True)
+    out, name, cur = [], None, {}
+    for line in notes.splitlines():
+        s = line.strip().lstrip("- ").strip()
+        if s.startswith(".name:"):
+            name = s.split(":", 1)[1].strip()
+            cur = {}
+        for key in (".private_segment_fixed_size", ".sgpr_spill_count", ".vgpr_count", ".agpr_count", ".vgpr_spill_count"):
+            if s.startswith(key + ":"):
+                cur[key] = int(s.split(":", 1)[1])
+                if key == ".vgpr_spill_count":
+                    out.append((name, dict(cur)))
+    return out
+
+
+def demangle(n):
+    try:
+        return subprocess.check_output([f"{LLVM}/llvm-cxxfilt", n], text=True).strip()
+    except Exception:
+        return n
+
+
+def main():
+    objs = sorted(glob.glob(os.path.join(ROOT, "betty_amd", "csrc", "build", "*.o")))
+    if not objs:
+        sys.exit("check_spills: no objects under betty_amd/csrc/build — run make first")
+    bad, allk = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            for name, d in kernels_of(o, tmp):
+                allk.append((name, d))
+                if d.get(".vgpr_spill_count", 0) or d.get(".private_segment_fixed_size", 0) or d.get(".sgpr_spill_count", 0) > ALLOW_SGPR:
+                    bad.append((name, d))
+    allk.sort(key=lambda t: -t[1].get(".vgpr_count", 0))
+    if "--list" in sys.argv:
+        for name, d in allk:
+            print(d, demangle(name).split("(")[0])
+    print(f"check_spills: {len(allk)} kernels in {len(objs)} objects; fattest: " +
+          ", ".join(f"{demangle(n).split('(')[0].split('::')[-1]}={d['.vgpr_count']}" for n, d in allk[:5]))
+    if bad:
+        for name, d in bad:
+            print("  SPILL:", demangle(name).split("(")[0], d, file=sys.stderr)
+        sys.exit(f"check_spills: {len(bad)} kernel(s) spill registers / use scratch")
+    print("check_spills: no VGPR spills, no scratch")
+
+
+if __name__ == "__main__":
+    main()

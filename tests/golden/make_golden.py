@@ -10,7 +10,9 @@ vector) and, per case, the reference's results
     out/<case>/sync32/<i>     sync=True, fp32: prev.grad after the call (the call returns None)
     out/<case>/w32/<i>        darts only: inner weights after the call (perturb/restore drift)
 
-Usage:  PYTHONPATH=/root/reference python tests/golden/make_golden.py
+Usage:  PYTHONPATH=/root/reference python tests/golden/make_golden.py [--with-cfg2]
+        --with-cfg2 also regenerates cfg2_full.npz (the metric workload at FULL size, N = 10,034,826, cg K = 20 and
+        neumann K = 10 on five seeds of two conditioning variants; ~10 min) through make_cfg2_golden.py.
 """
 import os
 import sys
@@ -77,3 +79,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if "--with-cfg2" in sys.argv:
+        import make_cfg2_golden
+
+        make_cfg2_golden.main()

@@ -1,0 +1,142 @@
+"""Parity of the metric workload at FULL size (N = 10,034,826) against outputs of the REAL reference's CPU run
+(tests/golden/cfg2_full.npz, made by tests/golden/make_cfg2_golden.py from /root/reference: cg.py:8-70 K = 20,
+neumann.py:8-66 K = 10, fp32 and fp64).
+
+  well    (ridge 0.3, five seeds clear of ReLU kinks): the reference's own fp32-vs-fp64 spread is <= 2e-6 there, so
+          north_star's rtol 1e-4 has resolving power — EVERY kernel arm (one-pass solver, HVP + recurrence kernel,
+          resident / stream, BHG_MLP_WSK 0 / 1 / 2 / 3, opaque autograd HVP) is held to it on every seed.
+  metric  (ridge 1e-2, seeds 0-4, the configuration bench.py times): CG-20 is not a contraction in fp32 on it — the
+          reference sits 1.7e-3 ... 8e-2 from its own fp64 answer — so the product is held to the reference's own spread
+          there, and the three distances are printed side by side.
+
+CPU (not gpu): the file is self-consistent (bench.build reproduces the stored input checksums) and the oracle
+reproduces one full-size golden bit for bit.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import bench  # noqa: E402
+import make_cfg2_golden as mk  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "cfg2_full.npz"))
+WELL_SEEDS = [int(s) for s in GOLD["well/seeds"]]
+METRIC_SEEDS = [int(s) for s in GOLD["metric/seeds"]]
+RTOL = 1e-4   # north_star: "hypergradients matching CPU reference to rtol 1e-4"
+
+
+def rel(got, want):
+    g = np.concatenate([np.asarray(t, dtype=np.float64).ravel() for t in got])
+    w = np.asarray(want, dtype=np.float64).ravel()
+    if not np.all(np.isfinite(g)):
+        return float("inf")
+    return float(np.linalg.norm(g - w) / np.linalg.norm(w))
+
+
+def test_golden_file_is_what_its_generator_says():
+    assert float(GOLD["well/ridge"]) == mk.RIDGE_WELL and float(GOLD["metric/ridge"]) == bench.RIDGE
+    assert METRIC_SEEDS == [0, 1, 2, 3, 4] and len(WELL_SEEDS) == 5
+    for s in WELL_SEEDS:
+        assert float(GOLD[f"well/{s}/kink_margin"]) >= mk.KINK_MARGIN
+        for a in mk.ALGOS:
+            assert float(GOLD[f"well/{s}/{a}/ref_spread"]) <= 1e-5   # the reference against itself (fp32 vs fp64)
+            assert GOLD[f"well/{s}/{a}/fp32"].shape == (301,)
+
+
+@pytest.mark.parametrize("seed", [WELL_SEEDS[0], METRIC_SEEDS[-1]])
+def test_bench_build_reproduces_the_golden_inputs(seed):
+    variant = "well" if seed == WELL_SEEDS[0] else "metric"
+    assert np.array_equal(mk.checksums(seed), GOLD[f"{variant}/{seed}/checksum"])
+
+
+def test_oracle_reproduces_a_full_size_golden_bit_for_bit():
+    """The restatement on the very problem the metric is quoted on (Neumann K = 10; ~6 s on one thread)."""
+    import hypergrad_oracle as orc
+
+    seed = WELL_SEEDS[0]
+    curr, prev, vector = bench.build(torch.device("cpu"), seed, K=10, algo="neumann", ridge=mk.RIDGE_WELL)
+    out = orc.neumann(vector, curr, prev, False)
+    got = torch.cat([o.detach().reshape(-1) for o in out]).numpy()
+    assert np.array_equal(got, GOLD[f"well/{seed}/neumann10/fp32"])
+
+
+# ---- GPU: every arm against the reference's CPU outputs ----------------------------------------------------------------
+def _arms(algo):
+    arms = [(f"fused-wsk{w}", dict(hvp="hip", fused=True, wsk=str(w))) for w in (0, 1, 2, 3)]
+    arms += [(f"unfused-wsk{w}", dict(hvp="hip", fused=False, wsk=str(w))) for w in (0, 1, 2, 3)]
+    arms += [("fused-default", dict(hvp="hip", fused=True, wsk=None)), ("fused+solution", dict(hvp="hip", fused=True, wsk=None, keep=True))]
+    if algo == "cg":
+        arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
+                 ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
+    else:
+        arms += [("autograd", dict(hvp="autograd"))]
+    return arms
+
+
+def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
+    from betty_amd import _native
+    from betty_amd import hypergradient as hg
+    from betty_amd.backend import get_backend
+
+    be = get_backend()
+    assert be.name == "hip"
+    if arm.get("wsk") is None:
+        monkeypatch.delenv("BHG_MLP_WSK", raising=False)
+    else:
+        monkeypatch.setenv("BHG_MLP_WSK", arm["wsk"])
+    saved = be.cg_variant
+    be.cg_variant = {"stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}.get(arm.get("variant"), _native.BHG_CG_AUTO)
+    try:
+        curr, prev, vector = bench.build(torch.device("cuda:0"), seed, K=K, algo=algo, ridge=ridge)
+        if arm["hvp"] == "hip":
+            bench.declare_structure(curr, "hip", fused=arm["fused"], keep_solution=arm.get("keep", False))
+        out = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
+        return [t.detach().cpu().numpy() for t in out]
+    finally:
+        be.cg_variant = saved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aname", list(mk.ALGOS))
+@pytest.mark.parametrize("seed", WELL_SEEDS)
+def test_every_arm_matches_the_reference_cpu_golden_on_the_well_conditioned_variant(seed, aname, monkeypatch):
+    algo, K = mk.ALGOS[aname]
+    want32, want64 = GOLD[f"well/{seed}/{aname}/fp32"], GOLD[f"well/{seed}/{aname}/fp64"]
+    spread = float(GOLD[f"well/{seed}/{aname}/ref_spread"])
+    worst = 0.0
+    for name, arm in _arms(algo):
+        got = _run_arm(algo, K, seed, mk.RIDGE_WELL, arm, monkeypatch)
+        e32, e64 = rel(got, want32), rel(got, want64)
+        worst = max(worst, e32)
+        print(f"cfg2 well seed={seed} {aname} {name:18s}: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e} "
+              f"(reference fp32 vs fp64 {spread:.2e})")
+        assert e32 <= RTOL, (seed, aname, name, e32)
+    assert worst <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", METRIC_SEEDS)
+def test_metric_configuration_against_the_reference_cpu_goldens(seed, monkeypatch):
+    """ridge 1e-2: CG-20's fp32 noise decides the 3rd-4th digit, whoever runs it (the reference's CPU run sits `ref_spread`
+    from its own fp64 run).  Held: the product is no further from the fp64 truth than 3x the reference's own distance
+    (floor rtol 1e-4); Neumann (no division, no chaos) to rtol 1e-4 — except where a ReLU kink separates the reference's
+    fp32 and fp64 runs themselves (seed 4), there to either side of the kink."""
+    for aname, (algo, K) in mk.ALGOS.items():
+        want32, want64 = GOLD[f"metric/{seed}/{aname}/fp32"], GOLD[f"metric/{seed}/{aname}/fp64"]
+        spread = float(GOLD[f"metric/{seed}/{aname}/ref_spread"])
+        got = _run_arm(algo, K, seed, bench.RIDGE, dict(hvp="hip", fused=True, wsk=None), monkeypatch)
+        e32, e64 = rel(got, want32), rel(got, want64)
+        print(f"cfg2 metric seed={seed} {aname}: product vs reference-CPU fp32 {e32:.2e}, product vs fp64 truth {e64:.2e}, "
+              f"reference fp32 vs fp64 {spread:.2e}")
+        if algo == "cg":
+            assert e64 <= max(RTOL, 3.0 * spread), (seed, e64, spread)
+        else:
+            assert min(e32, e64) <= RTOL, (seed, e32, e64, spread)

@@ -1,11 +1,11 @@
 """Drop-in under the REAL reference: `betty_amd.install()` replaces the registry entries of a live
 `betty.hypergradient` and the reference's own Engine/Problem (unmodified, imported from the checkout named by
-$BETTY_REF, default /root/reference) drives our cg/neumann/darts through `Problem.backward -> get_grads`.
-Only runs where a reference checkout exists:
+$BETTY_REF; default: oracle/_ref — the git-ignored staging copy `make -C oracle ref` / `__graft_entry__.build()` takes
+in the build container and gpurun ships to the GPU box — else /root/reference) drives our cg/neumann/darts through
+`Problem.backward -> get_grads`.
   * in the build container (no GPU) the kernels are the C oracle via the test-only checker backend;
-  * `-m gpu` with BETTY_REF pointing at a checkout on a GPU box: the SAME scenario with the reference's Engine over the
-    HIP kernels (`HipBackend`) — the two halves of the drop-in claim in one run.  (The GPU box the driver uses has no
-    reference checkout, so there the scenario runs through betty_amd's own caller slice, tests/test_engine_shim.py.)"""
+  * `-m gpu`: the SAME scenario with the reference's Engine over the HIP kernels (`HipBackend`) — the two halves of the
+    drop-in claim in one run."""
 import contextlib
 import os
 import sys
@@ -15,7 +15,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-REF = os.environ.get("BETTY_REF", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+REF = os.environ.get("BETTY_REF") or (_STAGED if os.path.isdir(os.path.join(_STAGED, "betty")) else "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "betty")), reason="reference checkout not present")
 
 

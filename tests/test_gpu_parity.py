@@ -611,6 +611,79 @@ def test_fused_neumann_without_an_accumulator_vector(dims, B, K, be):
     assert rel <= 2e-6, rel
 
 
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+def test_mixed_coeff_identifies_the_solve_by_token_not_by_address(algo, be):
+    """Round-2 finding: the state recognised "the solution the fused solver just produced" by pointer arithmetic on
+    data_ptr().  Now the solver returns a token.  With the solution materialised (keep_solution=True):
+      * mixed_vjp(views, solve=token)  -> coefficient from the accumulated Rz (no R-forward),
+      * mixed_vjp(CLONED views)        -> no token, the clones are read like any direction (one R-forward) — same
+        hypergradient to fp32 noise, wherever the caller's copies live,
+      * a token from an earlier solve, or after a hand-driven HVP, is refused."""
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    dims, B, K = [256, 384, 128, 10], 100, 5
+    curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=77)
+    prov = WeightedCEMLP(curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=0.05,
+                         impl="hip", fused=True, keep_solution=True)
+    hvp_fn = prov.prepare()
+    vec = [0.1 * d for d in direction]
+    lay = be.layout(vec)
+    if algo == "cg":
+        x, r, p = lay.state(3)
+        be.cg_init(lay, vec, x, r, p)
+        token = prov.fused_cg(lay, x, r, p, K, 1.0)
+        sol = x
+    else:
+        v, p = lay.state(2)
+        be.neumann_init(lay, vec, v, p)
+        token = prov.fused_neumann(lay, v, p, K, 0.05)
+        sol = p
+    assert token and token is not True
+    views = lay.views(sol, vec)
+    by_token = _np(prov.mixed_vjp(views, False, solve=token))
+    clones = [t.clone() for t in views]          # different addresses, same numbers
+    by_clone = _np(prov.mixed_vjp(clones, False))
+    rel, _ = rel_err(by_clone, by_token)
+    assert rel <= 2e-6, rel
+    # the un-fused loop on the same inputs
+    curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
+    curr.hypergradient_structure = lambda prev_: WeightedCEMLP(curr, prev_, layers=list(curr.module.layers),
+                                                                weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=0.05,
+                                                                impl="hip", fused=False)
+    want = _np(hg.jvp_fn_mapping[algo](vec, curr, prev, False))
+    rel, _ = rel_err(by_clone, want)
+    assert rel <= 5e-5, rel
+    # stale tokens are refused: a hand-driven HVP reuses the workspace the token refers to
+    hvp_fn(lay.views(lay.state(3)[2], vec))
+    with pytest.raises(RuntimeError, match="stale"):
+        prov.mixed_vjp(views, False, solve=token)
+
+
+def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
+    """A classifier head wider than 32 outputs: the once-per-step passes (forward, deltas, mixed coefficient) run on ATen, the
+    K HVPs on the MFMA kernels (no fused solver: bhg_mlp_supports_fused_solve is false) — against the opaque autograd
+    path on the same inputs, CG and Neumann."""
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    dims, B = [192, 256, 128, 48], 72
+    for algo, K in (("cg", 4), ("neumann", 4)):
+        outs = {}
+        for arm in ("hip", "autograd"):
+            curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=5)
+            curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
+            if arm == "hip":
+                prov = WeightedCEMLP(curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce, prev=prev: prev.fwd(ce.reshape(-1, 1)),
+                                     ridge=0.05, impl="hip", fused=True)
+                curr.hypergradient_structure = lambda prev_, prov=prov: prov
+            outs[arm] = _np(hg.jvp_fn_mapping[algo]([0.1 * d for d in direction], curr, prev, False))
+            if arm == "hip":
+                st = prov._state
+                assert not st.buf.native_prepare and not st.fused_supported(be.layout(direction))
+        rel, _ = rel_err(outs["hip"], outs["autograd"])
+        print(f"wide head {dims} {algo}: analytic (ATen prepare + MFMA HVPs) vs autograd {rel:.2e}")
+        assert rel <= 1e-4, (algo, rel)
+
+
 def test_fused_cg_scalars_match_unfused(be):
     """alpha from the batch-sized factors == alpha from the N-sized dot (to fp32 reduction noise), iteration by
     iteration: one fused iteration against one un-fused iteration started from the same state."""

@@ -300,6 +300,38 @@ class _FakeFusedProvider:
         return [torch.zeros_like(q) for q in self.prev.trainable_parameters()]
 
 
+class _TokenProvider(_FakeFusedProvider):
+    """A provider whose fused solvers return a token object: cg() / neumann() must hand exactly that object back."""
+
+    class Token:
+        pass
+
+    def fused_cg(self, layout, x, r, p, K, alpha):
+        self.token = self.Token()
+        return self.token
+
+    fused_neumann = lambda self, layout, v, p, K, alpha: self.fused_cg(layout, None, None, p, K, alpha)  # noqa: E731
+
+    def mixed_vjp(self, views, sync, solve=None):
+        self.seen.append(("mixed_vjp", solve))
+        return [torch.zeros_like(q) for q in self.prev.trainable_parameters()]
+
+
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+def test_fused_solve_token_travels_back_to_mixed_vjp(algo):
+    """The solution of a fused solve is identified by the token the solver returned (object identity), never by the
+    addresses of the views (round-2 finding: `data_ptr()` arithmetic)."""
+    inner, upper = zoo.MLP([6, 5, 3]), zoo.MWN(4)
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    curr = zoo.StubProblem("inner", inner, config=Config(type=algo, cg_iterations=2, neumann_iterations=2, neumann_alpha=0.1))
+    provider = _TokenProvider(prev, free=True)
+    curr.hypergradient_structure = lambda prev_: provider
+    vector = [torch.randn_like(p) for p in inner.parameters()]
+    with use_backend(_RecordingBackend()):
+        hg.jvp_fn_mapping[algo](vector, curr, prev, False)
+    assert provider.seen[-1] == ("mixed_vjp", provider.token)
+
+
 @pytest.mark.parametrize("algo", ["cg", "neumann"])
 @pytest.mark.parametrize("free", [True, False])
 def test_solution_free_protocol_of_structured_providers(algo, free):
