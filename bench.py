@@ -146,20 +146,24 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
+
+
 def pmc_traffic(key, N):
-    """Fabric-side bytes per iteration from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, corrected per MI355X_MICROARCH.md §HBM; written
-    by scripts/gpu_pmc.sh).  PMC collection needs rocprofv3 around the process, so bench.py can only replay a
-    committed measurement — and does so ONLY when that file is stamped with the sha256 of the very libbhg.so
-    that is loaded now (same kernels); otherwise the field is null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get("lib_sha256") != lib_sha256() or d.get("workload_N") != N:
-        return None
-    return d.get("traffic_bytes", {}).get(key)
+    """(bytes, source) — fabric-side bytes per iteration from the committed PMC passes (profiles/rNN_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this very command, corrected per MI355X_MICROARCH.md
+    §HBM; written by scripts/gpu_pmc2.sh).  PMC collection needs rocprofv3 around the process, so bench.py can only
+    REPLAY a committed measurement — and does so ONLY when that file is stamped with the sha256 of the very libbhg.so
+    that is loaded now (same kernels); otherwise (None, reason).  The source string says so in the JSON line."""
+    sha = lib_sha256()
+    for name in PMC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if d.get("lib_sha256") == sha and d.get("workload_N") == N and d.get("traffic_bytes", {}).get(key) is not None:
+            return d["traffic_bytes"][key], f"replayed from profiles/{name} (not measured in this run; libbhg.so sha256-matched {sha[:16]})"
+    return None, "no committed PMC pass carries the sha256 of the loaded libbhg.so"
 
 
 def host_info():
@@ -250,6 +254,7 @@ def main():
                          "from the accumulated Rz(x), x is never written)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
 
@@ -335,6 +340,18 @@ def main():
         step()
     # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream.
     elapsed = timed_region(args.steps)
+    # Region 1b — the same `steps` steps with HALF the iterations, equally free of events: the difference of the two
+    # regions is K/2 full iterations per step on the SAME clock as the headline (no per-launch events, no profiler), so
+    # the roofline span and the headline agree by construction:  iteration = (t(K) - t(K/2)) / (K/2);
+    # outside the K loop = t(K) - K * iteration (it absorbs what the short last iteration saves).
+    elapsed_half = None
+    if args.algo in ("cg", "neumann") and K >= 2 and not args.no_slope:
+        key = "cg_iterations" if args.algo == "cg" else "neumann_iterations"
+        setattr(curr.config, key, K // 2)
+        step()
+        elapsed_half = timed_region(args.steps)
+        setattr(curr.config, key, K)
+        step()
     # Region 2 — the same `steps` steps again with HIP events around the launch groups (recorded inside libbhg on the
     # launch stream) for the roofline objects.  Kept out of region 1 because every event record costs the stream a
     # ~4 us bubble (measured: 210 vs 192 steps/s with 4 records per CG iteration); its throughput is reported as
@@ -360,6 +377,10 @@ def main():
             t = torch.tensor([elapsed_timed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed_timed = float(t.item())
+        if elapsed_half is not None:
+            t = torch.tensor([elapsed_half], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_half = float(t.item())
     be.check_health()
 
     finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
@@ -378,20 +399,32 @@ def main():
         mall_note = ("working set (x, r, p, W, activations = %.0f MB) is smaller than the 256 MiB Infinity Cache: this is "
                      "fabric-side bandwidth on cache-resident data, quoted against the 8 TB/s HBM peak as north_star asks; "
                      "cache-defeated figures: profiles/r02_bench_kernels_N10M_cache_defeated.json" % ((3 * 4 * N + 4 * N + 8e6) / 1e6))
-        if fused and args.algo == "cg" and "cg_iter" in spans:
-            us, n = spans["cg_iter"]
-            alg = rec_bytes + 20.0 * N
-            roof = {"bound": "hbm", "kernel": "bhg_mlp_cg_solve: one fused CG-HVP iteration (k_cg_beta + HVP chain whose output kernels carry the "
-                    "r/x/p update)", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": pmc_traffic("cg_iter_fused", N),
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n, "note": mall_note}
-        elif fused and args.algo == "neumann" and "hvp" in spans:
-            us, n = spans["hvp"]
-            alg = rec_bytes + 20.0 * N
-            roof = {"bound": "hbm", "kernel": "bhg_mlp_neumann_solve: one fused Neumann-HVP iteration", "achieved": alg / (us * 1e-6) / 1e9,
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                    "traffic": pmc_traffic("neumann_iter_fused", N), "algorithmic_bytes_per_launch": alg, "avg_launch_us": us,
-                    "launches_timed": n, "note": mall_note}
+        # event-free iteration time (region 1 vs region 1b): the span every fused roofline figure below is quoted on
+        iter_us = 1e6 * (elapsed - elapsed_half) / (args.steps * (K - K // 2)) if elapsed_half is not None else None
+        if fused and args.algo in ("cg", "neumann") and (iter_us is not None or ("cg_iter" if args.algo == "cg" else "hvp") in spans):
+            ev_us, ev_n = spans.get("cg_iter" if args.algo == "cg" else "hvp", (None, 0))
+            us = iter_us if iter_us is not None else ev_us
+            traffic, traffic_src = pmc_traffic("cg_iter_fused" if args.algo == "cg" else "neumann_iter_fused", N)
+            alg = rec_bytes                     # 28*N per CG iteration, 20*N per Neumann iteration
+            comp = rec_bytes + 20.0 * N         # + Appendix A.3's HVP weight traffic (read W, V twice, write H*dir once)
+            roof = {"bound": "hbm",
+                    "kernel": ("bhg_mlp_cg_solve: one whole fused CG-HVP iteration (k_cg_beta + R-chain + k_cg_alpha + k_outer_all, whose "
+                               "epilogue carries the r/p update)" if args.algo == "cg" else
+                               "bhg_mlp_neumann_solve: one whole fused Neumann-HVP iteration"),
+                    "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "algorithmic_bytes_per_launch": alg,
+                    "avg_launch_us": us,
+                    "avg_launch_us_source": ("event-free: (t(K) - t(K/2)) / (K/2) over two timed regions of %d steps, the headline's own clock"
+                                             % args.steps) if iter_us is not None else "HIP events around the iteration (bhg_timing)",
+                    "avg_launch_us_hip_events": ev_us, "launches_timed": ev_n,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "achieved_on_traffic_GBps": (traffic / (us * 1e-6) / 1e9) if traffic else None,
+                    "composite_recurrence_plus_hvp_weights": {"algorithmic_bytes": comp, "achieved": comp / (us * 1e-6) / 1e9,
+                                                              "frac": comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                              "note": "round-2's figure (28N + 20N); the fused path neither writes nor re-reads H*p, "
+                                                                      "so this counts bytes the kernels do not move — yardstick only"},
+                    "note": mall_note + "; the iteration is bound by the fp32 matrix pipe, not by HBM: see hvp_roofline"}
         elif ("cg_step" if args.algo == "cg" else "neumann_step") in spans:
             us, n = spans["cg_step" if args.algo == "cg" else "neumann_step"]
             roof = {
@@ -400,7 +433,8 @@ def main():
                            "k_cg_resident (1 launch/iter)" if resident else "k_cg_dot+k_cg_resid+k_cg_dir (3 launches/iter)"),
                 "achieved": rec_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": rec_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic("k_cg_resident" if resident else "cg_stream", N) if args.algo == "cg" else None,
+                "traffic": pmc_traffic("k_cg_resident" if resident else "cg_stream", N)[0] if args.algo == "cg" else None,
+                "traffic_source": pmc_traffic("k_cg_resident" if resident else "cg_stream", N)[1] if args.algo == "cg" else None,
                 "algorithmic_bytes_per_launch": rec_bytes, "avg_launch_us": us, "launches_timed": n, "note": mall_note,
             }
         hvp_roof = None
@@ -412,16 +446,22 @@ def main():
             outer = sum(2.0 * BATCH * d[l] * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 1))
             flops = fwd + bwd + outer
             us, n = spans["hvp"]
+            src = "HIP events around the HVP chain (bhg_timing)"
+            if fused and iter_us is not None:   # the whole iteration IS the HVP chain plus two ~5 us scalar launches
+                us, src = iter_us, "event-free whole-iteration time (see roofline.avg_launch_us_source)"
             hvp_roof = {
                 "bound": "mfma",
                 "kernel": "MLP HVP chain (k_gemm<NT>, k_gemm<NN>, k_outer, head kernels, split-K reduces)" +
                           ("; fused: its output kernels also carry the recurrence's r/x (or v/p) update" if fused else ""),
                 "achieved": flops / (us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": flops / (us * 1e-6) / 1e12 / 157.3, "flops_per_call": flops, "avg_call_us": us, "calls_timed": n,
+                "frac": flops / (us * 1e-6) / 1e12 / 157.3, "flops_per_call": flops, "avg_call_us": us, "avg_call_us_source": src,
+                "avg_call_us_hip_events": spans["hvp"][0], "calls_timed": n,
             }
         K_eff = 0 if args.algo == "darts" else K
         per_iter_us = None
-        if fused and args.algo == "cg" and "cg_iter" in spans:
+        if fused and iter_us is not None:
+            per_iter_us = iter_us
+        elif fused and args.algo == "cg" and "cg_iter" in spans:
             per_iter_us = spans["cg_iter"][0]
         elif "hvp" in spans:
             per_iter_us = spans["hvp"][0] + (spans.get("cg_step") or spans.get("neumann_step") or (0.0, 0))[0]
@@ -458,7 +498,8 @@ def main():
             "hvp_roofline": hvp_roof,
             "value_with_kernel_timing": ((world if args.mode == "replica" else 1) * args.steps / elapsed_timed) if elapsed_timed else None,
             "per_iteration_us": per_iter_us,
-            "outside_k_loop_ms": (1e3 * elapsed_timed / args.steps - K_eff * per_iter_us * 1e-3) if per_iter_us and elapsed_timed else None,
+            "outside_k_loop_ms": ((1e3 * elapsed / args.steps - K_eff * iter_us * 1e-3) if (fused and iter_us is not None) else
+                                  (1e3 * elapsed_timed / args.steps - K_eff * per_iter_us * 1e-3) if per_iter_us and elapsed_timed else None),
             "cpu_baseline": None,
         }
         if world == 1 and args.cpu_steps > 0:

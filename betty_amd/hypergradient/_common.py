@@ -1,6 +1,8 @@
 """Shared pieces of cg/neumann: inner-gradient graph, HVP providers, final mixed VJP."""
 from __future__ import annotations
 
+import contextlib
+import os
 import warnings
 from typing import List, Sequence
 
@@ -27,6 +29,105 @@ class AutogradHVP:
 
     def __call__(self, direction_views: Sequence[torch.Tensor]):
         return torch.autograd.grad(self.in_grad, self.params, grad_outputs=direction_views, retain_graph=True)
+
+
+# ---- hipGraph replay of an opaque Hessian-vector product ----------------------------------------------------------------
+# The double backward of a user's training_step is hundreds to thousands of small ATen launches (cfg 2's MLP: ~1 ms per
+# HVP for ~0.35 ms of GPU work; a DARTS supernet: tens of thousands of launches): the K HVPs of one solve run the SAME
+# launch sequence on the SAME addresses — the autograd graph of `in_grad` is fixed for the step and the direction lives in
+# one persistent flat vector — so the sequence is captured once (HIP graph) and replayed K - 2 times.
+#   call 1: eager (settles library handles, workspaces, autotuning on the capture stream)
+#   call 2: captured (hipStreamBeginCapture .. EndCapture around torch.autograd.grad), then replayed
+#   call 3..K: replayed
+# Autograd runs a backward node on the stream its forward ran on, so the graph of `in_grad` must be BUILT on the stream
+# that later captures: `solve_stream` moves the whole solve to a library-owned side stream when the caller sits on the
+# default (legacy) stream, which HIP cannot capture.  Anything that cannot be captured (a host sync inside the double
+# backward, an op that allocates through an uncaptured path) raises inside the capture: the wrapper then stays eager for
+# the rest of the solve.  BHG_HVP_GRAPH=0 turns it off, =1 forces it on; default: on for K >= 4.
+_SOLVE_STREAMS = {}
+_GRAPH_POOLS = {}
+GRAPH_STATS = {"captures": 0, "replays": 0, "fallbacks": 0}
+
+
+def hvp_graph_wanted(K: int, tensors) -> bool:
+    mode = os.environ.get("BHG_HVP_GRAPH", "auto")
+    if mode == "0" or not tensors or not tensors[0].is_cuda:
+        return False
+    return mode == "1" or K >= 4
+
+
+@contextlib.contextmanager
+def solve_stream(device, enabled: bool):
+    """Run the body on a capturable stream (see above); joins the caller's stream on both sides."""
+    if not enabled:
+        yield None
+        return
+    cur = torch.cuda.current_stream(device)
+    if cur != torch.cuda.default_stream(device):
+        yield cur       # the caller already works on a stream of its own
+        return
+    side = _SOLVE_STREAMS.get(device.index)
+    if side is None:
+        side = _SOLVE_STREAMS[device.index] = torch.cuda.Stream(device)
+    side.wait_stream(cur)
+    try:
+        with torch.cuda.stream(side):
+            yield side
+    finally:
+        cur.wait_stream(side)
+
+
+class GraphedHVP:
+    """Wraps an eager HVP callable ``fn(direction_views) -> tuple of tensors`` (pure device work on fixed addresses)."""
+
+    def __init__(self, fn):
+        self.fn, self.calls, self.graph, self.out, self.key, self.dead = fn, 0, None, None, None, False
+
+    @staticmethod
+    def _key(views):
+        return tuple((v.data_ptr(), tuple(v.shape), v.dtype) for v in views)
+
+    def __call__(self, views):
+        self.calls += 1
+        if self.dead:
+            return self.fn(views)
+        key = self._key(views)
+        if self.graph is not None:
+            if key == self.key:
+                self.graph.replay()
+                GRAPH_STATS["replays"] += 1
+                return self.out
+            self.dead = True            # the caller moved the direction: the captured addresses are stale
+            return self.fn(views)
+        dev = views[0].device
+        if self.calls == 1 or torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+            self.key = key
+            return self.fn(views)
+        if key != self.key:
+            self.dead = True
+            return self.fn(views)
+        graph = torch.cuda.CUDAGraph()
+        pool = _GRAPH_POOLS.get(dev.index)
+        if pool is None:
+            pool = _GRAPH_POOLS[dev.index] = torch.cuda.graph_pool_handle()
+        try:
+            graph.capture_begin(pool=pool, capture_error_mode="thread_local")
+            try:
+                out = self.fn(views)
+            finally:
+                graph.capture_end()
+            graph.replay()
+        except Exception as exc:   # not capturable on this stack: eager for the rest of the solve
+            self.dead = True
+            GRAPH_STATS["fallbacks"] += 1
+            warnings.warn(f"betty_amd: hipGraph capture of the Hessian-vector product failed ({type(exc).__name__}: {exc}); "
+                          "continuing with eager launches", RuntimeWarning)
+            torch.cuda.synchronize(dev)
+            return self.fn(views)
+        GRAPH_STATS["captures"] += 1
+        GRAPH_STATS["replays"] += 1
+        self.graph, self.out = graph, tuple(out)
+        return self.out
 
 
 def mixed_vjp(in_grad, prev, neg_x_views: List[torch.Tensor], sync: bool):

@@ -11,7 +11,7 @@ streaming kernels (40*N bytes) instead of ~10*T ATen launches moving ~140*N byte
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, inner_gradient, mixed_vjp
+from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, solve_stream
 from .structured import structured_hvp_for
 
 
@@ -20,19 +20,27 @@ def cg(vector, curr, prev, sync):
     in ``prev``'s parameter space.  ``sync=True``: accumulate into ``prev`` ``.grad`` and return
     None; ``sync=False``: return the list (cg.py:58-68)."""
     assert len(curr.paths) == 0, "cg method is not supported for higher order MLO!"
+    vector = list(vector)
+    provider = structured_hvp_for(curr, prev)
+    K = int(curr.config.cg_iterations)
+    # opaque double backward (no structure, or a structure whose HVP is an autograd callback): replayed as a HIP graph
+    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector)
+    with solve_stream(vector[0].device if vector else None, graphed):
+        return _cg(vector, curr, prev, sync, provider, K, graphed)
+
+
+def _cg(vector, curr, prev, sync, provider, K, graphed):
     config = curr.config
     be = get_backend()
-    vector = list(vector)
-
-    provider = structured_hvp_for(curr, prev)
     if provider is None:
         in_grad = inner_gradient(curr)
         hvp_fn = AutogradHVP(in_grad, curr.parameters())
     else:
         in_grad = None
         hvp_fn = provider.prepare()
+    if graphed:
+        hvp_fn = GraphedHVP(hvp_fn)
 
-    K = int(config.cg_iterations)
     alpha = float(config.cg_alpha)
     fused = getattr(provider, "fused_cg", None)
     layout = be.layout(vector)

@@ -8,17 +8,24 @@ ATen launches; the final ``alpha*p`` and the negation are folded into the last i
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, inner_gradient, mixed_vjp
+from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, solve_stream
 from .structured import structured_hvp_for
 
 
 def neumann(vector, curr, prev, sync):
     assert len(curr.paths) == 0, "neumann method is not supported for higher order MLO!"
+    vector = list(vector)
+    provider = structured_hvp_for(curr, prev)
+    K = int(curr.config.neumann_iterations)
+    # opaque double backward: captured once per solve, replayed as a HIP graph (see _common.GraphedHVP)
+    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector)
+    with solve_stream(vector[0].device if vector else None, graphed):
+        return _neumann(vector, curr, prev, sync, provider, K, graphed)
+
+
+def _neumann(vector, curr, prev, sync, provider, K, graphed):
     config = curr.config
     be = get_backend()
-    vector = list(vector)
-
-    provider = structured_hvp_for(curr, prev)
     if provider is None:
         in_grad = inner_gradient(curr)
         # neumann.py:39 differentiates w.r.t. trainable_parameters() (cg uses parameters())
@@ -26,8 +33,9 @@ def neumann(vector, curr, prev, sync):
     else:
         in_grad = None
         hvp_fn = provider.prepare()
+    if graphed:
+        hvp_fn = GraphedHVP(hvp_fn)
 
-    K = int(config.neumann_iterations)
     alpha = float(config.neumann_alpha)
     fused = getattr(provider, "fused_neumann", None)
     layout = be.layout(vector)

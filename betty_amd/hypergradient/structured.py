@@ -296,6 +296,8 @@ class ProximalRegularized:
     align one-to-one with ``curr.parameters()``.
     """
 
+    hvp_is_autograd = True   # the HVP callback is an opaque double backward: cg/neumann may replay it as a HIP graph
+
     def __init__(self, curr, prev, data_loss: Callable, reg: float, batch=None):
         self.curr, self.prev, self.data_loss, self.reg, self.batch = curr, prev, data_loss, float(reg), batch
         self.hvp_shift = 2.0 * self.reg

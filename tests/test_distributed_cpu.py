@@ -93,6 +93,78 @@ def test_sync_hop_averages_over_ranks(case_name):
         assert differs > 1e-3, "ranks must see different data for the test to mean anything"
 
 
+def _roberta_ddp_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zoo
+        from _cpu_checker_backend import CpuCheckerBackend
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        from betty_amd import Config
+        from betty_amd import hypergradient as hg
+        from betty_amd.backend import use_backend
+
+        def build():
+            torch.manual_seed(3)    # the same weights on every rank (what DDP's constructor would broadcast)
+            inner = zoo.RobertaInner(layers=2, hidden=64, heads=4, ffn=128, vocab=1000, positions=66)
+            upper = zoo.MWN(50)
+            g = torch.Generator().manual_seed(100 + rank)   # a different token batch per rank
+            B, S = 6, 24
+            batch = (torch.randint(3, 999, (B, S), generator=g), torch.ones(B, S, dtype=torch.long),
+                     torch.zeros(B, S, dtype=torch.long), torch.randint(0, 2, (B,), generator=g))
+            gv = torch.Generator().manual_seed(9)
+            vector = [0.05 * torch.randn(p.shape, generator=gv) for p in inner.parameters()]
+            prev = zoo.StubProblem("upper", upper, config=Config())
+            # radius 1.0: the +/- perturbations differ by enough that the fp32 difference of the two gradients keeps 4 digits
+            curr = zoo.StubProblem("inner", inner, config=Config(type="darts", darts_alpha=1.0),
+                                   loss_fn=zoo.make_roberta_reweight_loss(prev), batch=batch)
+            return curr, prev, vector
+
+        with use_backend(CpuCheckerBackend()):
+            curr, prev, vector = build()
+            local = hg.jvp_fn_mapping["darts"](vector, curr, prev, False)
+            local = torch.cat([t.reshape(-1) for t in local]).detach()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            want = torch.stack(gathered).mean(0)
+            curr, prev, vector = build()
+            prev.fwd = DDP(prev.module, gradient_as_bucket_view=True, find_unused_parameters=True)   # problem.py:220-224
+            ret = hg.jvp_fn_mapping["darts"](vector, curr, prev, True)
+            got = torch.cat([p.grad.reshape(-1) for p in prev.trainable_parameters()]).detach()
+        err = float((got - want).abs().max() / want.abs().max())
+        differs = float((local - want).abs().max() / want.abs().max())
+        q.put((rank, ret is None, err, differs, len(vector)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_roberta_darts_sync_hop_under_ddp():
+    """BASELINE cfg 4's shape of problem at CPU size: transformers' RobertaForSequenceClassification (2 layers, width 64 —
+    the class the example uses, reduced in depth and width), reweighting net upper, DARTS finite difference, DDP over 2
+    ranks with different token batches: the synced hop leaves the MEAN of the per-rank hypergradients in prev.grad
+    (darts.py:44-46,52-53 through DistributedDataParallel's reducer) and returns None."""
+    pytest.importorskip("transformers")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_roberta_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, returned_none, err, differs, T in sorted(q.get(timeout=5) for _ in range(world)):
+        assert returned_none and T > 30
+        assert err < 2e-4, (rank, err)       # finite differences + fp32 all-reduce rounding (as reweight_darts above)
+        assert differs > 1e-3, "ranks must see different data for the test to mean anything"
+
+
 def _sync_worker(rank, world, port, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))

@@ -1186,6 +1186,54 @@ def test_cfg4_roberta_scale_darts(radius, be):
     assert drift <= 2.4e-7, drift
 
 
+def test_cfg4_roberta_base_as_named_darts(be):
+    """BASELINE cfg 4 AS NAMED: ``RobertaForSequenceClassification`` (roberta-base from config: 124,647,170 parameters in
+    201 tensors — examples/bert_data_reweighting/model.py:11-32), reweighting net 1-500-1 (main.py:96-100), 16 x 50 tokens
+    (+ mask, segments, labels), finite-difference DARTS hypergradient.  Same three-way comparison as the stand-in above."""
+    import copy
+
+    pytest.importorskip("transformers")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    g = torch.Generator().manual_seed(17)
+    torch.manual_seed(17)
+    inner, upper = zoo.RobertaInner().to(DEV), zoo.MWN(500).to(DEV)
+    n_par = sum(p.numel() for p in inner.parameters())
+    assert n_par == 124_647_170 and len(list(inner.parameters())) == 201
+    assert sum(p.numel() for p in upper.parameters()) == 1_501
+    B, S = 16, 50
+    batch = (torch.randint(3, 50264, (B, S), generator=g).to(DEV), torch.ones(B, S, dtype=torch.long, device=DEV),
+             torch.zeros(B, S, dtype=torch.long, device=DEV), torch.randint(0, 2, (B,), generator=g).to(DEV))
+    vector = [1e-3 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+    radius = 1.0   # well above fp32 resolution of a 124 M-element perturbation (see the stand-in test for the default 0.01)
+
+    def problems(inner_m, upper_m):
+        prev = zoo.StubProblem("upper", upper_m, config=Config())
+        curr = zoo.StubProblem("inner", inner_m, config=Config(type="darts", darts_alpha=radius),
+                               loss_fn=zoo.make_roberta_reweight_loss(prev), batch=batch)
+        return curr, prev
+
+    curr64, prev64 = problems(copy.deepcopy(inner).double(), copy.deepcopy(upper).double())
+    truth = horc.darts([v.double() for v in vector], curr64, prev64, False)
+    del curr64, prev64
+    w_before = [p.data.clone() for p in inner.parameters()]
+    curr, prev = problems(inner, upper)
+    want = horc.darts(vector, curr, prev, False)
+    for p, w in zip(inner.parameters(), w_before):
+        p.data.copy_(w)
+    got = hg.jvp_fn_mapping["darts"](vector, curr, prev, False)
+    e_ref, _ = rel_err(_np(want), _np(truth))
+    e_got, _ = rel_err(_np(got), _np(truth))
+    rel, _ = rel_err(_np(got), _np(want))
+    print(f"RobertaForSequenceClassification (124,647,170 params / 201 tensors) darts R={radius}: vs fp64 truth: reference-fp32 "
+          f"{e_ref:.2e}, hip {e_got:.2e}; hip vs reference-fp32 {rel:.2e}")
+    assert rel <= max(2e-3, e_ref), (rel, e_ref)
+    assert e_got <= max(2e-3, 2.0 * e_ref), (e_got, e_ref)
+    drift = max(((p.data - w).abs() / w.abs().clamp_min(1e-3)).max().item() for p, w in zip(inner.parameters(), w_before))
+    assert drift <= 2.4e-7, drift
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json cfg 5 shape: mixed-op supernet inner (621 tensors), architecture parameters upper,
 # Neumann K = 20

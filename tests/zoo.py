@@ -192,6 +192,44 @@ class TokenClassifier(nn.Module):
         return self.head(self.encoder(h)[:, 0])
 
 
+def roberta_seqcls(layers=12, hidden=768, heads=12, ffn=3072, vocab=50265, positions=514):
+    """BASELINE.json cfg 4's inner model AS NAMED: transformers' ``RobertaForSequenceClassification`` built offline from a
+    config (examples/bert_data_reweighting/model.py:11-32 loads the same class from a checkpoint):
+    roberta-base = 124,647,170 parameters in 201 tensors.  Dropout is switched off — a finite-difference hypergradient
+    evaluates the loss three times and needs the same function each time.  Reduced ``layers`` / sizes give the CPU-sized
+    variant of the distributed tests."""
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+
+    cfg = RobertaConfig(vocab_size=vocab, max_position_embeddings=positions, type_vocab_size=1, num_labels=2, hidden_size=hidden,
+                        num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    return RobertaForSequenceClassification(cfg)
+
+
+class RobertaInner(nn.Module):
+    """forward(batch) -> logits, as BertModel.forward does with (seqs, masks, segments) (model.py:22-32)."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.bert = roberta_seqcls(**kw)
+
+    def forward(self, batch):
+        seqs, masks, segments = batch
+        return self.bert(input_ids=seqs, attention_mask=masks, token_type_ids=segments).logits
+
+
+def make_roberta_reweight_loss(upper):
+    """examples/bert_data_reweighting/main.py:118-128: per-sample CE weighted by the reweighting net of its detached value."""
+
+    def loss(self, batch):
+        seqs, masks, segments, labels = batch
+        lv = F.cross_entropy(self.fwd((seqs, masks, segments)).view(-1, 2), labels, reduction="none").reshape(-1, 1)
+        w = upper.fwd(lv.detach())
+        return torch.mean(w * lv)
+
+    return loss
+
+
 class _MixedOp(nn.Module):
     """Softmax(alpha)-weighted sum of candidate ops (DARTS search space, reduced)."""
 
