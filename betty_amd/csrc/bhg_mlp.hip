@@ -174,18 +174,27 @@ __device__ __forceinline__ float frag(const float* __restrict__ lds, int row, in
 // launch_gemm).  The instance then has NO edge path: with the ragged-tile branches in the loop hipcc puts an
 // `s_waitcnt vmcnt(0)` at the top of every step (the control-flow join), which serialises the two-stage
 // register prefetch — step s+1's loads had to land BEFORE step s's MFMAs instead of behind them.
+// gemm_body: one workgroup's tile; (bx, by, bz) = (N tile, M tile, split).  k_gemm maps them from blockIdx; the grouped
+// launch of the hoisted direction products (k_hoist) from a per-problem block table.  `smem`: (2 * A_ELEMS + 2 * B_ELEMS)
+// floats of LDS provided by the kernel.
+template <int LA, int LB, int TN>
+struct GemmLds {
+  static constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
+  static constexpr int B_ELEMS = (LB == LAYOUT_KC) ? TN * kPadK : kTK * TN;
+  static constexpr int FLOATS = 2 * A_ELEMS + 2 * B_ELEMS;
+};
 template <int LA, int LB, int TN, bool FAST, bool BF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 3 : 2, TN == 32 ? 3 : 2))) void k_gemm(GemmArgs a) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* __restrict__ smem) {
   static_assert(TN == 64 || TN == 32, "tile width");
   constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
-  constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
-  constexpr int B_ELEMS = (LB == LAYOUT_KC) ? TN * kPadK : kTK * TN;
-  __shared__ __attribute__((aligned(16))) float sA[2][A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float sB[2][B_ELEMS];
+  constexpr int A_ELEMS = GemmLds<LA, LB, TN>::A_ELEMS;
+  constexpr int B_ELEMS = GemmLds<LA, LB, TN>::B_ELEMS;
+  float (*sA)[A_ELEMS] = reinterpret_cast<float (*)[A_ELEMS]>(smem);
+  float (*sB)[B_ELEMS] = reinterpret_cast<float (*)[B_ELEMS]>(smem + 2 * A_ELEMS);
 
-  const int n0 = blockIdx.x * TN;
-  const int m0 = blockIdx.y * kTM;
-  int split = blockIdx.z, nsplit = a.splits, npairs = a.pairs, first = 0;
+  const int n0 = bx * TN;
+  const int m0 = by * kTM;
+  int split = bz, nsplit = a.splits, npairs = a.pairs, first = 0;
   if (a.pair_split > 0) {   // this workgroup's K range belongs to ONE of the two operand pairs (workgroup-uniform)
     first = split >= a.pair_split ? 1 : 0;
     nsplit = first ? a.splits - a.pair_split : a.pair_split;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
 #undef SCHED_FENCE
 
   // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)blockIdx.z * a.out_rows * a.ldo : 0);
+  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)bz * a.out_rows * a.ldo : 0);
   if (FAST && TN == 32 && LA == LAYOUT_KC && !a.addend && a.xpose_out) {
     // all-interior 128 x 32 tile: transpose through LDS (the A buffer, free now) so the slab leaves as four 16-B stores
     // per lane (8 lanes cover one 128-B row segment) instead of sixteen 4-B stores
@@ -363,6 +372,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 
       }
     }
   }
+}
+
+template <int LA, int LB, int TN, bool FAST, bool BF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 3 : 2, TN == 32 ? 3 : 2))) void k_gemm(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmLds<LA, LB, TN>::FLOATS];
+  gemm_body<LA, LB, TN, FAST, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // ---- fused recurrence epilogues ("one pass": the weight-shaped HVP output never round-trips through HBM) ------
@@ -1061,6 +1076,7 @@ struct HeadFuse {
   const float* bias;   // c_{L-2}[K]
   const float* mask;   // m_{L-2}[rows][K]
   float* rh_out;       // Rh_{L-2}[rows][K]
+  const float* addend; // [rows][K] or NULL: hoisted chain — the direction's share h_{L-2} V_{L-2}^T, already reduced
 };
 // PF (solver iterations: HEAD_JVP with the fused R-backward, K <= 512, C <= 12): the kernel is a chain of dependent
 // L2 round trips (slab batches -> dot-product operands -> softmax inputs -> three class batches of the R-backward);
@@ -1148,6 +1164,10 @@ __global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < NB; ++u)
           if (s0 + u < fz.splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
+      }
+      if (fz.addend) {
+        const float4 ad = ld16(fz.addend + (int64_t)b * K + k);
+        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
       }
       v.x = (v.x + bv.x) * mv.x; v.y = (v.y + bv.y) * mv.y; v.z = (v.z + bv.z) * mv.z; v.w = (v.w + bv.w) * mv.w;
       *reinterpret_cast<float4*>(srow + k) = v;
@@ -1544,6 +1564,8 @@ struct WskArgs {
   double* partT2;       // one partial per workgroup or NULL
   const double* scal;   // BF instances: beta
   int ntm, ntn;         // output tiles
+  const float* addend;  // [M][N] or NULL: a fully reduced product added before bias / mask (hoisted chain: the direction's
+                        // share G_l, see k_hoist); with partT2 it — not the first operand pair — is T2's left factor
 };
 constexpr int kWskWaves = 8;
 constexpr int kWskPad = 33;
@@ -1776,7 +1798,11 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
   const int nwp = kWskWaves / a.pairs;   // waves per operand pair
   const int pi = wave / nwp;             // wave-uniform
   const int wq = wave - pi * nwp;
-  const int Kw = a.K / nwp;
+  // this wave's share of the pair's K range, in 32-k chunks: [c0, c1) — even when nwp divides the chunk count, else the
+  // first waves take one chunk more; a wave without a chunk contributes a zero tile
+  const int nct = a.K / 32;
+  const int c0 = (int)(((int64_t)wq * nct) / nwp), c1 = (int)(((int64_t)(wq + 1) * nct) / nwp);
+  const int kbeg_w = c0 * 32, nch_w = c1 - c0;
   const GemmPair pr = a.pr[pi];
   f32x4 acc[2][2];
 #pragma unroll
@@ -1786,7 +1812,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
   // epilogue operands of this thread's two outputs: requested before the K loop, they land under it
-  float e_mask[2], e_rh[2], e_bias[2];
+  float e_mask[2], e_rh[2], e_bias[2], e_add[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = threadIdx.x + 64 * kWskWaves * u;
@@ -1794,14 +1820,17 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
     e_mask[u] = a.mask ? a.mask[idx] : 1.f;
     e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
     e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
+    e_add[u] = a.addend ? a.addend[idx] : 0.f;
   }
-  if (LDSV) {
-    float* my = wsl_smem + wave * kWslWaveFloats;
-    if (BF && pr.mix) wsl_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc, my);
-    else wsl_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc, my);
-    __syncthreads();   // every wave is done with its staging tile before the partial tiles overwrite them
-  } else if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, wq * Kw, Kw / 32, (float)a.scal[S_BETA], acc);
-  else wsk_loop<LB, false, D>(pr, m0, n0, wq * Kw, Kw / 32, 0.f, acc);
+  if (nch_w > 0) {   // (wave-uniform)
+    if (LDSV) {
+      float* my = wsl_smem + wave * kWslWaveFloats;
+      if (BF && pr.mix) wsl_loop<LB, true, D>(pr, m0, n0, kbeg_w, nch_w, (float)a.scal[S_BETA], acc, my);
+      else wsl_loop<LB, false, D>(pr, m0, n0, kbeg_w, nch_w, 0.f, acc, my);
+    } else if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, kbeg_w, nch_w, (float)a.scal[S_BETA], acc);
+    else wsk_loop<LB, false, D>(pr, m0, n0, kbeg_w, nch_w, 0.f, acc);
+  }
+  if (LDSV) __syncthreads();   // every wave is done with its staging tile before the partial tiles overwrite them
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -1822,9 +1851,15 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
     const int m = m0 + row, n = n0 + col;
     const int64_t idx = (int64_t)m * a.N + n;
     float v = 0.f;
-    for (int w = 0; w < nwp; ++w) v += sP[w][row][col];
-    if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
-    for (int w = nwp; w < kWskWaves; ++w) v += sP[w][row][col];
+    if (a.addend) {   // hoisted chain: the direction's share arrives reduced; every wave of this launch carries the chain product
+      v = e_add[u];
+      if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
+      for (int w = 0; w < kWskWaves; ++w) v += sP[w][row][col];
+    } else {
+      for (int w = 0; w < nwp; ++w) v += sP[w][row][col];
+      if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
+      for (int w = nwp; w < kWskWaves; ++w) v += sP[w][row][col];
+    }
     if (a.bias) v += e_bias[u];
     if (a.mask) v *= e_mask[u];
     a.out[idx] = m < a.B ? v : 0.f;
@@ -1872,12 +1907,12 @@ inline int wsk_depth() {
 }
 inline bool wsk_eligible(const WskArgs& a) {
   if (a.pairs < 1 || a.pairs > 2) return false;
-  const int nwp = kWskWaves / a.pairs;
-  bool ok = a.M % 32 == 0 && a.N % 32 == 0 && a.K % (32 * nwp) == 0 && a.K >= 32 * nwp;
+  bool ok = a.M % 32 == 0 && a.N % 32 == 0 && a.K % 32 == 0 && a.K >= 32;
   for (int i = 0; i < a.pairs; ++i) ok = ok && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
   return ok;
 }
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
+int64_t g_hoist_launches = 0; // bhg_mlp_hoist_launches()
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
@@ -2060,11 +2095,11 @@ struct BetaArgs {
   const float* r; float* p;
   int64_t off[BHG_MLP_MAX_LAYERS + 1]; int len[BHG_MLP_MAX_LAYERS + 1]; int nt;   // small slices (flat element offsets)
 };
-__global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
+__device__ __forceinline__ void beta_body(const BetaArgs& a, const int bx) {
   __shared__ double red[3][kWaves];
   __shared__ float s_beta;
   // this thread's element of the small slices: its loads are issued BEFORE the partial sums are reduced (independent)
-  const int gi = blockIdx.x * kThreads + threadIdx.x;
+  const int gi = bx * kThreads + threadIdx.x;
   int64_t eoff = -1;
   {
     int base = 0;
@@ -2100,7 +2135,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
     const double rr_old = a.scal[S_RR_OLD];
     const float beta = (float)tot[0] / (float)rr_old;
     s_beta = beta;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       a.scal[S_RR_NEW] = tot[0];
       a.scal[S_BETA] = (double)beta;
       a.scal[S_PP] = tot[0] + 2.0 * (double)beta * tot[1] + (double)beta * (double)beta * tot[2];
@@ -2108,6 +2143,109 @@ __global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) {
   }
   __syncthreads();
   if (eoff >= 0) a.p[eoff] = fz_add(rv, fz_mul(s_beta, pv));
+}
+__global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) { beta_body(a, blockIdx.x); }
+
+// ---- hoisted direction products (fused CG solver, BHG_MLP_HOIST) ----------------------------------------------------------
+// Half of the R-chain's matrix work does not depend on the chain at all, only on the direction: the forward products
+// Gf_l = h_l V_l^T (every MFMA layer) and the backward products Gb_l = delta_l V_l (every layer behind the first).  And
+// they are LINEAR in the direction, which the lazy CG direction is a two-term sum of:  p_k = r_k + beta p_{k-1}  =>
+//     G(p_k) = G(r_k) + beta * G(p_{k-1})          (batch-sized arrays, kept from iteration to iteration)
+// So ONE grouped launch at the top of the iteration (k_hoist) forms every G(r_k) — reading the residual alone: no
+// second operand, no mixing in the loaders, and no step of the chain in front of it, not even beta: the blocks behind the
+// GEMM tiles of the same launch do k_cg_beta's work — and k_hoist_reduce turns the split-K slabs into G(p_k).  What stays on
+// the dependent chain are the products with the constant weights, Rh_{l-1} W_l^T and Rd_l W_l: one operand pair, half the K
+// loop, run in the in-workgroup split-K form whose epilogue adds G (no slabs, no reduce launch).  One fill / drain for
+// half of the chain's flops instead of five; 9 dependent launches per iteration instead of 12.
+struct HoistProb {
+  const float* A;      // [Bp][K] batch-sized and iteration-invariant: h_l (forward) / delta_l (backward)
+  const float* Bm;     // residual slice of the W_l-shaped state: [N][K] (forward, K-contiguous) / [K][N] (backward)
+  float* slabs;        // [splits][Bp][N]
+  int K, N, splits, rc, lda, ldb;
+};
+constexpr int kHoistMax = 14;
+struct HoistArgs {
+  HoistProb p[kHoistMax];
+  int blk0[kHoistMax + 1];
+  int n, Bp, gemm_blocks, do_beta;
+  BetaArgs beta;
+};
+static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
+constexpr int kHoistLds = GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS > GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS
+                              ? GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS : GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hoist(HoistArgs ha) {
+  __shared__ __attribute__((aligned(16))) float smem[kHoistLds];
+  const int b = blockIdx.x;
+  if (b >= ha.gemm_blocks) {   // the scalar work between two iterations rides behind the tiles (cg.py:51-53, see k_cg_beta)
+    if (ha.do_beta) beta_body(ha.beta, b - ha.gemm_blocks);
+    return;
+  }
+  int i = 0;
+  while (i + 1 < ha.n && b >= ha.blk0[i + 1]) ++i;
+  const int t = b - ha.blk0[i];
+  GemmArgs a{};
+  a.pr[0].A = ha.p[i].A; a.pr[0].B = ha.p[i].Bm; a.pr[0].lda = ha.p[i].lda; a.pr[0].ldb = ha.p[i].ldb;
+  a.pairs = 1; a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
+  a.out = ha.p[i].slabs; a.ldo = a.N; a.out_rows = ha.Bp; a.nt_out = 1; a.xpose_out = 1;
+  const int ntn = a.N / 32, ntm = ha.Bp / kTM;
+  const int bx = t % ntn, by = (t / ntn) % ntm, bz = t / (ntn * ntm);
+  if (ha.p[i].rc) gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false>(a, bx, by, bz, smem);
+  else gemm_body<LAYOUT_KC, LAYOUT_KC, 32, true, false>(a, bx, by, bz, smem);
+}
+
+// G(p_k)[m][n] = sum_s slabs[s][m][n] + beta * G(p_{k-1})[m][n]   (rows >= B zero; first iteration: no second term), and for
+// the first layer's forward product also Rh_0 = mask_0 * (G + c_0).  One float4 per thread; fixed summation order.
+struct HoistRedProb {
+  const float* slabs; float* G; int N, splits;
+  const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (G + bias)
+};
+struct HoistRedArgs {
+  HoistRedProb p[kHoistMax];
+  int blk0[kHoistMax + 1];
+  int n, Bp, B, first;
+  const double* scal;
+};
+__global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < ra.n && b >= ra.blk0[i + 1]) ++i;
+  const HoistRedProb pr = ra.p[i];
+  const int nv = pr.N / 4;
+  const int64_t total = (int64_t)ra.Bp * nv;
+  const int64_t idx = (int64_t)(b - ra.blk0[i]) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
+  const int64_t slab = (int64_t)ra.Bp * pr.N;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m < ra.B) {
+    constexpr int NB = 8;
+    const float* p0 = pr.slabs + idx * 4;
+    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), bv = gp, mv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (!ra.first) gp = ld16(pr.G + idx * 4);
+    if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
+    for (int s0 = 0; s0 < pr.splits; s0 += NB) {
+      float4 t[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) t[u] = ld16(p0 + (int64_t)(s0 + u < pr.splits ? s0 + u : pr.splits - 1) * slab);
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        if (s0 + u < pr.splits) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    if (!ra.first) {   // the two roundings of p = r + (beta * p_old), applied to the products instead of the operands
+      const float beta = (float)ra.scal[S_BETA];
+      v.x = fz_add(v.x, fz_mul(beta, gp.x)); v.y = fz_add(v.y, fz_mul(beta, gp.y));
+      v.z = fz_add(v.z, fz_mul(beta, gp.z)); v.w = fz_add(v.w, fz_mul(beta, gp.w));
+    }
+    *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
+    if (pr.out) {
+      float4 o;
+      o.x = (v.x + bv.x) * mv.x; o.y = (v.y + bv.y) * mv.y; o.z = (v.z + bv.z) * mv.z; o.w = (v.w + bv.w) * mv.w;
+      *reinterpret_cast<float4*>(pr.out + idx * 4) = o;
+    }
+  } else {
+    *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
+    if (pr.out) *reinterpret_cast<float4*>(pr.out + idx * 4) = v;
+  }
 }
 
 // ---- per-device side stream + events -------------------------------------------------------------------------------
@@ -2165,12 +2303,73 @@ int reduce_blocks(int slab, int N) {
   return blocks > 2048 ? 2048 : blocks;
 }
 
+// Plan of the hoisted direction products (see k_hoist): which products, their split-K factors — the smallest K-steps-per-
+// workgroup target whose workgroups all fit one resident wave of the chip (3 per CU) — and where their slabs and their
+// persistent G arrays live inside the fused workspace.
+struct HoistPlan {
+  bool ok;
+  int n;
+  int layer[kHoistMax], bwd[kHoistMax], K[kHoistMax], N[kHoistMax], splits[kHoistMax];
+  int blk0[kHoistMax + 1];
+  size_t slab_off[kHoistMax], g_off[kHoistMax];   // float offsets inside the hoist region
+  size_t floats;
+  int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
+};
+inline int hoist_mode() {
+  const char* e = getenv("BHG_MLP_HOIST");   // read on every call so a test can compare both arms in one process
+  return e ? atoi(e) : 1;
+}
+void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
+  memset(hp, 0, sizeof(*hp));
+  const int L = m->L, Bp = m->Bp;
+  for (int l = 0; l < BHG_MLP_MAX_LAYERS; ++l) hp->gf[l] = hp->gb[l] = -1;
+  if (!use_head(m) || L < 3 || L - 1 > kHoistMax / 2 || Bp % kTM != 0) return;
+  for (int l = 0; l <= L - 1; ++l) if (m->dims[l] % 32 != 0) return;           // every MFMA layer: K and N multiples of 32
+  const int Nh = m->dims[L - 1];
+  if ((size_t)Nh * sizeof(float) > 64 * 1024) return;                         // the head kernel combines the last hidden layer
+  for (int l = 1; l + 1 < L; ++l)                                              // T2 slots were sized for the reduce launch
+    if ((Bp / 32) * (m->dims[l] / 32) != reduce_blocks(Bp * m->dims[l], m->dims[l])) return;
+  int n = 0;
+  for (int l = 0; l + 1 < L; ++l) { hp->layer[n] = l; hp->bwd[n] = 0; hp->K[n] = m->dims[l]; hp->N[n] = m->dims[l + 1]; hp->gf[l] = n; ++n; }
+  for (int l = 1; l + 1 < L; ++l) { hp->layer[n] = l; hp->bwd[n] = 1; hp->K[n] = m->dims[l + 1]; hp->N[n] = m->dims[l]; hp->gb[l] = n; ++n; }
+  hp->n = n;
+  static const int slots = getenv("BHG_HOIST_WGS") ? atoi(getenv("BHG_HOIST_WGS")) : 768;
+  const int ntm = Bp / kTM;
+  int tgt = 8;
+  for (; tgt < 4096; ++tgt) {
+    int wgs = 0;
+    for (int i = 0; i < n; ++i) {
+      const int ks = hp->K[i] / kTK;
+      const int per = ks < tgt ? ks : tgt;
+      wgs += (hp->N[i] / 32) * ntm * ((ks + per - 1) / per);
+    }
+    if (wgs <= slots) break;
+  }
+  size_t off = 0;
+  int blk = 0;
+  for (int i = 0; i < n; ++i) {
+    const int ks = hp->K[i] / kTK;
+    int sp = (ks + tgt - 1) / tgt;
+    const int per = (ks + sp - 1) / sp;
+    sp = (ks + per - 1) / per;               // no empty split
+    hp->splits[i] = sp;
+    hp->blk0[i] = blk;
+    blk += (hp->N[i] / 32) * ntm * sp;
+    hp->slab_off[i] = off; off += (size_t)sp * Bp * hp->N[i];
+    hp->g_off[i] = off;    off += (size_t)Bp * hp->N[i];
+  }
+  hp->blk0[n] = blk;
+  hp->floats = off;
+  hp->ok = true;
+}
+
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
   float* rz; double* rzx;           // [Bp][dims[L]]: Rz of the current direction / accumulated Rz(x)
   int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
+  float* hoist;                     // slabs + G arrays of the hoisted direction products (HoistPlan offsets)
   size_t bytes;
 };
 void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
@@ -2192,6 +2391,9 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->partT2 = static_cast<double*>(take(sizeof(double) * (nt2 > 0 ? nt2 : 1)));
   w->rz = static_cast<float*>(take(sizeof(float) * (size_t)m->Bp * m->dims[m->L]));
   w->rzx = static_cast<double*>(take(sizeof(double) * (size_t)m->Bp * m->dims[m->L]));
+  HoistPlan hp;
+  hoist_plan(m, &hp);
+  w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
   w->bytes = off;
 }
 
@@ -2217,6 +2419,8 @@ struct ChainMode {
   double* rzx_acc;              // FUSE_NEUMANN without an accumulator vector: sum_k Rz(v_k) lands here (head kernel)
   int skip_outputs;             // FUSE_CG: stop after the step length (see bhg_mlp_cg_solve)
   int gemm_mode;                // FUSE_NONE: BHG_MLP_WSK-style mode asked for by the caller (bhg_mlp_hvp_mode)
+  const HoistPlan* hoist;       // FUSE_CG + lazy: run the hoisted form of the chain (k_hoist); NULL = the classic chain
+  const BetaArgs* beta; int beta_blocks;   // hoisted form: k_cg_beta's work rides in k_hoist's launch (iterations > 0)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2273,10 +2477,79 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     part_base_bias = base;
   }
 
-  // ---- R-forward ------------------------------------------------------------------------------------
+  const HoistPlan* hp = (cg && cm.lazy) ? cm.hoist : nullptr;
+  // ---- hoisted form: every direction product in ONE grouped launch, then the chain with the constant weights only ---------
   HeadFuse head_fuse{};
   bool fuse_head = false;
-  for (int l = 0; l < L; ++l) {
+  if (hp) {
+    float* hbase = cm.ws->hoist;
+    HoistArgs ha{};
+    HoistRedArgs ra{};
+    for (int i = 0; i < hp->n; ++i) {
+      const int l = hp->layer[i];
+      HoistProb& q = ha.p[i];
+      q.A = hp->bwd[i] ? m->delta[l] : m->h[l];
+      q.Bm = cm.fa + cm.starts[2 * l];            // the RESIDUAL's slice: G(p) = G(r) + beta G(p_old) (k_hoist_reduce)
+      q.slabs = hbase + hp->slab_off[i];
+      q.K = hp->K[i]; q.N = hp->N[i]; q.splits = hp->splits[i]; q.rc = hp->bwd[i];
+      q.lda = hp->K[i]; q.ldb = hp->bwd[i] ? hp->N[i] : hp->K[i];
+      ha.blk0[i] = hp->blk0[i];
+      HoistRedProb& rq = ra.p[i];
+      rq.slabs = q.slabs; rq.G = hbase + hp->g_off[i]; rq.N = hp->N[i]; rq.splits = hp->splits[i];
+      if (!hp->bwd[i] && l == 0) { rq.bias = static_cast<const float*>(dir[1]); rq.mask = m->mask[0]; rq.out = m->Rh[0]; }
+    }
+    ha.blk0[hp->n] = hp->blk0[hp->n];
+    ha.n = hp->n; ha.Bp = Bp; ha.gemm_blocks = hp->blk0[hp->n];
+    ha.do_beta = (!cm.first && cm.beta) ? 1 : 0;
+    if (ha.do_beta) ha.beta = *cm.beta;
+    hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
+    ++g_hoist_launches;
+    int rblk = 0;
+    for (int i = 0; i < hp->n; ++i) { ra.blk0[i] = rblk; rblk += (Bp * (hp->N[i] / 4) + 255) / 256; }
+    ra.blk0[hp->n] = rblk;
+    ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cm.first; ra.scal = cm.scal;
+    hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
+    static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 1024;
+    // forward chain: Rh_l = mask_l * (Rh_{l-1} W_l^T + Gf_l + c_l)
+    for (int l = 1; l + 1 < L; ++l) {
+      const int K = m->dims[l], N = m->dims[l + 1];
+      const float* c = static_cast<const float*>(dir[2 * l + 1]);
+      const float* Gf = hbase + hp->g_off[hp->gf[l]];
+      if (l == L - 2) {   // the head kernel combines this layer's slabs itself (and adds Gf)
+        GemmArgs a{};
+        a.pr[0] = {m->Rh[l - 1], m->W[l], K, K};
+        a.pairs = 1; a.M = Bp; a.N = N; a.K = K;
+        a.splits = pick_splits((N + tn - 1) / tn, K, 1);
+        a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+        launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+        head_fuse = {m->partial, a.splits, Bp * N, c, m->mask[l], m->Rh[l], Gf};
+        fuse_head = true;
+      } else {
+        WskArgs w{};
+        w.pr[0] = {m->Rh[l - 1], m->W[l], K, K}; w.pairs = 1; w.M = Bp; w.N = N; w.K = K; w.B = B;
+        w.bias = c; w.mask = m->mask[l]; w.out = m->Rh[l]; w.addend = Gf;
+        launch_gemm_wsk<LAYOUT_KC>(w, st, K >= staged_mink);
+      }
+    }
+    {
+      const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
+      launch_head_forward(st, Bp, (const float*)m->Rh[l - 1], m->h[l], m->W[l], static_cast<const float*>(dir[2 * l]),
+                          static_cast<const float*>(dir[2 * l + 1]), m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr,
+                          (const float*)m->delta[l], (const float*)m->mask[l - 1], m->Rd[l - 1], &head_fuse, cm.ws->partT1,
+                          cm.ws->partT2h, cm.ws->rz, cm.rzx_acc, cm.first);
+    }
+    // backward chain: Rd_{l-1} = mask_{l-1} * (Rd_l W_l + Gb_l); T2_l = 2 <Gb_l, Rh_{l-1}> from the tile epilogue
+    for (int l = L - 2; l >= 1; --l) {
+      const int K = m->dims[l + 1], N = m->dims[l];
+      WskArgs w{};
+      w.pr[0] = {m->Rd[l], m->W[l], K, N}; w.pairs = 1; w.M = Bp; w.N = N; w.K = K; w.B = B;
+      w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.addend = hbase + hp->g_off[hp->gb[l]];
+      w.rh = m->Rh[l - 1]; w.partT2 = cm.ws->partT2 + cm.ws->t2_off[l];
+      launch_gemm_wsk<LAYOUT_RC>(w, st, K >= staged_mink);
+    }
+  }
+  // ---- R-forward ------------------------------------------------------------------------------------
+  for (int l = 0; l < L && !hp; ++l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
@@ -2416,7 +2689,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first; aa.kpar = cm.kpar;
   }
   // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
-  for (int l = L - 1; l >= 1; --l) {
+  for (int l = L - 1; l >= 1 && !hp; --l) {
     if (!single) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
       if (no_side) {
         launch_outer(l, st);
@@ -2602,6 +2875,7 @@ int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out,
 
 // ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
 int64_t bhg_mlp_wsk_launches(void) { return bhg::g_wsk_launches; }
+int64_t bhg_mlp_hoist_launches(void) { return bhg::g_hoist_launches; }
 
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff, float alpha,
                                 int K, void* fws, size_t fws_bytes, void* stream) {
@@ -2676,6 +2950,10 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     }
   }
   const int bgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;   // one element of the small slices per thread
+  HoistPlan hplan;
+  hplan.ok = false;
+  if (lazy && hoist_mode() != 0) hoist_plan(m, &hplan);
+  const bool hoist = lazy && hplan.ok;
   for (int k = 0; k < K; ++k) {
     hipEvent_t ta, tb, tc, td;
     const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
@@ -2683,7 +2961,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
     if (lazy && k > 0) {   // beta, p.p of the coming direction, direction update of the small slices
       ba.part = w.partRR[k & 1];
-      hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);
+      if (!hoist) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);   // (hoisted form: inside k_hoist)
     }
     if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     ChainMode cm{};
@@ -2708,6 +2986,8 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.skip_outputs = (!x && k == K - 1) ? 1 : 0;
     cm.first = k == 0;
     cm.kpar = k & 1;
+    cm.hoist = hoist ? &hplan : nullptr;
+    cm.beta = &ba; cm.beta_blocks = bgrid;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
     if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

@@ -45,7 +45,6 @@ class AutogradHVP:
 # backward, an op that allocates through an uncaptured path) raises inside the capture: the wrapper then stays eager for
 # the rest of the solve.  BHG_HVP_GRAPH=0 turns it off, =1 forces it on; default: on for K >= 4.
 _SOLVE_STREAMS = {}
-_GRAPH_POOLS = {}
 GRAPH_STATS = {"captures": 0, "replays": 0, "fallbacks": 0}
 
 
@@ -107,11 +106,11 @@ class GraphedHVP:
             self.dead = True
             return self.fn(views)
         graph = torch.cuda.CUDAGraph()
-        pool = _GRAPH_POOLS.get(dev.index)
-        if pool is None:
-            pool = _GRAPH_POOLS[dev.index] = torch.cuda.graph_pool_handle()
         try:
-            graph.capture_begin(pool=pool, capture_error_mode="thread_local")
+            # a private memory pool per graph (released with the graph at the end of the solve): a pool handle shared
+            # across solves is dropped by the caching allocator when the previous graph dies (round-3 measurement: the second
+            # capture then trips an internal assert of HIPCachingAllocator)
+            graph.capture_begin(capture_error_mode="thread_local")
             try:
                 out = self.fn(views)
             finally:

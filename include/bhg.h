@@ -272,6 +272,12 @@ int bhg_mlp_cg_mixed_coeff(const bhg_mlp* m, const int64_t* labels, float* coeff
  * is used: 0 nowhere, 1 wherever the shape allows, 2 short reductions only — the fused CG solver's default —, 3 the
  * same plus the LDS-staged form for the long R-backward reduction — the Neumann solver's default).              */
 int64_t bhg_mlp_wsk_launches(void);
+/* Test / measurement hook: how many iterations of bhg_mlp_cg_solve this process ran in the HOISTED form of the chain (env
+ * BHG_MLP_HOIST, default 1): every product that depends on the direction alone — h_l V_l^T and delta_l V_l, half of the
+ * R-chain's matrix work — in ONE grouped split-K launch on the residual, G(p_k) = G(r_k) + beta G(p_{k-1}) by linearity of the
+ * products in the lazy direction p_k = r_k + beta p_{k-1} (cg.py:53); the chain keeps the products with the constant
+ * weights, in the in-workgroup split-K form with G as addend.  BHG_MLP_HOIST=0: the classic chain (A/B arm).        */
+int64_t bhg_mlp_hoist_launches(void);
 /* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
  * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
  * in direction v_K (`v_last`: the 2L slices of the direction buffer that holds v_K — v0 for even K, v1 for odd K) into the

@@ -74,6 +74,10 @@ def _arms(algo):
     arms += [(f"unfused-wsk{w}", dict(hvp="hip", fused=False, wsk=str(w))) for w in (0, 1, 2, 3)]
     arms += [("fused-default", dict(hvp="hip", fused=True, wsk=None)), ("fused+solution", dict(hvp="hip", fused=True, wsk=None, keep=True))]
     if algo == "cg":
+        # the classic chain (direction products inside the chain, lazy direction mixed in the GEMM loaders) next to the default
+        # hoisted form (k_hoist: G(p) = G(r) + beta G(p_old))
+        arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
+                 ("fused-classic-wsk0", dict(hvp="hip", fused=True, wsk="0", hoist="0"))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
@@ -92,6 +96,10 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
         monkeypatch.delenv("BHG_MLP_WSK", raising=False)
     else:
         monkeypatch.setenv("BHG_MLP_WSK", arm["wsk"])
+    if arm.get("hoist") is None:
+        monkeypatch.delenv("BHG_MLP_HOIST", raising=False)
+    else:
+        monkeypatch.setenv("BHG_MLP_HOIST", arm["hoist"])
     saved = be.cg_variant
     be.cg_variant = {"stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}.get(arm.get("variant"), _native.BHG_CG_AUTO)
     try:

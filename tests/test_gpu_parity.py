@@ -640,11 +640,12 @@ def test_mixed_coeff_identifies_the_solve_by_token_not_by_address(algo, be):
         sol = p
     assert token and token is not True
     views = lay.views(sol, vec)
-    by_token = _np(prov.mixed_vjp(views, False, solve=token))
-    clones = [t.clone() for t in views]          # different addresses, same numbers
+    st = prov._state
+    c_token = st.mixed_coeff(views, token).clone()            # from the Rz the solver accumulated
+    clones = [t.clone() for t in views]                       # different addresses, same numbers
+    c_clone = st.mixed_coeff(clones).clone()                  # no token: the clones are read like any direction
+    assert (c_token - c_clone).norm().item() <= 2e-6 * c_clone.norm().item()
     by_clone = _np(prov.mixed_vjp(clones, False))
-    rel, _ = rel_err(by_clone, by_token)
-    assert rel <= 2e-6, rel
     # the un-fused loop on the same inputs
     curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
     curr.hypergradient_structure = lambda prev_: WeightedCEMLP(curr, prev_, layers=list(curr.module.layers),
@@ -656,7 +657,7 @@ def test_mixed_coeff_identifies_the_solve_by_token_not_by_address(algo, be):
     # stale tokens are refused: a hand-driven HVP reuses the workspace the token refers to
     hvp_fn(lay.views(lay.state(3)[2], vec))
     with pytest.raises(RuntimeError, match="stale"):
-        prov.mixed_vjp(views, False, solve=token)
+        st.mixed_coeff(views, token)
 
 
 def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
@@ -765,11 +766,41 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
     assert all(np.array_equal(u, v) for u, v in zip(again[1], sols["1"][1]))
 
 
+@pytest.mark.parametrize(
+    "dims,B,K",
+    [([256, 384, 128, 10], 100, 5), ([512, 256, 256, 64, 10], 128, 4), ([256, 256, 256, 256, 128, 10], 100, 6), ([512, 1024, 64, 10], 200, 3),
+     ([3072, 2048, 1536, 384, 10], 100, 20)],
+    ids=lambda v: str(v),
+)
+def test_hoisted_chain_matches_classic_chain(dims, B, K, monkeypatch):
+    """Fused CG solver, BHG_MLP_HOIST=1 (default: every direction product h V^T / delta V in ONE grouped launch on the
+    residual, G(p) = G(r) + beta G(p_old), the chain keeps the constant-weight products in the in-workgroup split-K form with
+    G as addend; k_cg_beta's work inside that launch) against BHG_MLP_HOIST=0 (direction products inside the chain, lazy
+    direction mixed in the loaders) and against the un-fused loop: same hypergradient, same CG scalars, bit-reproducible,
+    with and without a solution vector."""
+    lib = _native.load()
+    out = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("BHG_MLP_HOIST", arm)
+        n0 = lib.bhg_mlp_hoist_launches()
+        out[arm] = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, True)
+        assert (lib.bhg_mlp_hoist_launches() > n0) == (arm == "1"), "the arm under test must be the one that ran"
+    unf = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, False)
+    tol = 1e-4 if K >= 20 else 5e-5
+    rel, _ = rel_err(out["1"][0], out["0"][0])
+    rel_u, _ = rel_err(out["1"][0], unf[0])
+    print(f"hoisted vs classic chain {dims} K={K}: {rel:.2e}; hoisted vs un-fused {rel_u:.2e}")
+    assert rel <= tol and rel_u <= tol, (rel, rel_u)
+    again = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, True)
+    assert all(np.array_equal(u, v) for u, v in zip(again[0], out["1"][0])), "bit-reproducible"
+
+
 def test_wsk_defaults_per_solver(monkeypatch):
     """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k (mode 2); the
     un-fused CG chain never does; the Neumann solver uses mode 3 (short reductions direct, long R-backward LDS-staged)
     in BOTH arms — the un-fused loop asks for it through bhg_mlp_hvp_mode — so they stay bitwise equal."""
     monkeypatch.delenv("BHG_MLP_WSK", raising=False)
+    monkeypatch.setenv("BHG_MLP_HOIST", "0")   # the classic chain (the hoisted form has its own test below)
     lib = _native.load()
     dims, B = [256, 384, 128, 10], 100     # per iteration: R-forward of layer 0 (256 k) and R-backward into it (2 x 128 k)
     n0 = lib.bhg_mlp_wsk_launches()
