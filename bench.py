@@ -254,6 +254,8 @@ def main():
                          "from the accumulated Rz(x), x is never written)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--no-hvp-graph", action="store_true",
+                    help="--hvp autograd only: eager launches of the double backward instead of the (opt-in) hipGraph replay")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
@@ -304,6 +306,8 @@ def main():
         declare_structure(curr, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution)
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
+    else:   # opaque double backward: opt into the hipGraph replay of the K HVPs (betty_amd/hypergradient/_common.py)
+        curr.hypergradient_graph = not args.no_hvp_graph
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
     layout = be.layout(vector)
@@ -484,7 +488,8 @@ def main():
                 "batch %d, %s K=%d, sync=True" % (N, M, BATCH, args.algo, K),
                 "hvp": ("analytic R-op HVP on fp32 MFMA, recurrence fused into its output kernels (one pass)" if fused else
                         "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp) + recurrence kernel" if args.hvp == "analytic" else
-                        "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else "pytorch-rocm autograd double backward"),
+                        "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else
+                        "pytorch-rocm autograd double backward" + ("" if args.no_hvp_graph else ", captured once per solve and replayed as a HIP graph (opt-in)")),
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else
                                     "not materialised: the mixed second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), "

@@ -2509,7 +2509,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     ra.blk0[hp->n] = rblk;
     ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cm.first; ra.scal = cm.scal;
     hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
-    static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 1024;
+    static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
     // forward chain: Rh_l = mask_l * (Rh_{l-1} W_l^T + Gf_l + c_l)
     for (int l = 1; l + 1 < L; ++l) {
       const int K = m->dims[l], N = m->dims[l + 1];

@@ -32,27 +32,31 @@ class AutogradHVP:
 
 
 # ---- hipGraph replay of an opaque Hessian-vector product ----------------------------------------------------------------
-# The double backward of a user's training_step is hundreds to thousands of small ATen launches (cfg 2's MLP: ~1 ms per
-# HVP for ~0.35 ms of GPU work; a DARTS supernet: tens of thousands of launches): the K HVPs of one solve run the SAME
-# launch sequence on the SAME addresses — the autograd graph of `in_grad` is fixed for the step and the direction lives in
-# one persistent flat vector — so the sequence is captured once (HIP graph) and replayed K - 2 times.
+# The double backward of a user's training_step is hundreds to thousands of small ATen launches (cfg 2's MLP: ~1.1 ms per
+# HVP, launch-bound): the K HVPs of one solve run the SAME launch sequence on the SAME addresses — the autograd graph of
+# `in_grad` is fixed for the step and the direction lives in one persistent flat vector — so the sequence is captured once
+# (HIP graph) and replayed K - 2 times.
 #   call 1: eager (settles library handles, workspaces, autotuning on the capture stream)
 #   call 2: captured (hipStreamBeginCapture .. EndCapture around torch.autograd.grad), then replayed
 #   call 3..K: replayed
 # Autograd runs a backward node on the stream its forward ran on, so the graph of `in_grad` must be BUILT on the stream
 # that later captures: `solve_stream` moves the whole solve to a library-owned side stream when the caller sits on the
-# default (legacy) stream, which HIP cannot capture.  Anything that cannot be captured (a host sync inside the double
-# backward, an op that allocates through an uncaptured path) raises inside the capture: the wrapper then stays eager for
-# the rest of the solve.  BHG_HVP_GRAPH=0 turns it off, =1 forces it on; default: on for K >= 4.
+# default (legacy) stream, which HIP cannot capture.  A capture that raises (a host sync inside the double backward, ...)
+# leaves the wrapper eager for the rest of the solve.
+# OPT-IN (measured on the MI355X, round 3): cfg 2 with the opaque HVP goes from 43.9 to 72.4 steps/s and seven solves of
+# seven captures each replay cleanly, a ResNet-12 (GPU-bound double backward) gains nothing — and hipStreamEndCapture
+# SEGFAULTS inside ROCm 7.2 on the tiny logistic-regression graph of the reference's regression scenario, which no
+# try / except can contain.  So nothing is captured unless the user says so: `curr.hypergradient_graph = True` on the inner
+# problem, or BHG_HVP_GRAPH=1 in the environment (=0 forces it off).
 _SOLVE_STREAMS = {}
 GRAPH_STATS = {"captures": 0, "replays": 0, "fallbacks": 0}
 
 
-def hvp_graph_wanted(K: int, tensors) -> bool:
-    mode = os.environ.get("BHG_HVP_GRAPH", "auto")
-    if mode == "0" or not tensors or not tensors[0].is_cuda:
+def hvp_graph_wanted(K: int, tensors, curr=None) -> bool:
+    mode = os.environ.get("BHG_HVP_GRAPH", "")
+    if mode == "0" or K < 3 or not tensors or not tensors[0].is_cuda:
         return False
-    return mode == "1" or K >= 4
+    return mode == "1" or bool(getattr(curr, "hypergradient_graph", False))
 
 
 @contextlib.contextmanager

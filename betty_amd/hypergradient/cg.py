@@ -24,7 +24,7 @@ def cg(vector, curr, prev, sync):
     provider = structured_hvp_for(curr, prev)
     K = int(curr.config.cg_iterations)
     # opaque double backward (no structure, or a structure whose HVP is an autograd callback): replayed as a HIP graph
-    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector)
+    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector, curr)
     with solve_stream(vector[0].device if vector else None, graphed):
         return _cg(vector, curr, prev, sync, provider, K, graphed)
 

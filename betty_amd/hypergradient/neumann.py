@@ -18,7 +18,7 @@ def neumann(vector, curr, prev, sync):
     provider = structured_hvp_for(curr, prev)
     K = int(curr.config.neumann_iterations)
     # opaque double backward: captured once per solve, replayed as a HIP graph (see _common.GraphedHVP)
-    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector)
+    graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector, curr)
     with solve_stream(vector[0].device if vector else None, graphed):
         return _neumann(vector, curr, prev, sync, provider, K, graphed)
 

@@ -644,7 +644,7 @@ def test_mixed_coeff_identifies_the_solve_by_token_not_by_address(algo, be):
     c_token = st.mixed_coeff(views, token).clone()            # from the Rz the solver accumulated
     clones = [t.clone() for t in views]                       # different addresses, same numbers
     c_clone = st.mixed_coeff(clones).clone()                  # no token: the clones are read like any direction
-    assert (c_token - c_clone).norm().item() <= 2e-6 * c_clone.norm().item()
+    assert (c_token - c_clone).norm().item() <= 1e-5 * c_clone.norm().item()   # Rz of a sum vs the sum of the Rz's
     by_clone = _np(prov.mixed_vjp(clones, False))
     # the un-fused loop on the same inputs
     curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
@@ -658,6 +658,29 @@ def test_mixed_coeff_identifies_the_solve_by_token_not_by_address(algo, be):
     hvp_fn(lay.views(lay.state(3)[2], vec))
     with pytest.raises(RuntimeError, match="stale"):
         st.mixed_coeff(views, token)
+
+
+@pytest.mark.parametrize("algo,K", [("cg", 8), ("neumann", 6)])
+def test_opaque_hvp_replayed_as_a_hip_graph(algo, K, be):
+    """Opt-in `curr.hypergradient_graph = True`: the opaque double backward of an MLP (no declared structure) is captured on
+    the second call of a solve and replayed for the rest (GraphedHVP); the replayed launches are the very kernels eager
+    autograd runs, so the hypergradient equals the eager one to ATen's own run-to-run noise, solve after solve."""
+    from betty_amd.hypergradient import _common
+
+    dims, B = [256, 384, 128, 10], 100
+    outs = {}
+    for arm in (False, True):
+        curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=21)
+        curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
+        curr.hypergradient_graph = arm
+        before = dict(_common.GRAPH_STATS)
+        vec = [0.1 * d for d in direction]
+        for _ in range(3):   # three solves: three captures, each on a fresh autograd graph
+            outs[arm] = _np(hg.jvp_fn_mapping[algo](vec, curr, prev, False))
+        d = {k: _common.GRAPH_STATS[k] - before[k] for k in before}
+        assert d == ({"captures": 3, "replays": 3 * (K - 1), "fallbacks": 0} if arm else {"captures": 0, "replays": 0, "fallbacks": 0}), d
+    rel, _ = rel_err(outs[True], outs[False])
+    assert rel <= 2e-5, rel
 
 
 def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
