@@ -2477,7 +2477,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     part_base_bias = base;
   }
 
-  const HoistPlan* hp = (cg && cm.lazy) ? cm.hoist : nullptr;
+  // CG: needs the lazy direction (G(p) = G(r) + beta G(p_old)); Neumann: the direction v is explicit, G(v) directly
+  const HoistPlan* hp = ((cg && cm.lazy) || (cm.mode == FUSE_NEUMANN && single)) ? cm.hoist : nullptr;
   // ---- hoisted form: every direction product in ONE grouped launch, then the chain with the constant weights only ---------
   HeadFuse head_fuse{};
   bool fuse_head = false;
@@ -2489,7 +2490,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const int l = hp->layer[i];
       HoistProb& q = ha.p[i];
       q.A = hp->bwd[i] ? m->delta[l] : m->h[l];
-      q.Bm = cm.fa + cm.starts[2 * l];            // the RESIDUAL's slice: G(p) = G(r) + beta G(p_old) (k_hoist_reduce)
+      // CG: the RESIDUAL's slice — G(p) = G(r) + beta G(p_old) (k_hoist_reduce); Neumann: the direction itself
+      q.Bm = cg ? cm.fa + cm.starts[2 * l] : static_cast<const float*>(dir[2 * l]);
       q.slabs = hbase + hp->slab_off[i];
       q.K = hp->K[i]; q.N = hp->N[i]; q.splits = hp->splits[i]; q.rc = hp->bwd[i];
       q.lda = hp->K[i]; q.ldb = hp->bwd[i] ? hp->N[i] : hp->K[i];
@@ -2500,14 +2502,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     ha.blk0[hp->n] = hp->blk0[hp->n];
     ha.n = hp->n; ha.Bp = Bp; ha.gemm_blocks = hp->blk0[hp->n];
-    ha.do_beta = (!cm.first && cm.beta) ? 1 : 0;
+    ha.do_beta = (cg && !cm.first && cm.beta) ? 1 : 0;
     if (ha.do_beta) ha.beta = *cm.beta;
     hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
     ++g_hoist_launches;
     int rblk = 0;
     for (int i = 0; i < hp->n; ++i) { ra.blk0[i] = rblk; rblk += (Bp * (hp->N[i] / 4) + 255) / 256; }
     ra.blk0[hp->n] = rblk;
-    ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cm.first; ra.scal = cm.scal;
+    ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cg ? cm.first : 1; ra.scal = cm.scal;
     hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
     static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
     // forward chain: Rh_l = mask_l * (Rh_{l-1} W_l^T + Gf_l + c_l)
@@ -2535,8 +2537,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
       launch_head_forward(st, Bp, (const float*)m->Rh[l - 1], m->h[l], m->W[l], static_cast<const float*>(dir[2 * l]),
                           static_cast<const float*>(dir[2 * l + 1]), m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr,
-                          (const float*)m->delta[l], (const float*)m->mask[l - 1], m->Rd[l - 1], &head_fuse, cm.ws->partT1,
-                          cm.ws->partT2h, cm.ws->rz, cm.rzx_acc, cm.first);
+                          (const float*)m->delta[l], (const float*)m->mask[l - 1], m->Rd[l - 1], &head_fuse,
+                          cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr, cg ? cm.ws->rz : nullptr, cm.rzx_acc, cm.first);
     }
     // backward chain: Rd_{l-1} = mask_{l-1} * (Rd_l W_l + Gb_l); T2_l = 2 <Gb_l, Rh_{l-1}> from the tile epilogue
     for (int l = L - 2; l >= 1; --l) {
@@ -2544,7 +2546,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       WskArgs w{};
       w.pr[0] = {m->Rd[l], m->W[l], K, N}; w.pairs = 1; w.M = Bp; w.N = N; w.K = K; w.B = B;
       w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.addend = hbase + hp->g_off[hp->gb[l]];
-      w.rh = m->Rh[l - 1]; w.partT2 = cm.ws->partT2 + cm.ws->t2_off[l];
+      if (cg) { w.rh = m->Rh[l - 1]; w.partT2 = cm.ws->partT2 + cm.ws->t2_off[l]; }
       launch_gemm_wsk<LAYOUT_RC>(w, st, K >= staged_mink);
     }
   }
@@ -3012,6 +3014,9 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   FusedWs w;
   carve_fused_ws(m, fws, &w);
+  HoistPlan hplan;
+  hplan.ok = false;
+  if (hoist_mode() != 0) hoist_plan(m, &hplan);
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
     float* vout = (k & 1) ? v0 : v1;
@@ -3029,6 +3034,8 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     static const bool p_every = getenv("BHG_NEUMANN_P_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = p_every ? 0 : ((k & 1) ? 2 : (k + 1 < K ? 1 : 0));
     if (!p) { cm.x_mode = 1; cm.rzx_acc = w.rzx; cm.first = k == 0; }
+    cm.ws = &w;
+    cm.hoist = hplan.ok ? &hplan : nullptr;   // every direction product in one grouped launch (k_hoist), as in the CG solver
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   }

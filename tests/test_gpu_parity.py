@@ -539,14 +539,20 @@ def test_fused_solver_matches_unfused(algo, dims, B, K):
     """One-pass solver vs K x (bhg_mlp_hvp + recurrence kernel) on the same inputs: ragged tiles (edge path of the
     fused epilogue), L = 1 (head only), L = 2, deep nets, several 128-row batch tiles, all-interior FAST tiles;
     the flat solution vector itself is compared too, not only the M-sized hypergradient."""
+    lib = _native.load()
+    n0 = lib.bhg_mlp_hoist_launches()
     got, st_f = _run_solver(algo, dims, B, 0.05, K, sum(dims) + B, True)
+    hoisted = lib.bhg_mlp_hoist_launches() > n0     # shapes the hoisted chain takes (>= 3 layers, all widths % 32 == 0)
     want, st_u = _run_solver(algo, dims, B, 0.05, K, sum(dims) + B, False)
     rel, _ = rel_err(got, want)
     assert rel <= 5e-5, rel
     x_f, x_u = st_f[0].astype(np.float64), st_u[0].astype(np.float64)   # x (cg) / p (neumann): the solve's result
     assert np.linalg.norm(x_f - x_u) <= 5e-5 * np.linalg.norm(x_u)
-    if algo == "neumann":   # no reduction anywhere in the Neumann recurrence: identical tiles, identical roundings
-        assert np.array_equal(st_f[0], st_u[0])
+    if algo == "neumann":
+        if hoisted:   # same products, another summation tree (direction products summed on their own, added in the epilogue)
+            assert np.linalg.norm(x_f - x_u) <= 2e-6 * np.linalg.norm(x_u)
+        else:         # no reduction anywhere in the Neumann recurrence: identical tiles, identical roundings
+            assert np.array_equal(st_f[0], st_u[0])
 
 
 @pytest.mark.parametrize("dims,B,K", [([256, 384, 128, 10], 100, 5), ([70, 130, 36, 10], 100, 4), ([3072, 2048, 1536, 384, 10], 100, 20)],
@@ -795,7 +801,8 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
      ([3072, 2048, 1536, 384, 10], 100, 20)],
     ids=lambda v: str(v),
 )
-def test_hoisted_chain_matches_classic_chain(dims, B, K, monkeypatch):
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+def test_hoisted_chain_matches_classic_chain(algo, dims, B, K, monkeypatch):
     """Fused CG solver, BHG_MLP_HOIST=1 (default: every direction product h V^T / delta V in ONE grouped launch on the
     residual, G(p) = G(r) + beta G(p_old), the chain keeps the constant-weight products in the in-workgroup split-K form with
     G as addend; k_cg_beta's work inside that launch) against BHG_MLP_HOIST=0 (direction products inside the chain, lazy
@@ -806,15 +813,15 @@ def test_hoisted_chain_matches_classic_chain(dims, B, K, monkeypatch):
     for arm in ("0", "1"):
         monkeypatch.setenv("BHG_MLP_HOIST", arm)
         n0 = lib.bhg_mlp_hoist_launches()
-        out[arm] = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, True)
+        out[arm] = _run_solver(algo, dims, B, 0.05, K, sum(dims) + B, True)
         assert (lib.bhg_mlp_hoist_launches() > n0) == (arm == "1"), "the arm under test must be the one that ran"
-    unf = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, False)
-    tol = 1e-4 if K >= 20 else 5e-5
+    unf = _run_solver(algo, dims, B, 0.05, K, sum(dims) + B, False)
+    tol = 5e-6 if algo == "neumann" else (1e-4 if K >= 20 else 5e-5)
     rel, _ = rel_err(out["1"][0], out["0"][0])
     rel_u, _ = rel_err(out["1"][0], unf[0])
     print(f"hoisted vs classic chain {dims} K={K}: {rel:.2e}; hoisted vs un-fused {rel_u:.2e}")
     assert rel <= tol and rel_u <= tol, (rel, rel_u)
-    again = _run_solver("cg", dims, B, 0.05, K, sum(dims) + B, True)
+    again = _run_solver(algo, dims, B, 0.05, K, sum(dims) + B, True)
     assert all(np.array_equal(u, v) for u, v in zip(again[0], out["1"][0])), "bit-reproducible"
 
 
