@@ -3014,9 +3014,12 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   FusedWs w;
   carve_fused_ws(m, fws, &w);
+  // The hoisted chain is an A/B arm here (BHG_MLP_HOIST=2), not the default: measured on the MI355X it neither gains nor
+  // loses for Neumann (656 vs 656 steps/s at cfg 2: no step length, no lazy direction, no beta launch to save), and the
+  // classic chain keeps the fused and un-fused arms bitwise equal.
   HoistPlan hplan;
   hplan.ok = false;
-  if (hoist_mode() != 0) hoist_plan(m, &hplan);
+  if (hoist_mode() == 2) hoist_plan(m, &hplan);
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
     float* vout = (k & 1) ? v0 : v1;

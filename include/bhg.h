@@ -276,7 +276,8 @@ int64_t bhg_mlp_wsk_launches(void);
  * BHG_MLP_HOIST, default 1): every product that depends on the direction alone — h_l V_l^T and delta_l V_l, half of the
  * R-chain's matrix work — in ONE grouped split-K launch on the residual, G(p_k) = G(r_k) + beta G(p_{k-1}) by linearity of the
  * products in the lazy direction p_k = r_k + beta p_{k-1} (cg.py:53); the chain keeps the products with the constant
- * weights, in the in-workgroup split-K form with G as addend.  BHG_MLP_HOIST=0: the classic chain (A/B arm).        */
+ * weights, in the in-workgroup split-K form with G as addend.  BHG_MLP_HOIST=0: the classic chain (A/B arm); =2: the
+ * Neumann solver takes the hoisted form as well (G(v) directly — measured: no gain there, so not its default).       */
 int64_t bhg_mlp_hoist_launches(void);
 /* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
  * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
