@@ -12,7 +12,7 @@ if len(inits) < 2:
     print("need >= 2 steps in the trace"); sys.exit(0)
 lo, hi = inits[-2], inits[-1]
 seg = rows[lo:hi + 1]
-last_loop = max(i for i, r in enumerate(seg) if any(k in r["Kernel_Name"] for k in ("k_outer", "k_cg_pdir", "k_cg_resident", "k_neumann_step")))
+last_loop = max(i for i, r in enumerate(seg) if any(k in r["Kernel_Name"] for k in ("k_outer", "k_cg_alpha", "k_cg_pdir", "k_cg_resident", "k_neumann_step")))
 tail = seg[last_loop:]
 t0 = int(tail[0]["End_Timestamp"])
 busy = 0
