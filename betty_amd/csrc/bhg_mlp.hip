@@ -1771,7 +1771,7 @@ __device__ __forceinline__ void wsl_loop(const GemmPair& pr, const int m0, const
 }
 
 template <int LB, bool BF, int D, bool LDSV = false>
-__global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
+__device__ __forceinline__ void wsk_body(const WskArgs& a, const int blk) {
   // LDSV: dynamic LDS = 8 wave-private staging tiles (73.7 KB); the partial-tile exchange aliases them after the loop
   extern __shared__ __attribute__((aligned(16))) float wsl_smem[];
   __shared__ float sP_static[LDSV ? 1 : kWskWaves * 32 * kWskPad];
@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
   // XCD (the streamed weight-side operand is fetched into one L2), consecutive column tiles on different XCDs.
   int tm, tn;
   {
-    const int b = blockIdx.x;
+    const int b = blk;
     if ((a.ntn & 7) == 0) {
       const int xcd = b & 7, j = b >> 3;
       tm = j % a.ntm;
@@ -1803,7 +1803,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
   const int nct = a.K / 32;
   const int c0 = (int)(((int64_t)wq * nct) / nwp), c1 = (int)(((int64_t)(wq + 1) * nct) / nwp);
   const int kbeg_w = c0 * 32, nch_w = c1 - c0;
-  const GemmPair pr = a.pr[pi];
+  const GemmPair pr = pi ? a.pr[1] : a.pr[0];   // (a select, not an index: a locally built descriptor must not go to scratch)
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1872,9 +1872,32 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) {
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < kWskWaves; ++i) s += red[i];
-      a.partT2[blockIdx.x] = 2.0 * s;
+      a.partT2[blk] = 2.0 * s;
     }
   }
+}
+template <int LB, bool BF, int D, bool LDSV = false>
+__global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) { wsk_body<LB, BF, D, LDSV>(a, blockIdx.x); }
+
+// Several small K-contiguous x K-contiguous products in ONE launch of the LDS-staged form (projected CG: the B x B Gram
+// products T_l = h_l Rh_{l-1}^T, E_l = delta_l Rd_l^T of an iteration, or S_l = h_l h_l^T, D_l = delta_l delta_l^T once per
+// solve): blocks [blk0[i], blk0[i+1]) are the 32 x 32 tiles of problem i.
+constexpr int kWskGroupMax = 16;
+struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; };
+struct WskGroupArgs {
+  WskGroupProb p[kWskGroupMax];
+  int blk0[kWskGroupMax + 1];
+  int n;
+};
+__global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
+  WskArgs a{};
+  a.pr[0].A = g.p[i].A; a.pr[0].B = g.p[i].Bm; a.pr[0].lda = g.p[i].K; a.pr[0].ldb = g.p[i].K;
+  a.pairs = 1; a.M = g.p[i].M; a.N = g.p[i].N; a.K = g.p[i].K; a.B = g.p[i].B;
+  a.out = g.p[i].out; a.ntm = a.M / 32; a.ntn = a.N / 32;
+  wsk_body<LAYOUT_KC, false, 2, true>(a, b - g.blk0[i]);
 }
 
 // BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
@@ -1913,6 +1936,7 @@ inline bool wsk_eligible(const WskArgs& a) {
 }
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 int64_t g_hoist_launches = 0; // bhg_mlp_hoist_launches()
+int64_t g_proj_iterations = 0; // bhg_mlp_proj_iterations()
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
@@ -1946,6 +1970,16 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
     if (d == 2) BHG_WSK(false, 2); else BHG_WSK(false, 3);
   }
 #undef BHG_WSK
+}
+
+void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {
+  const int lds = (int)(sizeof(float) * kWslWaveFloats * kWskWaves);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_wsk_group, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
 
 template <int LA, int LB>
@@ -2160,8 +2194,10 @@ __global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) { beta_body(a,
 struct HoistProb {
   const float* A;      // [Bp][K] batch-sized and iteration-invariant: h_l (forward) / delta_l (backward)
   const float* Bm;     // residual slice of the W_l-shaped state: [N][K] (forward, K-contiguous) / [K][N] (backward)
-  float* slabs;        // [splits][Bp][N]
+  float* slabs;        // [splits][Bp][N]  (splits == 1: the product itself)
   int K, N, splits, rc, lda, ldb;
+  const float* A2;     // optional second operand pair with the same layouts and leading dimensions (projected CG:
+  const float* B2m;    // G(raw) = S Rd + T delta, two B x B Gram matrices times two batch-sized arrays); NULL = one pair
 };
 constexpr int kHoistMax = 14;
 struct HoistArgs {
@@ -2185,7 +2221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int t = b - ha.blk0[i];
   GemmArgs a{};
   a.pr[0].A = ha.p[i].A; a.pr[0].B = ha.p[i].Bm; a.pr[0].lda = ha.p[i].lda; a.pr[0].ldb = ha.p[i].ldb;
-  a.pairs = 1; a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
+  a.pairs = 1;
+  if (ha.p[i].A2) { a.pr[1].A = ha.p[i].A2; a.pr[1].B = ha.p[i].B2m; a.pr[1].lda = ha.p[i].lda; a.pr[1].ldb = ha.p[i].ldb; a.pairs = 2; }
+  a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
   a.out = ha.p[i].slabs; a.ldo = a.N; a.out_rows = ha.Bp; a.nt_out = 1; a.xpose_out = 1;
   const int ntn = a.N / 32, ntm = ha.Bp / kTM;
   const int bx = t % ntn, by = (t / ntn) % ntm, bz = t / (ntn * ntm);
@@ -2198,6 +2236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 struct HoistRedProb {
   const float* slabs; float* G; int N, splits;
   const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (G + bias)
+  float* G2;                                          // projected CG, first iteration: G(r_0) = G(p_0), kept separately
 };
 struct HoistRedArgs {
   HoistRedProb p[kHoistMax];
@@ -2237,6 +2276,7 @@ __global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
       v.z = fz_add(v.z, fz_mul(beta, gp.z)); v.w = fz_add(v.w, fz_mul(beta, gp.w));
     }
     *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
+    if (pr.G2) *reinterpret_cast<float4*>(pr.G2 + idx * 4) = v;
     if (pr.out) {
       float4 o;
       o.x = (v.x + bv.x) * mv.x; o.y = (v.y + bv.y) * mv.y; o.z = (v.z + bv.z) * mv.z; o.w = (v.w + bv.w) * mv.w;
@@ -2244,7 +2284,69 @@ __global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
     }
   } else {
     *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
+    if (pr.G2) *reinterpret_cast<float4*>(pr.G2 + idx * 4) = v;
     if (pr.out) *reinterpret_cast<float4*>(pr.out + idx * 4) = v;
+  }
+}
+
+// ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
+// The products G(.) are linear, and the residual itself obeys r' = r - alpha (raw + shift p) with raw = H p's weight-shaped
+// outputs — outer products of batch-sized factors:  raw(W_l) = Rd_l^T h_l + delta_l^T Rh_{l-1}.  So
+//     Gf_l(raw) = h_l raw(W_l)^T  = (h_l h_l^T) Rd_l       + (h_l Rh_{l-1}^T) delta_l   = S_l Rd_l + T_l delta_l
+//     Gb_l(raw) = delta_l raw(W_l) = (delta_l Rd_l^T) h_l  + (delta_l delta_l^T) Rh_{l-1} = E_l h_l + D_l Rh_{l-1}
+// with B x B Gram matrices (S_l, D_l once per solve; T_l, E_l per iteration: k_wsk_group) and batch-deep products
+// (k_hoist with two operand pairs, K = batch): ~0.2 GFLOP instead of the 2.75 GFLOP of k_hoist on the residual, and no pass
+// over the N-sized state at all.  The recurrences (k_proj_update, at the top of the next iteration):
+//     G(r_{k+1}) = G(r_k) - alpha_k (G(raw_k) + shift G(p_k))        G(p_{k+1}) = G(r_{k+1}) + beta_k G(p_k)
+// Only iteration 0 reads the N-sized residual (k_hoist on the initial vector).  Checked against the reference's CPU goldens
+// on the well-conditioned full-size variant like every other arm (tests/test_cfg2_goldens.py); fp32 emulation on the CPU
+// beforehand: 1e-6 from the fp64 truth, the same as the direct form and as the reference itself.
+struct ProjProb {
+  float* Gr; float* Gp; const float* Graw; int N;
+  const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (Gp + bias)   (first layer: Rh_0)
+};
+struct ProjArgs {
+  ProjProb p[kHoistMax];
+  int blk0[kHoistMax + 1];
+  int n, Bp, B, kpar_prev;
+  float shift;
+  const double* scal;
+};
+__global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < pa.n && b >= pa.blk0[i + 1]) ++i;
+  const ProjProb pr = pa.p[i];
+  const int nv = pr.N / 4;
+  const int64_t total = (int64_t)pa.Bp * nv;
+  const int64_t idx = (int64_t)(b - pa.blk0[i]) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
+  float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gp = gr;
+  if (m < pa.B) {
+    const float4 r0 = ld16(pr.Gr + idx * 4), p0 = ld16(pr.Gp + idx * 4), w0 = ld16(pr.Graw + idx * 4);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
+    const float alpha = (float)pa.scal[S_ALPHA_RING + pa.kpar_prev], beta = (float)pa.scal[S_BETA];
+    // the rounding sequence of the N-sized recurrences (fuse_elem): Hp = raw + shift p; r' = r - alpha Hp; p' = r' + beta p
+#define BHG_PROJ1(c)                                                                  \
+    {                                                                                 \
+      float hv = w0.c;                                                                \
+      if (pa.shift != 0.f) hv = fz_add(hv, fz_mul(pa.shift, p0.c));                   \
+      gr.c = fz_sub(r0.c, fz_mul(alpha, hv));                                         \
+      gp.c = fz_add(gr.c, fz_mul(beta, p0.c));                                        \
+    }
+    BHG_PROJ1(x) BHG_PROJ1(y) BHG_PROJ1(z) BHG_PROJ1(w)
+#undef BHG_PROJ1
+    *reinterpret_cast<float4*>(pr.Gr + idx * 4) = gr;
+    *reinterpret_cast<float4*>(pr.Gp + idx * 4) = gp;
+    if (pr.out) {
+      float4 o;
+      o.x = (gp.x + bv.x) * mv.x; o.y = (gp.y + bv.y) * mv.y; o.z = (gp.z + bv.z) * mv.z; o.w = (gp.w + bv.w) * mv.w;
+      *reinterpret_cast<float4*>(pr.out + idx * 4) = o;
+    }
+  } else if (pr.out) {
+    *reinterpret_cast<float4*>(pr.out + idx * 4) = gr;
   }
 }
 
@@ -2312,9 +2414,15 @@ struct HoistPlan {
   int layer[kHoistMax], bwd[kHoistMax], K[kHoistMax], N[kHoistMax], splits[kHoistMax];
   int blk0[kHoistMax + 1];
   size_t slab_off[kHoistMax], g_off[kHoistMax];   // float offsets inside the hoist region
+  size_t gr_off[kHoistMax], graw_off[kHoistMax];  // projected CG: G(r) and G(raw) of every product
+  size_t s_off[BHG_MLP_MAX_LAYERS], d_off[BHG_MLP_MAX_LAYERS], t_off[BHG_MLP_MAX_LAYERS], e_off[BHG_MLP_MAX_LAYERS];   // B x B Gram matrices
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
+inline int proj_mode() {
+  const char* e = getenv("BHG_MLP_PROJ");   // read on every call (A/B in one process); default on
+  return e ? atoi(e) : 1;
+}
 inline int hoist_mode() {
   const char* e = getenv("BHG_MLP_HOIST");   // read on every call so a test can compare both arms in one process
   return e ? atoi(e) : 1;
@@ -2357,6 +2465,16 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     blk += (hp->N[i] / 32) * ntm * sp;
     hp->slab_off[i] = off; off += (size_t)sp * Bp * hp->N[i];
     hp->g_off[i] = off;    off += (size_t)Bp * hp->N[i];
+    hp->gr_off[i] = off;   off += (size_t)Bp * hp->N[i];
+    hp->graw_off[i] = off; off += (size_t)Bp * hp->N[i];
+  }
+  for (int l = 0; l + 1 < L; ++l) {
+    hp->s_off[l] = off; off += (size_t)Bp * Bp;
+    if (l >= 1) {
+      hp->d_off[l] = off; off += (size_t)Bp * Bp;
+      hp->t_off[l] = off; off += (size_t)Bp * Bp;
+      hp->e_off[l] = off; off += (size_t)Bp * Bp;
+    }
   }
   hp->blk0[n] = blk;
   hp->floats = off;
@@ -2421,6 +2539,7 @@ struct ChainMode {
   int gemm_mode;                // FUSE_NONE: BHG_MLP_WSK-style mode asked for by the caller (bhg_mlp_hvp_mode)
   const HoistPlan* hoist;       // FUSE_CG + lazy: run the hoisted form of the chain (k_hoist); NULL = the classic chain
   const BetaArgs* beta; int beta_blocks;   // hoisted form: k_cg_beta's work rides in k_hoist's launch (iterations > 0)
+  int proj;                     // FUSE_CG, hoisted: projected CG — direction products from batch-sized recurrences (k_proj_update)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2502,15 +2621,45 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     ha.blk0[hp->n] = hp->blk0[hp->n];
     ha.n = hp->n; ha.Bp = Bp; ha.gemm_blocks = hp->blk0[hp->n];
-    ha.do_beta = (cg && !cm.first && cm.beta) ? 1 : 0;
-    if (ha.do_beta) ha.beta = *cm.beta;
-    hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
-    ++g_hoist_launches;
+    const bool proj = cg && cm.proj;
     int rblk = 0;
     for (int i = 0; i < hp->n; ++i) { ra.blk0[i] = rblk; rblk += (Bp * (hp->N[i] / 4) + 255) / 256; }
     ra.blk0[hp->n] = rblk;
-    ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cg ? cm.first : 1; ra.scal = cm.scal;
-    hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
+    if (!proj || cm.first) {   // the N-sized pass over the residual: every iteration, or (projected CG) the first one only
+      ha.do_beta = (cg && !cm.first && cm.beta && !proj) ? 1 : 0;
+      if (ha.do_beta) ha.beta = *cm.beta;
+      hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
+      ++g_hoist_launches;
+      if (proj) for (int i = 0; i < hp->n; ++i) ra.p[i].G2 = hbase + hp->gr_off[i];
+      ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cg ? cm.first : 1; ra.scal = cm.scal;
+      hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
+      if (proj) {   // the iteration-invariant Gram matrices S_l = h_l h_l^T, D_l = delta_l delta_l^T (once per solve)
+        WskGroupArgs g{};
+        int blk = 0;
+        for (int l = 0; l + 1 < L; ++l) {
+          g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B};
+          g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+          if (l >= 1) {
+            g.p[g.n] = {m->delta[l], m->delta[l], hbase + hp->d_off[l], Bp, Bp, m->dims[l + 1], B};
+            g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+          }
+        }
+        g.blk0[g.n] = blk;
+        launch_wsk_group(g, blk, st);
+      }
+    } else {                   // projected CG: G(r), G(p) from their batch-sized recurrences — nothing N-sized is read
+      ProjArgs pa{};
+      for (int i = 0; i < hp->n; ++i) {
+        ProjProb& q = pa.p[i];
+        q.Gr = hbase + hp->gr_off[i]; q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
+        if (!hp->bwd[i] && hp->layer[i] == 0) { q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0]; }
+        pa.blk0[i] = ra.blk0[i];
+      }
+      pa.blk0[hp->n] = rblk;
+      pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cm.scal;
+      hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
+      ++g_proj_iterations;
+    }
     static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
     // forward chain: Rh_l = mask_l * (Rh_{l-1} W_l^T + Gf_l + c_l)
     for (int l = 1; l + 1 < L; ++l) {
@@ -2754,6 +2903,39 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       BHG_HIP_CHECK(hipGetLastError());
       return BHG_OK;
     }
+    if (hp && cg && cm.proj && !cm.apply_out) {   // projected CG: G(raw) of this iteration for the next one's recurrences
+      float* hbase = cm.ws->hoist;
+      WskGroupArgs g{};
+      int blk = 0;
+      for (int l = 1; l + 1 < L; ++l) {
+        g.p[g.n] = {m->h[l], m->Rh[l - 1], hbase + hp->t_off[l], Bp, Bp, m->dims[l], B};        // T_l = h_l Rh_{l-1}^T
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->e_off[l], Bp, Bp, m->dims[l + 1], B};    // E_l = delta_l Rd_l^T
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+      }
+      g.blk0[g.n] = blk;
+      if (g.n > 0) launch_wsk_group(g, blk, st);
+      HoistArgs ga{};
+      int gblk = 0;
+      const int ntm = Bp / kTM;
+      for (int i = 0; i < hp->n; ++i) {
+        const int l = hp->layer[i];
+        HoistProb& q = ga.p[i];
+        if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
+          q.A = hbase + hp->s_off[l]; q.Bm = m->Rd[l];
+          if (l >= 1) { q.A2 = hbase + hp->t_off[l]; q.B2m = m->delta[l]; }
+        } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
+          q.A = hbase + hp->e_off[l]; q.Bm = m->h[l];
+          q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
+        }
+        q.slabs = hbase + hp->graw_off[i];
+        q.K = Bp; q.N = hp->N[i]; q.splits = 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
+        ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm;
+      }
+      ga.blk0[hp->n] = gblk;
+      ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
+      hipLaunchKernelGGL(k_hoist, dim3(gblk), dim3(256), 0, st, ga);
+    }
     // one launch for all outputs when every MFMA layer is all-interior
     const int n_mfma = head ? L - 1 : L;
     OuterAllArgs oa{};
@@ -2878,6 +3060,7 @@ int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out,
 // ---- fused solvers: K iterations of HVP + recurrence without an N-sized H*direction vector ---------------------------
 int64_t bhg_mlp_wsk_launches(void) { return bhg::g_wsk_launches; }
 int64_t bhg_mlp_hoist_launches(void) { return bhg::g_hoist_launches; }
+int64_t bhg_mlp_proj_iterations(void) { return bhg::g_proj_iterations; }
 
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff, float alpha,
                                 int K, void* fws, size_t fws_bytes, void* stream) {
@@ -2956,6 +3139,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   hplan.ok = false;
   if (lazy && hoist_mode() != 0) hoist_plan(m, &hplan);
   const bool hoist = lazy && hplan.ok;
+  const bool proj = hoist && proj_mode() != 0;
   for (int k = 0; k < K; ++k) {
     hipEvent_t ta, tb, tc, td;
     const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
@@ -2963,7 +3147,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
     if (lazy && k > 0) {   // beta, p.p of the coming direction, direction update of the small slices
       ba.part = w.partRR[k & 1];
-      if (!hoist) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);   // (hoisted form: inside k_hoist)
+      if (!hoist || proj) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);   // (hoisted, not projected: inside k_hoist)
     }
     if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     ChainMode cm{};
@@ -2990,6 +3174,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.kpar = k & 1;
     cm.hoist = hoist ? &hplan : nullptr;
     cm.beta = &ba; cm.beta_blocks = bgrid;
+    cm.proj = proj ? 1 : 0;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
     if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

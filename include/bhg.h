@@ -279,6 +279,11 @@ int64_t bhg_mlp_wsk_launches(void);
  * weights, in the in-workgroup split-K form with G as addend.  BHG_MLP_HOIST=0: the classic chain (A/B arm); =2: the
  * Neumann solver takes the hoisted form as well (G(v) directly — measured: no gain there, so not its default).       */
 int64_t bhg_mlp_hoist_launches(void);
+/* Test / measurement hook: iterations of bhg_mlp_cg_solve that formed their direction products by PROJECTION (env
+ * BHG_MLP_PROJ, default 1; needs the hoisted form): G(r_{k+1}) = G(r_k) - alpha_k (G(raw_k) + shift G(p_k)) with
+ * G(raw_k) from B x B Gram matrices times batch-sized arrays (raw_k = the weight-shaped outputs of H p_k are outer products of
+ * batch-sized factors), G(p_{k+1}) = G(r_{k+1}) + beta_k G(p_k) — no N-sized operand is read after the first iteration. */
+int64_t bhg_mlp_proj_iterations(void);
 /* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
  * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
  * in direction v_K (`v_last`: the 2L slices of the direction buffer that holds v_K — v0 for even K, v1 for odd K) into the

@@ -77,7 +77,9 @@ def _arms(algo):
         # the classic chain (direction products inside the chain, lazy direction mixed in the GEMM loaders) next to the default
         # hoisted form (k_hoist: G(p) = G(r) + beta G(p_old))
         arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
-                 ("fused-classic-wsk0", dict(hvp="hip", fused=True, wsk="0", hoist="0"))]
+                 ("fused-classic-wsk0", dict(hvp="hip", fused=True, wsk="0", hoist="0")),
+                 # hoisted, every iteration on the N-sized residual (the default projects: G(r) by batch-sized recurrences)
+                 ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, proj="0"))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
@@ -100,6 +102,10 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
         monkeypatch.delenv("BHG_MLP_HOIST", raising=False)
     else:
         monkeypatch.setenv("BHG_MLP_HOIST", arm["hoist"])
+    if arm.get("proj") is None:
+        monkeypatch.delenv("BHG_MLP_PROJ", raising=False)
+    else:
+        monkeypatch.setenv("BHG_MLP_PROJ", arm["proj"])
     saved = be.cg_variant
     be.cg_variant = {"stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}.get(arm.get("variant"), _native.BHG_CG_AUTO)
     try:

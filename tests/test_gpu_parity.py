@@ -804,32 +804,43 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
     ids=lambda v: str(v),
 )
 @pytest.mark.parametrize("algo", ["cg", "neumann"])
-def test_hoisted_chain_matches_classic_chain(algo, dims, B, K, monkeypatch):
-    """Fused CG solver, BHG_MLP_HOIST=1 (default: every direction product h V^T / delta V in ONE grouped launch on the
-    residual, G(p) = G(r) + beta G(p_old), the chain keeps the constant-weight products in the in-workgroup split-K form with
-    G as addend; k_cg_beta's work inside that launch) against BHG_MLP_HOIST=0 (direction products inside the chain, lazy
-    direction mixed in the loaders) and against the un-fused loop: same hypergradient, same CG scalars, bit-reproducible,
-    with and without a solution vector."""
+def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, monkeypatch):
+    """Fused solvers, three forms of the R-chain on the same inputs:
+      classic    BHG_MLP_HOIST=0: direction products inside the chain, lazy direction mixed in the GEMM loaders;
+      hoisted    BHG_MLP_HOIST=1 BHG_MLP_PROJ=0: every direction product h V^T / delta V in ONE grouped launch on the
+                 residual (k_hoist), G(p) = G(r) + beta G(p_old), the chain keeps the constant-weight products in the
+                 in-workgroup split-K form with G as addend, k_cg_beta's work inside that launch;
+      projected  the CG default: after the first iteration G(r) itself comes from batch-sized recurrences through B x B Gram
+                 matrices (k_wsk_group, k_hoist with two operand pairs, k_proj_update) — nothing N-sized is read.
+    Against each other and against the un-fused loop: same hypergradient; bit-reproducible; launch counters prove which arm
+    ran.  (Neumann takes the hoisted form only when asked, BHG_MLP_HOIST=2, and has no projected form.)"""
     lib = _native.load()
-    out = {}
     # ridge 0.5 at the full size: with 0.05 the Hessian of this random instance is indefinite and twenty CG iterations turn
     # ANY difference in summation order into an O(1) difference (measured: 1.97 between two correct arms)
     ridge = 0.5 if dims[0] >= 3072 else 0.05
-    on = "1" if algo == "cg" else "2"   # the Neumann solver takes the hoisted form only when asked (no gain there)
-    for arm in ("0", on):
-        monkeypatch.setenv("BHG_MLP_HOIST", arm)
-        n0 = lib.bhg_mlp_hoist_launches()
-        out[arm] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True)
-        assert (lib.bhg_mlp_hoist_launches() > n0) == (arm == on), "the arm under test must be the one that ran"
-    out["1"] = out[on]
+    arms = {"classic": {"BHG_MLP_HOIST": "0"}, "hoisted": {"BHG_MLP_HOIST": "1" if algo == "cg" else "2", "BHG_MLP_PROJ": "0"}}
+    if algo == "cg":
+        arms["projected"] = {"BHG_MLP_HOIST": "1", "BHG_MLP_PROJ": "1"}
+    out = {}
+    for name, env in arms.items():
+        for k in ("BHG_MLP_HOIST", "BHG_MLP_PROJ"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h0, p0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations()
+        out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True)
+        dh, dp = lib.bhg_mlp_hoist_launches() - h0, lib.bhg_mlp_proj_iterations() - p0
+        want = {"classic": (0, 0), "hoisted": (K, 0), "projected": (1, K - 1)}[name]
+        assert (dh, dp) == want, (name, dh, dp, want)
+        again = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True)
+        assert all(np.array_equal(u, v) for u, v in zip(again[0], out[name][0])), f"{name}: bit-reproducible"
     unf = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, False)
     tol = 5e-6 if algo == "neumann" else (1e-4 if K >= 20 else 5e-5)
-    rel, _ = rel_err(out["1"][0], out["0"][0])
-    rel_u, _ = rel_err(out["1"][0], unf[0])
-    print(f"hoisted vs classic chain {dims} K={K}: {rel:.2e}; hoisted vs un-fused {rel_u:.2e}")
-    assert rel <= tol and rel_u <= tol, (rel, rel_u)
-    again = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True)
-    assert all(np.array_equal(u, v) for u, v in zip(again[0], out["1"][0])), "bit-reproducible"
+    for name in arms:
+        rel_c, _ = rel_err(out[name][0], out["classic"][0])
+        rel_u, _ = rel_err(out[name][0], unf[0])
+        print(f"{algo} {dims} K={K} {name:9s}: vs classic chain {rel_c:.2e}, vs un-fused {rel_u:.2e}")
+        assert rel_c <= tol and rel_u <= tol, (name, rel_c, rel_u)
 
 
 def test_wsk_defaults_per_solver(monkeypatch):
