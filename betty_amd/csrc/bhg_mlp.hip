@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) { wsk_bo
 // Several small K-contiguous x K-contiguous products in ONE launch of the LDS-staged form (projected CG: the B x B Gram
 // products T_l = h_l Rh_{l-1}^T, E_l = delta_l Rd_l^T of an iteration, or S_l = h_l h_l^T, D_l = delta_l delta_l^T once per
 // solve): blocks [blk0[i], blk0[i+1]) are the 32 x 32 tiles of problem i.
-constexpr int kWskGroupMax = 16;
+constexpr int kWskGroupMax = 32;
 struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; };
 struct WskGroupArgs {
   WskGroupProb p[kWskGroupMax];
@@ -2200,20 +2200,52 @@ struct HoistProb {
   const float* B2m;    // G(raw) = S Rd + T delta, two B x B Gram matrices times two batch-sized arrays); NULL = one pair
 };
 constexpr int kHoistMax = 14;
+// Fully projected CG: partials of  r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>  and  p.raw (the same with G(p)) over the
+// MFMA layers' weight slices — the inner products of the N-sized residual / direction with the N-sized outer products, from
+// batch-sized arrays (see k_proj_scalars).  One float4 per thread, one (r.raw, p.raw) pair of fp64 partials per block.
+struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; };
 struct HoistArgs {
   HoistProb p[kHoistMax];
   int blk0[kHoistMax + 1];
   int n, Bp, gemm_blocks, do_beta;
   BetaArgs beta;
+  int beta_blocks;               // blocks [gemm_blocks, gemm_blocks + beta_blocks): k_cg_beta's work (do_beta)
+  int dot_blocks, nd, B;         // then dot_blocks blocks of the projected inner products (fully projected CG)
+  ProjDotProb dp[kHoistMax];
+  int dblk0[kHoistMax + 1];
+  double* part_dot;              // [2][dot_blocks]
 };
+
 static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
 constexpr int kHoistLds = GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS > GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS
                               ? GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS : GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hoist(HoistArgs ha) {
   __shared__ __attribute__((aligned(16))) float smem[kHoistLds];
   const int b = blockIdx.x;
-  if (b >= ha.gemm_blocks) {   // the scalar work between two iterations rides behind the tiles (cg.py:51-53, see k_cg_beta)
-    if (ha.do_beta) beta_body(ha.beta, b - ha.gemm_blocks);
+  if (b >= ha.gemm_blocks) {
+    const int e = b - ha.gemm_blocks;
+    if (e < ha.beta_blocks) {   // the scalar work between two iterations rides behind the tiles (cg.py:51-53, see k_cg_beta)
+      if (ha.do_beta) beta_body(ha.beta, e);
+      return;
+    }
+    // projected inner products: block d of product i
+    const int d = e - ha.beta_blocks;
+    int i = 0;
+    while (i + 1 < ha.nd && d >= ha.dblk0[i + 1]) ++i;
+    const ProjDotProb q = ha.dp[i];
+    const int nv = q.N / 4;
+    const int64_t idx = (int64_t)(d - ha.dblk0[i]) * 256 + threadIdx.x;
+    double ar = 0.0, ap = 0.0;
+    if (idx < (int64_t)ha.Bp * nv && (int)(idx / nv) < ha.B) {
+      const float4 xv = ld16(q.X + idx * 4), gr = ld16(q.Gr + idx * 4), gp = ld16(q.Gp + idx * 4);
+      ar = (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
+      ap = (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
+    }
+    double* red = reinterpret_cast<double*>(smem);
+    const double sr = block_sum(ar, red);
+    __syncthreads();
+    const double sp = block_sum(ap, red);
+    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; }
     return;
   }
   int i = 0;
@@ -2289,6 +2321,92 @@ __global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
   }
 }
 
+// ---- fully projected CG: the scalars of an iteration without an N-sized residual ------------------------------------------
+// With G(r), G(p) projected, the solve needs the N-sized residual and direction for ONE thing only: the dots r'.r' (-> beta,
+// next alpha) and p.p (-> the shift's share of p.Hp).  They follow from the recurrences as well — on the MFMA layers' slices
+//     r'.r' = r.r - 2 a r.Hp + a^2 Hp.Hp,   Hp = raw + shift p
+//     r.Hp  = r.raw + shift r.p          p.Hp = p.raw + shift p.p          Hp.Hp = raw.raw + 2 shift p.raw + shift^2 p.p
+//     r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>     (p.raw alike: the dot blocks of k_hoist)
+//     raw.raw = sum_l <Rd_l Rd_l^T, S_l> + 2 <E_l^T, T_l> + <D_l, Rh_{l-1} Rh_{l-1}^T>     (B x B Gram matrices, k_wsk_group)
+//     r'.p = r.p - a p.Hp ;  next:  r.p <- r'.r' + b r'.p ,  p.p <- r'.r' + 2 b r'.p + b^2 p.p
+// in fp64, while the small slices (biases, head weight) stay explicit: their epilogues (k_outer_all's head / bias blocks) emit
+// their share of r'.r', r'.p, p.p as before.  So after iteration 0 NO kernel reads or writes an N-sized state vector: what
+// is left of an iteration is the R-chain through the constant weights and batch-sized work.  (CPU emulation in fp32 against
+// the reference's fp64 run at full size: 1e-7 ... 2e-6 on the well-conditioned variant, r.r falling smoothly through
+// twenty orders of magnitude; GPU: tests/test_cfg2_goldens.py.)  One workgroup.
+struct ProjScalArgs {
+  const float* S[BHG_MLP_MAX_LAYERS]; const float* Q[BHG_MLP_MAX_LAYERS];                                   // l = 0 .. L-2
+  const float* D[BHG_MLP_MAX_LAYERS]; const float* P[BHG_MLP_MAX_LAYERS]; const float* E[BHG_MLP_MAX_LAYERS]; const float* T[BHG_MLP_MAX_LAYERS];  // l = 1 .. L-2
+  int nl, Bp, B;
+  const double* part_dot; int dot_blocks;
+  const double* part; int part_stride; int off0, n0, off1, n1;   // the small slices' epilogue partials [3][stride]
+  const float* p_small; int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;   // first iteration: r_small = p_small
+  double* scal; double* pscal;   // pscal: {rr_big, rp_big, pp_big}
+  float shift; int first;
+};
+__global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
+  __shared__ double red[kWaves];
+  const int t = threadIdx.x;
+  // raw.raw over the MFMA layers from the Gram matrices (elements with b, b' < B; the rest is zero)
+  double acc = 0.0;
+  const int nb = a.Bp * a.Bp;
+  for (int l = 0; l < a.nl; ++l) {
+    const float* S = a.S[l]; const float* Q = a.Q[l];
+    for (int i = t; i < nb; i += kThreads) acc += (double)S[i] * (double)Q[i];
+    if (l >= 1) {
+      const float* D = a.D[l]; const float* P = a.P[l]; const float* E = a.E[l]; const float* T = a.T[l];
+      for (int i = t; i < nb; i += kThreads) {
+        const int r = i / a.Bp, c = i - r * a.Bp;
+        acc += (double)D[i] * (double)P[i] + 2.0 * (double)E[c * a.Bp + r] * (double)T[i];
+      }
+    }
+  }
+  const double raw_raw = block_sum(acc, red);
+  __syncthreads();
+  double ar = 0.0, ap = 0.0;
+  for (int i = t; i < a.dot_blocks; i += kThreads) { ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; }
+  const double r_raw = block_sum(ar, red);
+  __syncthreads();
+  const double p_raw = block_sum(ap, red);
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = t; i < a.n0 + a.n1; i += kThreads) {
+    const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
+    s0 += a.part[j]; s1 += a.part[a.part_stride + j]; s2 += a.part[2 * (int64_t)a.part_stride + j];
+  }
+  const double rr_s = block_sum(s0, red);
+  __syncthreads();
+  const double rp_s = block_sum(s1, red);
+  __syncthreads();
+  const double pp_s = block_sum(s2, red);
+  __syncthreads();
+  double sq = 0.0;
+  if (a.first) {   // r_small(0) = p_small (bhg_cg_init; the small slices' direction is not touched by their epilogues)
+    for (int tt = 0; tt < a.snt; ++tt)
+      for (int i = t; i < a.slen[tt]; i += kThreads) { const double v = (double)a.p_small[a.soff[tt] + i]; sq += v * v; }
+  }
+  const double rr_small0 = block_sum(sq, red);
+  if (t == 0) {
+    const double rr_old = a.scal[S_RR_OLD];          // r.r of this iteration (k_cg_alpha)
+    const double al = a.scal[S_ALPHA], sh = (double)a.shift;
+    double rr_b, rp_b, pp_b;
+    if (a.first) rr_b = rp_b = pp_b = rr_old - rr_small0;
+    else { rr_b = a.pscal[0]; rp_b = a.pscal[1]; pp_b = a.pscal[2]; }
+    const double rHp = r_raw + sh * rp_b, pHp = p_raw + sh * pp_b, HpHp = raw_raw + 2.0 * sh * p_raw + sh * sh * pp_b;
+    const double rr_b1 = rr_b - 2.0 * al * rHp + al * al * HpHp;
+    const double rp_b1 = rp_b - al * pHp;              // r'.p over the MFMA layers
+    const double rr1 = rr_b1 + rr_s, rp1 = rp_b1 + rp_s, pp = pp_b + pp_s;
+    const float beta = (float)rr1 / (float)rr_old;     // fp32 division of the fp32-rounded dots, as the reference (cg.py:51-52)
+    const double b = (double)beta;
+    a.scal[S_RR_NEW] = rr1;
+    a.scal[S_BETA] = b;
+    a.scal[S_PP] = rr1 + 2.0 * b * rp1 + b * b * pp;
+    a.pscal[0] = rr_b1;
+    a.pscal[1] = rr_b1 + b * rp_b1;
+    a.pscal[2] = rr_b1 + 2.0 * b * rp_b1 + b * b * pp_b;
+  }
+}
+
 // ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
 // The products G(.) are linear, and the residual itself obeys r' = r - alpha (raw + shift p) with raw = H p's weight-shaped
 // outputs — outer products of batch-sized factors:  raw(W_l) = Rd_l^T h_l + delta_l^T Rh_{l-1}.  So
@@ -2311,9 +2429,24 @@ struct ProjArgs {
   int n, Bp, B, kpar_prev;
   float shift;
   const double* scal;
+  // fully projected CG: the direction update of the SMALL slices (biases, head weight: p = r + beta p, cg.py:53) rides in
+  // blocks [blk0[n], blk0[n] + small_blocks) — nothing else touches them between two iterations (no k_cg_beta launch)
+  int small_blocks; const float* sr; float* sp;
+  int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
 };
 __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
   const int b = blockIdx.x;
+  if (b >= pa.blk0[pa.n]) {   // small slices
+    const int gi = (b - pa.blk0[pa.n]) * 256 + threadIdx.x;
+    int64_t eoff = -1;
+    int base = 0;
+    for (int t = 0; t < pa.snt; ++t) {
+      if (eoff < 0 && gi < base + pa.slen[t]) eoff = pa.soff[t] + (gi - base);
+      base += pa.slen[t];
+    }
+    if (eoff >= 0) pa.sp[eoff] = fz_add(pa.sr[eoff], fz_mul((float)pa.scal[S_BETA], pa.sp[eoff]));
+    return;
+  }
   int i = 0;
   while (i + 1 < pa.n && b >= pa.blk0[i + 1]) ++i;
   const ProjProb pr = pa.p[i];
@@ -2416,6 +2549,8 @@ struct HoistPlan {
   size_t slab_off[kHoistMax], g_off[kHoistMax];   // float offsets inside the hoist region
   size_t gr_off[kHoistMax], graw_off[kHoistMax];  // projected CG: G(r) and G(raw) of every product
   size_t s_off[BHG_MLP_MAX_LAYERS], d_off[BHG_MLP_MAX_LAYERS], t_off[BHG_MLP_MAX_LAYERS], e_off[BHG_MLP_MAX_LAYERS];   // B x B Gram matrices
+  size_t q_off[BHG_MLP_MAX_LAYERS], p_off[BHG_MLP_MAX_LAYERS];   // fully projected CG: Rd_l Rd_l^T, Rh_{l-1} Rh_{l-1}^T
+  int dot_blocks;
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
@@ -2468,9 +2603,13 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->gr_off[i] = off;   off += (size_t)Bp * hp->N[i];
     hp->graw_off[i] = off; off += (size_t)Bp * hp->N[i];
   }
+  hp->dot_blocks = 0;
+  for (int i = 0; i < n; ++i) hp->dot_blocks += (Bp * (hp->N[i] / 4) + 255) / 256;
   for (int l = 0; l + 1 < L; ++l) {
     hp->s_off[l] = off; off += (size_t)Bp * Bp;
+    hp->q_off[l] = off; off += (size_t)Bp * Bp;
     if (l >= 1) {
+      hp->p_off[l] = off; off += (size_t)Bp * Bp;
       hp->d_off[l] = off; off += (size_t)Bp * Bp;
       hp->t_off[l] = off; off += (size_t)Bp * Bp;
       hp->e_off[l] = off; off += (size_t)Bp * Bp;
@@ -2488,6 +2627,7 @@ struct FusedWs {
   int t2_off[BHG_MLP_MAX_LAYERS];   // first T2 partial of the R-backward reduce INTO layer l-1 (l = 1 .. L-2)
   int nRR, nT2;
   float* hoist;                     // slabs + G arrays of the hoisted direction products (HoistPlan offsets)
+  double* part_dot; double* pscal;  // fully projected CG: [2][dot_blocks] partials of r.raw / p.raw; {rr, rp, pp} over the MFMA layers
   size_t bytes;
 };
 void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
@@ -2512,6 +2652,8 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   HoistPlan hp;
   hoist_plan(m, &hp);
   w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
+  w->part_dot = static_cast<double*>(take(sizeof(double) * 2 * (hp.ok ? hp.dot_blocks : 1)));
+  w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   w->bytes = off;
 }
 
@@ -2627,6 +2769,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     ra.blk0[hp->n] = rblk;
     if (!proj || cm.first) {   // the N-sized pass over the residual: every iteration, or (projected CG) the first one only
       ha.do_beta = (cg && !cm.first && cm.beta && !proj) ? 1 : 0;
+      ha.beta_blocks = ha.do_beta ? cm.beta_blocks : 0;
       if (ha.do_beta) ha.beta = *cm.beta;
       hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
       ++g_hoist_launches;
@@ -2657,7 +2800,13 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       pa.blk0[hp->n] = rblk;
       pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cm.scal;
-      hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
+      if (cm.proj >= 2 && cm.beta) {   // fully projected: the small slices' direction update rides here (no k_cg_beta launch)
+        pa.sr = cm.beta->r; pa.sp = cm.beta->p; pa.snt = cm.beta->nt;
+        int tot = 0;
+        for (int t = 0; t < cm.beta->nt; ++t) { pa.soff[t] = cm.beta->off[t]; pa.slen[t] = cm.beta->len[t]; tot += cm.beta->len[t]; }
+        pa.small_blocks = (tot + 255) / 256;
+      }
+      hipLaunchKernelGGL(k_proj_update, dim3(rblk + pa.small_blocks), dim3(256), 0, st, pa);
       ++g_proj_iterations;
     }
     static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
@@ -2913,6 +3062,15 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->e_off[l], Bp, Bp, m->dims[l + 1], B};    // E_l = delta_l Rd_l^T
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
       }
+      const bool full = cm.proj >= 2;   // fully projected: also Rd_l Rd_l^T and Rh_{l-1} Rh_{l-1}^T (-> raw.raw, k_proj_scalars)
+      for (int l = 0; full && l + 1 < L; ++l) {
+        g.p[g.n] = {m->Rd[l], m->Rd[l], hbase + hp->q_off[l], Bp, Bp, m->dims[l + 1], B};
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        if (l >= 1) {
+          g.p[g.n] = {m->Rh[l - 1], m->Rh[l - 1], hbase + hp->p_off[l], Bp, Bp, m->dims[l], B};
+          g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        }
+      }
       g.blk0[g.n] = blk;
       if (g.n > 0) launch_wsk_group(g, blk, st);
       HoistArgs ga{};
@@ -2934,10 +3092,22 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       ga.blk0[hp->n] = gblk;
       ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
-      hipLaunchKernelGGL(k_hoist, dim3(gblk), dim3(256), 0, st, ga);
+      if (full) {   // the projected inner products r.raw, p.raw ride behind the tiles
+        int dblk = 0;
+        for (int i = 0; i < hp->n; ++i) {
+          const int l = hp->layer[i];
+          ga.dp[i] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i]};
+          ga.dblk0[i] = dblk; dblk += (Bp * (hp->N[i] / 4) + 255) / 256;
+        }
+        ga.dblk0[hp->n] = dblk;
+        ga.nd = hp->n; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
+      }
+      hipLaunchKernelGGL(k_hoist, dim3(gblk + ga.dot_blocks), dim3(256), 0, st, ga);
     }
     // one launch for all outputs when every MFMA layer is all-interior
-    const int n_mfma = head ? L - 1 : L;
+    // (fully projected CG: the MFMA layers' slices of r and p are not materialised — only the small slices' blocks launch)
+    const bool proj_full = hp && cg && cm.proj >= 2;
+    const int n_mfma = proj_full ? 0 : (head ? L - 1 : L);
     OuterAllArgs oa{};
     bool all_fast = !no_outer_all && n_mfma <= kOuterAllMax && head;
     size_t lds_max = 0;
@@ -2985,6 +3155,23 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     } else {
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
+    }
+    if (proj_full) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
+      BHG_REQUIRE(all_fast, "the fully projected CG solver needs the single-launch output path");
+      float* hbase = cm.ws->hoist;
+      ProjScalArgs sa{};
+      sa.nl = L - 1; sa.Bp = Bp; sa.B = B;
+      for (int l = 0; l + 1 < L; ++l) {
+        sa.S[l] = hbase + hp->s_off[l]; sa.Q[l] = hbase + hp->q_off[l];
+        if (l >= 1) { sa.D[l] = hbase + hp->d_off[l]; sa.P[l] = hbase + hp->p_off[l]; sa.E[l] = hbase + hp->e_off[l]; sa.T[l] = hbase + hp->t_off[l]; }
+      }
+      sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
+      sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
+      sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;
+      sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
+      for (int t = 0; t < cm.beta->nt; ++t) { sa.soff[t] = cm.beta->off[t]; sa.slen[t] = cm.beta->len[t]; }
+      sa.scal = cm.scal; sa.pscal = cm.ws->pscal; sa.shift = cm.shift; sa.first = cm.first;
+      hipLaunchKernelGGL(k_proj_scalars, dim3(1), dim3(kThreads), 0, st, sa);
     }
     BHG_HIP_CHECK(hipGetLastError());
     return BHG_OK;
@@ -3139,7 +3326,10 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   hplan.ok = false;
   if (lazy && hoist_mode() != 0) hoist_plan(m, &hplan);
   const bool hoist = lazy && hplan.ok;
-  const bool proj = hoist && proj_mode() != 0;
+  // projection level: 1 = G(r) by recurrence, the N-sized r / p still updated by k_outer_all (needed when the caller wants x);
+  // 2 = fully projected (default without a solution vector): no N-sized state after the first iteration
+  // (BHG_MLP_PROJ: 0 off | 1 default | 9 level 1 even without a solution vector — the A/B arm of level 2)
+  const int proj_level = (!hoist || proj_mode() == 0) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
   for (int k = 0; k < K; ++k) {
     hipEvent_t ta, tb, tc, td;
     const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
@@ -3147,7 +3337,8 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
     if (lazy && k > 0) {   // beta, p.p of the coming direction, direction update of the small slices
       ba.part = w.partRR[k & 1];
-      if (!hoist || proj) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);   // (hoisted, not projected: inside k_hoist)
+      // hoisted, not projected: inside k_hoist; fully projected: k_proj_scalars (end of the last iteration) + k_proj_update
+      if (!hoist || proj_level == 1) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);
     }
     if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
     ChainMode cm{};
@@ -3174,7 +3365,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
     cm.kpar = k & 1;
     cm.hoist = hoist ? &hplan : nullptr;
     cm.beta = &ba; cm.beta_blocks = bgrid;
-    cm.proj = proj ? 1 : 0;
+    cm.proj = proj_level;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
     if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

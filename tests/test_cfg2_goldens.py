@@ -79,7 +79,9 @@ def _arms(algo):
         arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
                  ("fused-classic-wsk0", dict(hvp="hip", fused=True, wsk="0", hoist="0")),
                  # hoisted, every iteration on the N-sized residual (the default projects: G(r) by batch-sized recurrences)
-                 ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, proj="0"))]
+                 ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, proj="0")),
+                 # G(r) projected, r / p still N-sized (the default projects everything: "fused-default")
+                 ("fused-proj-level1", dict(hvp="hip", fused=True, wsk=None, proj="9"))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
