@@ -2203,7 +2203,9 @@ constexpr int kHoistMax = 14;
 // Fully projected CG: partials of  r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>  and  p.raw (the same with G(p)) over the
 // MFMA layers' weight slices — the inner products of the N-sized residual / direction with the N-sized outer products, from
 // batch-sized arrays (see k_proj_scalars).  One float4 per thread, one (r.raw, p.raw) pair of fp64 partials per block.
-struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; };
+// A Gram problem (w != 0) contributes w * <X or X^T, Gr> to raw.raw instead: <S_l, Rd_l Rd_l^T>, <D_l, Rh Rh^T>, 2 <E_l^T, T_l>.
+struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; float w; int xT; };
+constexpr int kProjDotMax = kHoistMax + 3 * (kHoistMax / 2);   // products + three Gram dots per MFMA layer
 struct HoistArgs {
   HoistProb p[kHoistMax];
   int blk0[kHoistMax + 1];
@@ -2211,9 +2213,9 @@ struct HoistArgs {
   BetaArgs beta;
   int beta_blocks;               // blocks [gemm_blocks, gemm_blocks + beta_blocks): k_cg_beta's work (do_beta)
   int dot_blocks, nd, B;         // then dot_blocks blocks of the projected inner products (fully projected CG)
-  ProjDotProb dp[kHoistMax];
-  int dblk0[kHoistMax + 1];
-  double* part_dot;              // [2][dot_blocks]
+  ProjDotProb dp[kProjDotMax];
+  int dblk0[kProjDotMax + 1];
+  double* part_dot;              // [3][dot_blocks]: r.raw, p.raw, raw.raw
 };
 
 static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
@@ -2235,17 +2237,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const ProjDotProb q = ha.dp[i];
     const int nv = q.N / 4;
     const int64_t idx = (int64_t)(d - ha.dblk0[i]) * 256 + threadIdx.x;
-    double ar = 0.0, ap = 0.0;
+    double ar = 0.0, ap = 0.0, ag = 0.0;
     if (idx < (int64_t)ha.Bp * nv && (int)(idx / nv) < ha.B) {
-      const float4 xv = ld16(q.X + idx * 4), gr = ld16(q.Gr + idx * 4), gp = ld16(q.Gp + idx * 4);
-      ar = (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
-      ap = (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
+      const float4 gr = ld16(q.Gr + idx * 4);
+      if (q.w != 0.f) {   // Gram problem (N = Bp): elementwise product of two B x B matrices, the first possibly transposed
+        float4 xv;
+        if (q.xT) {
+          const int mrow = (int)(idx / nv), n = (int)(idx - (int64_t)mrow * nv) * 4;
+          xv = make_float4(q.X[(int64_t)n * q.N + mrow], q.X[(int64_t)(n + 1) * q.N + mrow], q.X[(int64_t)(n + 2) * q.N + mrow],
+                           q.X[(int64_t)(n + 3) * q.N + mrow]);
+        } else xv = ld16(q.X + idx * 4);
+        ag = (double)q.w * ((double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w);
+      } else {
+        const float4 xv = ld16(q.X + idx * 4), gp = ld16(q.Gp + idx * 4);
+        ar = (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
+        ap = (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
+      }
     }
     double* red = reinterpret_cast<double*>(smem);
     const double sr = block_sum(ar, red);
-    __syncthreads();
     const double sp = block_sum(ap, red);
-    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; }
+    const double sg = block_sum(ag, red);
+    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; ha.part_dot[2 * (int64_t)ha.dot_blocks + d] = sg; }
     return;
   }
   int i = 0;
@@ -2335,51 +2348,32 @@ __global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
 // the reference's fp64 run at full size: 1e-7 ... 2e-6 on the well-conditioned variant, r.r falling smoothly through
 // twenty orders of magnitude; GPU: tests/test_cfg2_goldens.py.)  One workgroup.
 struct ProjScalArgs {
-  const float* S[BHG_MLP_MAX_LAYERS]; const float* Q[BHG_MLP_MAX_LAYERS];                                   // l = 0 .. L-2
-  const float* D[BHG_MLP_MAX_LAYERS]; const float* P[BHG_MLP_MAX_LAYERS]; const float* E[BHG_MLP_MAX_LAYERS]; const float* T[BHG_MLP_MAX_LAYERS];  // l = 1 .. L-2
-  int nl, Bp, B;
-  const double* part_dot; int dot_blocks;
+  const double* part_dot; int dot_blocks;                        // [3][dot_blocks]: r.raw, p.raw, raw.raw (k_hoist's dot blocks)
   const double* part; int part_stride; int off0, n0, off1, n1;   // the small slices' epilogue partials [3][stride]
-  const float* p_small; int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;   // first iteration: r_small = p_small
+  const float* r_small; float* p_small;                          // flat r / p (small slices only)
+  int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
   double* scal; double* pscal;   // pscal: {rr_big, rp_big, pp_big}
   float shift; int first;
 };
 __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
   __shared__ double red[kWaves];
+  __shared__ float s_beta;
   const int t = threadIdx.x;
-  // raw.raw over the MFMA layers from the Gram matrices (elements with b, b' < B; the rest is zero)
-  double acc = 0.0;
-  const int nb = a.Bp * a.Bp;
-  for (int l = 0; l < a.nl; ++l) {
-    const float* S = a.S[l]; const float* Q = a.Q[l];
-    for (int i = t; i < nb; i += kThreads) acc += (double)S[i] * (double)Q[i];
-    if (l >= 1) {
-      const float* D = a.D[l]; const float* P = a.P[l]; const float* E = a.E[l]; const float* T = a.T[l];
-      for (int i = t; i < nb; i += kThreads) {
-        const int r = i / a.Bp, c = i - r * a.Bp;
-        acc += (double)D[i] * (double)P[i] + 2.0 * (double)E[c * a.Bp + r] * (double)T[i];
-      }
-    }
+  double ar = 0.0, ap = 0.0, ag = 0.0;
+  for (int i = t; i < a.dot_blocks; i += kThreads) {
+    ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; ag += a.part_dot[2 * (int64_t)a.dot_blocks + i];
   }
-  const double raw_raw = block_sum(acc, red);
-  __syncthreads();
-  double ar = 0.0, ap = 0.0;
-  for (int i = t; i < a.dot_blocks; i += kThreads) { ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; }
   const double r_raw = block_sum(ar, red);
-  __syncthreads();
   const double p_raw = block_sum(ap, red);
-  __syncthreads();
+  const double raw_raw = block_sum(ag, red);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int i = t; i < a.n0 + a.n1; i += kThreads) {
     const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
     s0 += a.part[j]; s1 += a.part[a.part_stride + j]; s2 += a.part[2 * (int64_t)a.part_stride + j];
   }
   const double rr_s = block_sum(s0, red);
-  __syncthreads();
   const double rp_s = block_sum(s1, red);
-  __syncthreads();
   const double pp_s = block_sum(s2, red);
-  __syncthreads();
   double sq = 0.0;
   if (a.first) {   // r_small(0) = p_small (bhg_cg_init; the small slices' direction is not touched by their epilogues)
     for (int tt = 0; tt < a.snt; ++tt)
@@ -2404,7 +2398,17 @@ __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
     a.pscal[0] = rr_b1;
     a.pscal[1] = rr_b1 + b * rp_b1;
     a.pscal[2] = rr_b1 + 2.0 * b * rp_b1 + b * b * pp_b;
+    s_beta = beta;
   }
+  __syncthreads();
+  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p.  Here, in the launch that knows beta and runs alone —
+  // the chain of the next iteration and k_proj_update (Rh_0 needs the first bias direction) read them.
+  const float beta = s_beta;
+  for (int tt = 0; tt < a.snt; ++tt)
+    for (int i = t; i < a.slen[tt]; i += kThreads) {
+      const int64_t e = a.soff[tt] + i;
+      a.p_small[e] = fz_add(a.r_small[e], fz_mul(beta, a.p_small[e]));
+    }
 }
 
 // ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
@@ -2429,24 +2433,9 @@ struct ProjArgs {
   int n, Bp, B, kpar_prev;
   float shift;
   const double* scal;
-  // fully projected CG: the direction update of the SMALL slices (biases, head weight: p = r + beta p, cg.py:53) rides in
-  // blocks [blk0[n], blk0[n] + small_blocks) — nothing else touches them between two iterations (no k_cg_beta launch)
-  int small_blocks; const float* sr; float* sp;
-  int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
 };
 __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
   const int b = blockIdx.x;
-  if (b >= pa.blk0[pa.n]) {   // small slices
-    const int gi = (b - pa.blk0[pa.n]) * 256 + threadIdx.x;
-    int64_t eoff = -1;
-    int base = 0;
-    for (int t = 0; t < pa.snt; ++t) {
-      if (eoff < 0 && gi < base + pa.slen[t]) eoff = pa.soff[t] + (gi - base);
-      base += pa.slen[t];
-    }
-    if (eoff >= 0) pa.sp[eoff] = fz_add(pa.sr[eoff], fz_mul((float)pa.scal[S_BETA], pa.sp[eoff]));
-    return;
-  }
   int i = 0;
   while (i + 1 < pa.n && b >= pa.blk0[i + 1]) ++i;
   const ProjProb pr = pa.p[i];
@@ -2605,6 +2594,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
   }
   hp->dot_blocks = 0;
   for (int i = 0; i < n; ++i) hp->dot_blocks += (Bp * (hp->N[i] / 4) + 255) / 256;
+  hp->dot_blocks += (3 * (L - 2) + 1) * ((Bp * (Bp / 4) + 255) / 256);   // the Gram dots of raw.raw
   for (int l = 0; l + 1 < L; ++l) {
     hp->s_off[l] = off; off += (size_t)Bp * Bp;
     hp->q_off[l] = off; off += (size_t)Bp * Bp;
@@ -2652,7 +2642,7 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   HoistPlan hp;
   hoist_plan(m, &hp);
   w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
-  w->part_dot = static_cast<double*>(take(sizeof(double) * 2 * (hp.ok ? hp.dot_blocks : 1)));
+  w->part_dot = static_cast<double*>(take(sizeof(double) * 3 * (hp.ok ? hp.dot_blocks : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   w->bytes = off;
 }
@@ -2800,13 +2790,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       pa.blk0[hp->n] = rblk;
       pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cm.scal;
-      if (cm.proj >= 2 && cm.beta) {   // fully projected: the small slices' direction update rides here (no k_cg_beta launch)
-        pa.sr = cm.beta->r; pa.sp = cm.beta->p; pa.snt = cm.beta->nt;
-        int tot = 0;
-        for (int t = 0; t < cm.beta->nt; ++t) { pa.soff[t] = cm.beta->off[t]; pa.slen[t] = cm.beta->len[t]; tot += cm.beta->len[t]; }
-        pa.small_blocks = (tot + 255) / 256;
-      }
-      hipLaunchKernelGGL(k_proj_update, dim3(rblk + pa.small_blocks), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
       ++g_proj_iterations;
     }
     static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
@@ -3093,14 +3077,25 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ga.blk0[hp->n] = gblk;
       ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
       if (full) {   // the projected inner products r.raw, p.raw ride behind the tiles
-        int dblk = 0;
+        int dblk = 0, nd = 0;
         for (int i = 0; i < hp->n; ++i) {
           const int l = hp->layer[i];
-          ga.dp[i] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i]};
-          ga.dblk0[i] = dblk; dblk += (Bp * (hp->N[i] / 4) + 255) / 256;
+          ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i], 0.f, 0};
+          ga.dblk0[nd++] = dblk; dblk += (Bp * (hp->N[i] / 4) + 255) / 256;
         }
-        ga.dblk0[hp->n] = dblk;
-        ga.nd = hp->n; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
+        const int gblocks = (Bp * (Bp / 4) + 255) / 256;
+        for (int l = 0; l + 1 < L; ++l) {   // raw.raw from the Gram matrices (see k_proj_scalars)
+          ga.dp[nd] = {hbase + hp->q_off[l], nullptr, hbase + hp->s_off[l], Bp, 1.f, 0};
+          ga.dblk0[nd++] = dblk; dblk += gblocks;
+          if (l >= 1) {
+            ga.dp[nd] = {hbase + hp->p_off[l], nullptr, hbase + hp->d_off[l], Bp, 1.f, 0};
+            ga.dblk0[nd++] = dblk; dblk += gblocks;
+            ga.dp[nd] = {hbase + hp->t_off[l], nullptr, hbase + hp->e_off[l], Bp, 2.f, 1};
+            ga.dblk0[nd++] = dblk; dblk += gblocks;
+          }
+        }
+        ga.dblk0[nd] = dblk;
+        ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
       }
       hipLaunchKernelGGL(k_hoist, dim3(gblk + ga.dot_blocks), dim3(256), 0, st, ga);
     }
@@ -3158,17 +3153,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     if (proj_full) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
       BHG_REQUIRE(all_fast, "the fully projected CG solver needs the single-launch output path");
-      float* hbase = cm.ws->hoist;
       ProjScalArgs sa{};
-      sa.nl = L - 1; sa.Bp = Bp; sa.B = B;
-      for (int l = 0; l + 1 < L; ++l) {
-        sa.S[l] = hbase + hp->s_off[l]; sa.Q[l] = hbase + hp->q_off[l];
-        if (l >= 1) { sa.D[l] = hbase + hp->d_off[l]; sa.P[l] = hbase + hp->p_off[l]; sa.E[l] = hbase + hp->e_off[l]; sa.T[l] = hbase + hp->t_off[l]; }
-      }
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
       sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
       sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;
-      sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
+      sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
       for (int t = 0; t < cm.beta->nt; ++t) { sa.soff[t] = cm.beta->off[t]; sa.slen[t] = cm.beta->len[t]; }
       sa.scal = cm.scal; sa.pscal = cm.ws->pscal; sa.shift = cm.shift; sa.first = cm.first;
       hipLaunchKernelGGL(k_proj_scalars, dim3(1), dim3(kThreads), 0, st, sa);
