@@ -2352,63 +2352,72 @@ struct ProjScalArgs {
   const double* part; int part_stride; int off0, n0, off1, n1;   // the small slices' epilogue partials [3][stride]
   const float* r_small; float* p_small;                          // flat r / p (small slices only)
   int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
-  double* scal; double* pscal;   // pscal: {rr_big, rp_big, pp_big}
-  float shift; int first;
+  double* scal; double* pscal;   // pscal: {rr_big, rp_big, pp_big} x 2, ping-pong by iteration parity
+  float shift; int first, kpar;
 };
+// A few blocks (one thread per element of the small slices); every block recomputes the same scalars from the same partials in
+// the same order, block 0 publishes them (like k_cg_beta).  The previous iteration's {rr, rp, pp} are read from the OTHER
+// parity slot of pscal, so no block can see block 0's new values.
 __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
   __shared__ double red[kWaves];
   __shared__ float s_beta;
   const int t = threadIdx.x;
+  // this thread's element of the small slices: loads first (independent of the sums)
+  const int gi = blockIdx.x * kThreads + t;
+  int64_t eoff = -1;
+  {
+    int base = 0;
+    for (int tt = 0; tt < a.snt; ++tt) {
+      if (eoff < 0 && gi < base + a.slen[tt]) eoff = a.soff[tt] + (gi - base);
+      base += a.slen[tt];
+    }
+  }
+  float rv = 0.f, pv = 0.f;
+  if (eoff >= 0) { rv = a.r_small[eoff]; pv = a.p_small[eoff]; }
   double ar = 0.0, ap = 0.0, ag = 0.0;
   for (int i = t; i < a.dot_blocks; i += kThreads) {
     ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; ag += a.part_dot[2 * (int64_t)a.dot_blocks + i];
   }
-  const double r_raw = block_sum(ar, red);
-  const double p_raw = block_sum(ap, red);
-  const double raw_raw = block_sum(ag, red);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int i = t; i < a.n0 + a.n1; i += kThreads) {
     const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
     s0 += a.part[j]; s1 += a.part[a.part_stride + j]; s2 += a.part[2 * (int64_t)a.part_stride + j];
   }
+  const double r_raw = block_sum(ar, red);
+  const double p_raw = block_sum(ap, red);
+  const double raw_raw = block_sum(ag, red);
   const double rr_s = block_sum(s0, red);
   const double rp_s = block_sum(s1, red);
   const double pp_s = block_sum(s2, red);
-  double sq = 0.0;
-  if (a.first) {   // r_small(0) = p_small (bhg_cg_init; the small slices' direction is not touched by their epilogues)
-    for (int tt = 0; tt < a.snt; ++tt)
-      for (int i = t; i < a.slen[tt]; i += kThreads) { const double v = (double)a.p_small[a.soff[tt] + i]; sq += v * v; }
-  }
-  const double rr_small0 = block_sum(sq, red);
   if (t == 0) {
     const double rr_old = a.scal[S_RR_OLD];          // r.r of this iteration (k_cg_alpha)
     const double al = a.scal[S_ALPHA], sh = (double)a.shift;
+    const double* pin = a.pscal + 4 * (a.kpar ^ 1);
+    double* pout = a.pscal + 4 * a.kpar;
     double rr_b, rp_b, pp_b;
-    if (a.first) rr_b = rp_b = pp_b = rr_old - rr_small0;
-    else { rr_b = a.pscal[0]; rp_b = a.pscal[1]; pp_b = a.pscal[2]; }
+    // first iteration: p = r (bhg_cg_init), so the small slices' share of r.r is their p.p partial of this very iteration
+    if (a.first) rr_b = rp_b = pp_b = rr_old - pp_s;
+    else { rr_b = pin[0]; rp_b = pin[1]; pp_b = pin[2]; }
     const double rHp = r_raw + sh * rp_b, pHp = p_raw + sh * pp_b, HpHp = raw_raw + 2.0 * sh * p_raw + sh * sh * pp_b;
     const double rr_b1 = rr_b - 2.0 * al * rHp + al * al * HpHp;
     const double rp_b1 = rp_b - al * pHp;              // r'.p over the MFMA layers
     const double rr1 = rr_b1 + rr_s, rp1 = rp_b1 + rp_s, pp = pp_b + pp_s;
     const float beta = (float)rr1 / (float)rr_old;     // fp32 division of the fp32-rounded dots, as the reference (cg.py:51-52)
     const double b = (double)beta;
-    a.scal[S_RR_NEW] = rr1;
-    a.scal[S_BETA] = b;
-    a.scal[S_PP] = rr1 + 2.0 * b * rp1 + b * b * pp;
-    a.pscal[0] = rr_b1;
-    a.pscal[1] = rr_b1 + b * rp_b1;
-    a.pscal[2] = rr_b1 + 2.0 * b * rp_b1 + b * b * pp_b;
+    if (blockIdx.x == 0) {
+      a.scal[S_RR_NEW] = rr1;
+      a.scal[S_BETA] = b;
+      a.scal[S_PP] = rr1 + 2.0 * b * rp1 + b * b * pp;
+      pout[0] = rr_b1;
+      pout[1] = rr_b1 + b * rp_b1;
+      pout[2] = rr_b1 + 2.0 * b * rp_b1 + b * b * pp_b;
+    }
     s_beta = beta;
   }
   __syncthreads();
-  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p.  Here, in the launch that knows beta and runs alone —
-  // the chain of the next iteration and k_proj_update (Rh_0 needs the first bias direction) read them.
-  const float beta = s_beta;
-  for (int tt = 0; tt < a.snt; ++tt)
-    for (int i = t; i < a.slen[tt]; i += kThreads) {
-      const int64_t e = a.soff[tt] + i;
-      a.p_small[e] = fz_add(a.r_small[e], fz_mul(beta, a.p_small[e]));
-    }
+  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p.  Here, in a launch that runs alone: the chain of the
+  // next iteration and k_proj_update (Rh_0 needs the first bias direction) read them.
+  if (eoff >= 0) a.p_small[eoff] = fz_add(rv, fz_mul(s_beta, pv));
 }
 
 // ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
@@ -3159,8 +3168,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;
       sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
       for (int t = 0; t < cm.beta->nt; ++t) { sa.soff[t] = cm.beta->off[t]; sa.slen[t] = cm.beta->len[t]; }
-      sa.scal = cm.scal; sa.pscal = cm.ws->pscal; sa.shift = cm.shift; sa.first = cm.first;
-      hipLaunchKernelGGL(k_proj_scalars, dim3(1), dim3(kThreads), 0, st, sa);
+      sa.scal = cm.scal; sa.pscal = cm.ws->pscal; sa.shift = cm.shift; sa.first = cm.first; sa.kpar = cm.kpar;
+      int small_total = 0;
+      for (int t = 0; t < cm.beta->nt; ++t) small_total += cm.beta->len[t];
+      const int sgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;
+      hipLaunchKernelGGL(k_proj_scalars, dim3(sgrid), dim3(kThreads), 0, st, sa);
     }
     BHG_HIP_CHECK(hipGetLastError());
     return BHG_OK;
