@@ -836,7 +836,11 @@ struct AlphaArgs {
 // (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
 //  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
 //  launch cost, 264.7 vs 265.3 steps/s in a same-box A/B.)
+// (Callable from blocks of more than kThreads threads — k_wsk_group's alpha block: the threads past kThreads only take part in
+//  the barriers, so the partial sums are split and combined exactly as in k_cg_alpha.)
 __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool writer) {
+  const bool act = threadIdx.x < kThreads;
+  const int tid = act ? (int)threadIdx.x : (1 << 30);
   __shared__ double red[5][kWaves];
   __shared__ float s_alpha;
   // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
@@ -847,22 +851,22 @@ __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool wr
   double rzxv[kRzPer];
 #pragma unroll
   for (int u = 0; u < kRzPer; ++u) {
-    const int i = threadIdx.x + u * kThreads;
+    const int i = tid + u * kThreads;
     rzv[u] = (writer && i < a.nrz) ? a.rz[i] : 0.f;
     rzxv[u] = (writer && i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
   }
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < a.B; i += kThreads) acc[0] += a.partT1[i];
-  if (a.partT2h) for (int i = threadIdx.x; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
-  for (int i = threadIdx.x; i < a.nT2; i += kThreads)
+  for (int i = tid; i < a.B; i += kThreads) acc[0] += a.partT1[i];
+  if (a.partT2h) for (int i = tid; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
+  for (int i = tid; i < a.nT2; i += kThreads)
     acc[2] += a.partT2[i];
-  if (a.shift != 0.f) for (int i = threadIdx.x; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
-  for (int i = threadIdx.x; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
+  if (a.shift != 0.f) for (int i = tid; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
+  for (int i = tid; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const double v = wave_sum(acc[q]);
-    if (lane == 0) red[q][w] = v;
+    if (act && lane == 0) red[q][w] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -892,10 +896,10 @@ __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool wr
   const double al = (double)s_alpha;
 #pragma unroll
   for (int u = 0; u < kRzPer; ++u) {
-    const int i = threadIdx.x + u * kThreads;
+    const int i = tid + u * kThreads;
     if (i < a.nrz) a.rzx[i] = rzxv[u] + al * (double)rzv[u];
   }
-  for (int i = threadIdx.x + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
+  for (int i = tid + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
     const double v = al * (double)a.rz[i];
     a.rzx[i] = a.first ? v : a.rzx[i] + v;
   }
@@ -1006,8 +1010,8 @@ struct BiasArgs {
   float rho2;
   int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
 };
-template <int MODE>
-__device__ __forceinline__ void bias_body(const BiasArgs& a, const FuseArgs& fz, const int bx, float* red_base) {
+template <int MODE, class BA = BiasArgs>
+__device__ __forceinline__ void bias_body(const BA& a, const FuseArgs& fz, const int bx, float* red_base) {
   float (*red)[64] = reinterpret_cast<float (*)[64]>(red_base);   // 4 x 64 floats of LDS provided by the caller
   __shared__ double red_rr[kWaves];
   int l = 0;
@@ -1888,9 +1892,15 @@ struct WskGroupArgs {
   WskGroupProb p[kWskGroupMax];
   int blk0[kWskGroupMax + 1];
   int n;
+  int do_alpha; AlphaArgs alpha;   // block blk0[n]: k_cg_alpha's work (the step length needs the same inputs as this iteration's
+                                   // Gram products — the end of the R-chain — and nothing of them)
 };
 __global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
   const int b = blockIdx.x;
+  if (b >= g.blk0[g.n]) {
+    if (g.do_alpha) (void)alpha_compute(g.alpha, true);
+    return;
+  }
   int i = 0;
   while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
   WskArgs a{};
@@ -1972,7 +1982,7 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
 #undef BHG_WSK
 }
 
-void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {
+void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // blocks: the tiles (+ 1 with do_alpha)
   const int lds = (int)(sizeof(float) * kWslWaveFloats * kWskWaves);
   static bool attr_done = false;
   if (!attr_done) {
@@ -2206,6 +2216,17 @@ constexpr int kHoistMax = 14;
 // A Gram problem (w != 0) contributes w * <X or X^T, Gr> to raw.raw instead: <S_l, Rd_l Rd_l^T>, <D_l, Rh Rh^T>, 2 <E_l^T, T_l>.
 struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; float w; int xT; };
 constexpr int kProjDotMax = kHoistMax + 3 * (kHoistMax / 2);   // products + three Gram dots per MFMA layer
+// The small slices' outputs (head weight, biases) with their fused CG epilogue, as block classes of k_hoist (fully projected CG:
+// they are all that is left of k_outer_all).  Compact twin of BiasArgs (the hoisted forms take at most 8 layers).
+constexpr int kSmallL = kHoistMax / 2 + 1;
+struct BiasArgsC {
+  const float* rd[kSmallL]; const float* c[kSmallL]; float* out[kSmallL];
+  int n[kSmallL]; int blk0[kSmallL + 1]; int L, B; float rho2; int64_t foff[kSmallL];
+};
+struct SmallOutArgs {
+  HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
+  BiasArgsC ba; FuseArgs bf; int bias_blocks;
+};
 struct HoistArgs {
   HoistProb p[kHoistMax];
   int blk0[kHoistMax + 1];
@@ -2216,6 +2237,8 @@ struct HoistArgs {
   ProjDotProb dp[kProjDotMax];
   int dblk0[kProjDotMax + 1];
   double* part_dot;              // [3][dot_blocks]: r.raw, p.raw, raw.raw
+  int small_blocks;              // then the small slices' output blocks (head_blocks + bias_blocks)
+  SmallOutArgs so;
 };
 
 static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
@@ -2232,6 +2255,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     // projected inner products: block d of product i
     const int d = e - ha.beta_blocks;
+    if (d >= ha.dot_blocks) {   // small slices' outputs, CG epilogue (r' = r - alpha Hp on their slices + partials)
+      const int sb = d - ha.dot_blocks;
+      if (sb < ha.so.head_blocks) {
+        if (ha.so.head_has_rh) head_outer_body<true, FUSE_CG>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
+        else head_outer_body<false, FUSE_CG>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
+      } else {
+        bias_body<FUSE_CG>(ha.so.ba, ha.so.bf, sb - ha.so.head_blocks, smem);
+      }
+      return;
+    }
     int i = 0;
     while (i + 1 < ha.nd && d >= ha.dblk0[i + 1]) ++i;
     const ProjDotProb q = ha.dp[i];
@@ -3040,12 +3073,18 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
 
   if (single) {
     // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
-    if (cg) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
+    const bool proj_iter = hp && cg && cm.proj && !cm.apply_out && !cm.skip_outputs;
+    static const bool alpha_alone = getenv("BHG_PROJ_ALPHA_ALONE") != nullptr;   // A/B
+    const bool alpha_in_gram = proj_iter && !alpha_alone;
+    if (cg && !alpha_in_gram) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
       BHG_HIP_CHECK(hipGetLastError());
       return BHG_OK;
     }
-    if (hp && cg && cm.proj && !cm.apply_out) {   // projected CG: G(raw) of this iteration for the next one's recurrences
+    static const bool small_alone = getenv("BHG_PROJ_SMALL_ALONE") != nullptr;   // A/B
+    const bool small_in_graw = proj_iter && cm.proj >= 2 && !small_alone;
+    if (proj_iter) {   // projected CG: G(raw) of this iteration for the next one's recurrences
       float* hbase = cm.ws->hoist;
       WskGroupArgs g{};
       int blk = 0;
@@ -3065,7 +3104,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         }
       }
       g.blk0[g.n] = blk;
-      if (g.n > 0) launch_wsk_group(g, blk, st);
+      if (alpha_in_gram) { g.do_alpha = 1; g.alpha = aa; }
+      launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
       HoistArgs ga{};
       int gblk = 0;
       const int ntm = Bp / kTM;
@@ -3106,7 +3146,24 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         ga.dblk0[nd] = dblk;
         ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
       }
-      hipLaunchKernelGGL(k_hoist, dim3(gblk + ga.dot_blocks), dim3(256), 0, st, ga);
+      if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of this launch
+        SmallOutArgs& so = ga.so;
+        so.head = head_outer_args(L - 1);
+        so.hf = fuse_at(2 * (L - 1), part_base_w[L - 1]);
+        so.head_gx = (so.head.N + 63) / 64;
+        so.head_blocks = so.head_gx * so.head.C;
+        so.head_has_rh = L > 1;
+        so.ba.L = ba.L; so.ba.B = ba.B; so.ba.rho2 = ba.rho2;
+        for (int l = 0; l < L; ++l) {
+          so.ba.rd[l] = ba.rd[l]; so.ba.c[l] = ba.c[l]; so.ba.out[l] = ba.out[l]; so.ba.n[l] = ba.n[l]; so.ba.blk0[l] = ba.blk0[l];
+          so.ba.foff[l] = ba.foff[l];
+        }
+        so.ba.blk0[L] = ba.blk0[L];
+        so.bf = bias_fz;
+        so.bias_blocks = bias_blk;
+        ga.small_blocks = so.head_blocks + bias_blk;
+      }
+      hipLaunchKernelGGL(k_hoist, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
     }
     // one launch for all outputs when every MFMA layer is all-interior
     // (fully projected CG: the MFMA layers' slices of r and p are not materialised — only the small slices' blocks launch)
@@ -3135,7 +3192,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.blk0[i] = blk;
       blk += outer_blocks(m, l, head);
     }
-    if (all_fast) {
+    if (small_in_graw) {
+      // (the small slices' blocks already ran in k_hoist's launch)
+    } else if (all_fast) {
       oa.n = n_mfma;
       oa.blk0[n_mfma] = blk;
       oa.head = head_outer_args(L - 1);
@@ -3161,7 +3220,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       launch_bias(st);
     }
     if (proj_full) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
-      BHG_REQUIRE(all_fast, "the fully projected CG solver needs the single-launch output path");
+      BHG_REQUIRE(all_fast || small_in_graw, "the fully projected CG solver needs the single-launch output path");
       ProjScalArgs sa{};
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
       sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
