@@ -343,7 +343,21 @@ def main():
     for _ in range(args.warmup):
         step()
     # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream.
+    h0, p0 = int(be.lib.bhg_mlp_hoist_launches()), int(be.lib.bhg_mlp_proj_iterations())
     elapsed = timed_region(args.steps)
+    n_hoist, n_proj = int(be.lib.bhg_mlp_hoist_launches()) - h0, int(be.lib.bhg_mlp_proj_iterations()) - p0
+    solver_form = None
+    if fused and args.algo == "cg":
+        if n_proj == args.steps * (K - 1) and n_hoist == args.steps:
+            solver_form = ("fully projected CG (libbhg default without a solution vector): after the first iteration the direction "
+                           "products, r.r, p.p and p.Hp all come from batch-sized recurrences through B x B Gram matrices — no N-sized "
+                           "state vector is read or written; bhg_mlp_proj_iterations / bhg_mlp_hoist_launches = %d / %d" % (n_proj, n_hoist)
+                           if not args.keep_solution else
+                           "projected CG with the N-sized r / p kept (the caller asked for x): %d projected iterations" % n_proj)
+        elif n_hoist == args.steps * K:
+            solver_form = "hoisted chain on the N-sized residual every iteration (BHG_MLP_PROJ=0)"
+        elif n_hoist == 0:
+            solver_form = "classic chain (BHG_MLP_HOIST=0)"
     # Region 1b — the same `steps` steps with HALF the iterations, equally free of events: the difference of the two
     # regions is K/2 full iterations per step on the SAME clock as the headline (no per-launch events, no profiler), so
     # the roofline span and the headline agree by construction:  iteration = (t(K) - t(K/2)) / (K/2);
@@ -412,7 +426,11 @@ def main():
             alg = rec_bytes                     # 28*N per CG iteration, 20*N per Neumann iteration
             comp = rec_bytes + 20.0 * N         # + Appendix A.3's HVP weight traffic (read W, V twice, write H*dir once)
             roof = {"bound": "hbm",
-                    "kernel": ("bhg_mlp_cg_solve: one whole fused CG-HVP iteration (k_cg_beta + R-chain + k_cg_alpha + k_outer_all, whose "
+                    "kernel": ("bhg_mlp_cg_solve: one whole CG-HVP iteration — fully projected form: k_proj_update, the R-chain through the "
+                               "constant weights (k_gemm_wsk x3, k_gemm, k_head_forward), k_wsk_group (Gram products + step length), k_hoist "
+                               "(G(raw) products, inner products, small slices' outputs), k_proj_scalars" if (args.algo == "cg" and solver_form
+                                                                                                                and solver_form.startswith("fully")) else
+                               "bhg_mlp_cg_solve: one whole fused CG-HVP iteration (R-chain + k_cg_alpha + k_outer_all, whose "
                                "epilogue carries the r/p update)" if args.algo == "cg" else
                                "bhg_mlp_neumann_solve: one whole fused Neumann-HVP iteration"),
                     "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -428,7 +446,9 @@ def main():
                                                               "frac": comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                                               "note": "round-2's figure (28N + 20N); the fused path neither writes nor re-reads H*p, "
                                                                       "so this counts bytes the kernels do not move — yardstick only"},
-                    "note": mall_note + "; the iteration is bound by the fp32 matrix pipe, not by HBM: see hvp_roofline"}
+                    "note": mall_note + "; `achieved` is SURVEY 8(d)'s yardstick — the 28*N bytes the REFERENCE's recurrence moves per "
+                            "iteration divided by this solver's iteration time; the projected solver itself moves far fewer bytes (`traffic`), "
+                            "its iteration is a chain of ~9 dependent launches on batch-sized data plus one pass over the constant weights"}
         elif ("cg_step" if args.algo == "cg" else "neumann_step") in spans:
             us, n = spans["cg_step" if args.algo == "cg" else "neumann_step"]
             roof = {
@@ -453,10 +473,21 @@ def main():
             src = "HIP events around the HVP chain (bhg_timing)"
             if fused and iter_us is not None:   # the whole iteration IS the HVP chain plus two ~5 us scalar launches
                 us, src = iter_us, "event-free whole-iteration time (see roofline.avg_launch_us_source)"
+            # what the projected iteration actually executes on the matrix pipe (useful rows only): the constant-weight chain,
+            # the B x B Gram products and the batch-deep G(raw) products
+            chain = sum(2.0 * BATCH * d[l] * d[l + 1] * 2 for l in range(1, len(d) - 2)) + 2.0 * BATCH * d[-2] * d[-1] * 4
+            gram = sum(2.0 * BATCH * BATCH * (2 * d[l] + 2 * d[l + 1]) for l in range(1, len(d) - 2)) + 2.0 * BATCH * BATCH * d[1]
+            graw = sum(2.0 * BATCH * BATCH * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 2)) + \
+                sum(2.0 * BATCH * BATCH * d[l] * 2 for l in range(1, len(d) - 2))
             hvp_roof = {
                 "bound": "mfma",
-                "kernel": "MLP HVP chain (k_gemm<NT>, k_gemm<NN>, k_outer, head kernels, split-K reduces)" +
-                          ("; fused: its output kernels also carry the recurrence's r/x (or v/p) update" if fused else ""),
+                "kernel": "one H*p of the reference (R-forward, R-backward, weight-shaped outputs: the yardstick's 7.0 GFLOP)" +
+                          ("; the fully projected solver obtains the same iteration from %.2f GFLOP (constant-weight chain %.2f + Gram "
+                           "products %.2f + G(raw) products %.2f): the weight-shaped outputs are never formed"
+                           % ((chain + gram + graw) / 1e9, chain / 1e9, gram / 1e9, graw / 1e9)
+                           if (solver_form or "").startswith("fully") else
+                           "; fused: its output kernels also carry the recurrence's r/x (or v/p) update" if fused else ""),
+                "executed_flops_per_iteration": (chain + gram + graw) if (solver_form or "").startswith("fully") else None,
                 "achieved": flops / (us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                 "frac": flops / (us * 1e-6) / 1e12 / 157.3, "flops_per_call": flops, "avg_call_us": us, "avg_call_us_source": src,
                 "avg_call_us_hip_events": spans["hvp"][0], "calls_timed": n,
@@ -491,9 +522,10 @@ def main():
                         "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else
                         "pytorch-rocm autograd double backward" + ("" if args.no_hvp_graph else ", captured once per solve and replayed as a HIP graph (opt-in)")),
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
+                "solver_form": solver_form,
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else
                                     "not materialised: the mixed second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), "
-                                    "accumulated from batch-sized factors; same hypergradient bit for bit"),
+                                    "accumulated from batch-sized factors"),
                 "parallelism": ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world)
                 if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,

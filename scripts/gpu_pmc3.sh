@@ -39,7 +39,7 @@ for arm in ("fused", "nofuse"):
         n = (fe.get(k) or wr.get(k))[0]
         tab[k] = {"launches": n, "fetch_bytes": 2 * 1024 * (fe.get(k, (0, 0))[1]), "write_bytes": 1024 * (wr.get(k, (0, 0))[1])}
     out["per_kernel"][arm] = tab
-    loop = [k for k in tab if any(s in k for s in ("k_gemm", "k_hoist", "k_reduce_mask", "k_head_forward<true", "k_outer", "k_cg_alpha", "k_cg_beta", "k_cg_pdir", "k_bias", "k_head_outer", "k_cg_resident"))]
+    loop = [k for k in tab if any(s in k for s in ("k_gemm", "k_hoist", "k_wsk_group", "k_proj_", "k_reduce_mask", "k_head_forward<true", "k_outer", "k_cg_alpha", "k_cg_beta", "k_cg_pdir", "k_bias", "k_head_outer", "k_cg_resident"))]
     # bytes per CG iteration = sum over loop kernels of (avg bytes per launch x launches) / (steps x K); the once-per-step
     # passes use some of the same kernels (forward / backward / mixed coefficient), so this is an upper bound
     tot = sum((tab[k]["fetch_bytes"] + tab[k]["write_bytes"]) * tab[k]["launches"] for k in loop) / (steps * K)
