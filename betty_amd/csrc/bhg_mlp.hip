@@ -18,6 +18,9 @@
 // fill the 256 CUs (deterministic: partial slabs are summed in fixed order, no atomics).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "bhg_common.hpp"
 
 namespace bhg {
@@ -1947,6 +1950,8 @@ inline bool wsk_eligible(const WskArgs& a) {
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 int64_t g_hoist_launches = 0; // bhg_mlp_hoist_launches()
 int64_t g_proj_iterations = 0; // bhg_mlp_proj_iterations()
+std::mutex g_neumann_mu;        // which fused workspaces hold a PROJECTED Neumann solve (its Rz sum includes the last direction)
+std::unordered_map<const void*, bool> g_neumann_projected;
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
@@ -2244,6 +2249,7 @@ struct HoistArgs {
 static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
 constexpr int kHoistLds = GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS > GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS
                               ? GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS : GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS;
+template <int SMODE>   // epilogue of the small slices' output blocks: FUSE_CG / FUSE_NEUMANN
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hoist(HoistArgs ha) {
   __shared__ __attribute__((aligned(16))) float smem[kHoistLds];
   const int b = blockIdx.x;
@@ -2258,10 +2264,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (d >= ha.dot_blocks) {   // small slices' outputs, CG epilogue (r' = r - alpha Hp on their slices + partials)
       const int sb = d - ha.dot_blocks;
       if (sb < ha.so.head_blocks) {
-        if (ha.so.head_has_rh) head_outer_body<true, FUSE_CG>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
-        else head_outer_body<false, FUSE_CG>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
+        if (ha.so.head_has_rh) head_outer_body<true, SMODE>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
+        else head_outer_body<false, SMODE>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
       } else {
-        bias_body<FUSE_CG>(ha.so.ba, ha.so.bf, sb - ha.so.head_blocks, smem);
+        bias_body<SMODE>(ha.so.ba, ha.so.bf, sb - ha.so.head_blocks, smem);
       }
       return;
     }
@@ -2474,7 +2480,8 @@ struct ProjArgs {
   int blk0[kHoistMax + 1];
   int n, Bp, B, kpar_prev;
   float shift;
-  const double* scal;
+  const double* scal;   // CG: alpha_{k-1}, beta_{k-1}.  NULL: Neumann — G(v') = G(v) - alpha (G(raw) + shift G(v)) with the constant
+  float alpha;          // step `alpha` (Gr and Gp then name the same array)
 };
 __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
   const int b = blockIdx.x;
@@ -2491,14 +2498,14 @@ __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
     const float4 r0 = ld16(pr.Gr + idx * 4), p0 = ld16(pr.Gp + idx * 4), w0 = ld16(pr.Graw + idx * 4);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
-    const float alpha = (float)pa.scal[S_ALPHA_RING + pa.kpar_prev], beta = (float)pa.scal[S_BETA];
+    const float alpha = pa.scal ? (float)pa.scal[S_ALPHA_RING + pa.kpar_prev] : pa.alpha, beta = pa.scal ? (float)pa.scal[S_BETA] : 0.f;
     // the rounding sequence of the N-sized recurrences (fuse_elem): Hp = raw + shift p; r' = r - alpha Hp; p' = r' + beta p
 #define BHG_PROJ1(c)                                                                  \
     {                                                                                 \
       float hv = w0.c;                                                                \
       if (pa.shift != 0.f) hv = fz_add(hv, fz_mul(pa.shift, p0.c));                   \
       gr.c = fz_sub(r0.c, fz_mul(alpha, hv));                                         \
-      gp.c = fz_add(gr.c, fz_mul(beta, p0.c));                                        \
+      gp.c = pa.scal ? fz_add(gr.c, fz_mul(beta, p0.c)) : gr.c;                       \
     }
     BHG_PROJ1(x) BHG_PROJ1(y) BHG_PROJ1(z) BHG_PROJ1(w)
 #undef BHG_PROJ1
@@ -2713,7 +2720,8 @@ struct ChainMode {
   int gemm_mode;                // FUSE_NONE: BHG_MLP_WSK-style mode asked for by the caller (bhg_mlp_hvp_mode)
   const HoistPlan* hoist;       // FUSE_CG + lazy: run the hoisted form of the chain (k_hoist); NULL = the classic chain
   const BetaArgs* beta; int beta_blocks;   // hoisted form: k_cg_beta's work rides in k_hoist's launch (iterations > 0)
-  int proj;                     // FUSE_CG, hoisted: projected CG — direction products from batch-sized recurrences (k_proj_update)
+  int proj;                     // hoisted: direction products from batch-sized recurrences (k_proj_update); CG: 1 / 2, Neumann: 1
+  int stop_after_head;          // projected Neumann: the closing pass that only adds Rz(v_K) to the accumulated Rz sums
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2795,7 +2803,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     ha.blk0[hp->n] = hp->blk0[hp->n];
     ha.n = hp->n; ha.Bp = Bp; ha.gemm_blocks = hp->blk0[hp->n];
-    const bool proj = cg && cm.proj;
+    const bool proj = cm.proj != 0;
     int rblk = 0;
     for (int i = 0; i < hp->n; ++i) { ra.blk0[i] = rblk; rblk += (Bp * (hp->N[i] / 4) + 255) / 256; }
     ra.blk0[hp->n] = rblk;
@@ -2803,9 +2811,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ha.do_beta = (cg && !cm.first && cm.beta && !proj) ? 1 : 0;
       ha.beta_blocks = ha.do_beta ? cm.beta_blocks : 0;
       if (ha.do_beta) ha.beta = *cm.beta;
-      hipLaunchKernelGGL(k_hoist, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
+      hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(ha.gemm_blocks + (ha.do_beta ? cm.beta_blocks : 0)), dim3(256), 0, st, ha);
       ++g_hoist_launches;
-      if (proj) for (int i = 0; i < hp->n; ++i) ra.p[i].G2 = hbase + hp->gr_off[i];
+      if (proj && cg) for (int i = 0; i < hp->n; ++i) ra.p[i].G2 = hbase + hp->gr_off[i];
       ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cg ? cm.first : 1; ra.scal = cm.scal;
       hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
       if (proj) {   // the iteration-invariant Gram matrices S_l = h_l h_l^T, D_l = delta_l delta_l^T (once per solve)
@@ -2826,12 +2834,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ProjArgs pa{};
       for (int i = 0; i < hp->n; ++i) {
         ProjProb& q = pa.p[i];
-        q.Gr = hbase + hp->gr_off[i]; q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
+        q.Gr = hbase + (cg ? hp->gr_off[i] : hp->g_off[i]); q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
         if (!hp->bwd[i] && hp->layer[i] == 0) { q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0]; }
         pa.blk0[i] = ra.blk0[i];
       }
       pa.blk0[hp->n] = rblk;
-      pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cm.scal;
+      pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cg ? cm.scal : nullptr; pa.alpha = cm.alpha;
       hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
       ++g_proj_iterations;
     }
@@ -2863,6 +2871,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
                           static_cast<const float*>(dir[2 * l + 1]), m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr,
                           (const float*)m->delta[l], (const float*)m->mask[l - 1], m->Rd[l - 1], &head_fuse,
                           cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr, cg ? cm.ws->rz : nullptr, cm.rzx_acc, cm.first);
+    }
+    if (cm.stop_after_head) {   // (projected Neumann's closing pass: Rz(v_K) is in the accumulator now)
+      BHG_HIP_CHECK(hipGetLastError());
+      return BHG_OK;
     }
     // backward chain: Rd_{l-1} = mask_{l-1} * (Rd_l W_l + Gb_l); T2_l = 2 <Gb_l, Rh_{l-1}> from the tile epilogue
     for (int l = L - 2; l >= 1; --l) {
@@ -3074,16 +3086,17 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   if (single) {
     // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
     // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
-    const bool proj_iter = hp && cg && cm.proj && !cm.apply_out && !cm.skip_outputs;
+    // (projected Neumann: EVERY iteration — the closing pass needs G(raw) of the last one)
+    const bool proj_iter = hp && cm.proj && (cg ? (!cm.apply_out && !cm.skip_outputs) : true);
     static const bool alpha_alone = getenv("BHG_PROJ_ALPHA_ALONE") != nullptr;   // A/B
-    const bool alpha_in_gram = proj_iter && !alpha_alone;
+    const bool alpha_in_gram = cg && proj_iter && !alpha_alone;
     if (cg && !alpha_in_gram) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
       BHG_HIP_CHECK(hipGetLastError());
       return BHG_OK;
     }
     static const bool small_alone = getenv("BHG_PROJ_SMALL_ALONE") != nullptr;   // A/B
-    const bool small_in_graw = proj_iter && cm.proj >= 2 && !small_alone;
+    const bool small_in_graw = proj_iter && (cm.proj >= 2 || !cg) && !small_alone;
     if (proj_iter) {   // projected CG: G(raw) of this iteration for the next one's recurrences
       float* hbase = cm.ws->hoist;
       WskGroupArgs g{};
@@ -3094,7 +3107,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->e_off[l], Bp, Bp, m->dims[l + 1], B};    // E_l = delta_l Rd_l^T
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
       }
-      const bool full = cm.proj >= 2;   // fully projected: also Rd_l Rd_l^T and Rh_{l-1} Rh_{l-1}^T (-> raw.raw, k_proj_scalars)
+      const bool full = cg && cm.proj >= 2;   // fully projected CG: also Rd_l Rd_l^T and Rh_{l-1} Rh_{l-1}^T (-> raw.raw, k_proj_scalars)
       for (int l = 0; full && l + 1 < L; ++l) {
         g.p[g.n] = {m->Rd[l], m->Rd[l], hbase + hp->q_off[l], Bp, Bp, m->dims[l + 1], B};
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
@@ -3163,11 +3176,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         so.bias_blocks = bias_blk;
         ga.small_blocks = so.head_blocks + bias_blk;
       }
-      hipLaunchKernelGGL(k_hoist, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
+      if (cg) hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
+      else hipLaunchKernelGGL(k_hoist<FUSE_NEUMANN>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
     }
     // one launch for all outputs when every MFMA layer is all-interior
     // (fully projected CG: the MFMA layers' slices of r and p are not materialised — only the small slices' blocks launch)
-    const bool proj_full = hp && cg && cm.proj >= 2;
+    const bool proj_full = hp && ((cg && cm.proj >= 2) || (!cg && cm.proj));   // no N-sized state: only the small slices' blocks
     const int n_mfma = proj_full ? 0 : (head ? L - 1 : L);
     OuterAllArgs oa{};
     bool all_fast = !no_outer_all && n_mfma <= kOuterAllMax && head;
@@ -3219,7 +3233,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
     }
-    if (proj_full) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
+    if (proj_full && cg) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
       BHG_REQUIRE(all_fast || small_in_graw, "the fully projected CG solver needs the single-launch output path");
       ProjScalArgs sa{};
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
@@ -3314,11 +3328,19 @@ int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, con
   // coefficient of the accumulator-free Neumann solve: p_final = -alpha * sum_{k=0..K} v_k  (neumann.py:64,66 and the
   // negation of 45/54)  =>  coeff = -alpha * ( coeff(v_K)  +  (prob - onehot) . sum_{k<K} Rz(v_k) / B )
   BHG_REQUIRE(fws && fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
-  if (int rc = bhg_mlp_mixed_coeff(m, v_last, labels, coeff, stream)) return rc;   // coeff(v_K): one R-forward
+  bool projected = false;   // the last bhg_mlp_neumann_solve on this workspace already added Rz(v_K) to the sum
+  {
+    std::lock_guard<std::mutex> lock(g_neumann_mu);
+    auto it = g_neumann_projected.find(fws);
+    projected = it != g_neumann_projected.end() && it->second;
+  }
+  if (!projected)
+    if (int rc = bhg_mlp_mixed_coeff(m, v_last, labels, coeff, stream)) return rc;   // coeff(v_K): one R-forward
   FusedWs w;
   carve_fused_ws(m, fws, &w);
   hipLaunchKernelGGL(k_coeff_from_rzx, dim3((m->Bp + kThreads - 1) / kThreads), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     K > 0 ? (const double*)w.rzx : (const double*)nullptr, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -alpha, -alpha);
+                     K > 0 ? (const double*)w.rzx : (const double*)nullptr, m->prob, labels, coeff, m->Bp, m->dims[m->L], m->B, -alpha,
+                     projected ? 0.f : -alpha);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
@@ -3450,12 +3472,23 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   FusedWs w;
   carve_fused_ws(m, fws, &w);
-  // The hoisted chain is an A/B arm here (BHG_MLP_HOIST=2), not the default: measured on the MI355X it neither gains nor
-  // loses for Neumann (656 vs 656 steps/s at cfg 2: no step length, no lazy direction, no beta launch to save), and the
-  // classic chain keeps the fused and un-fused arms bitwise equal.
+  // Hoisting alone (direction products on the N-sized v every iteration, BHG_MLP_HOIST=2) neither gains nor loses for Neumann
+  // (656 vs 656 steps/s at cfg 2: no step length, no lazy direction, no beta launch to save) and is an A/B arm only.  The
+  // PROJECTED form (default without an accumulator vector) is the Neumann twin of the fully projected CG solver:
+  //     G(v_{k+1}) = G(v_k) - alpha (G(raw_k) + shift G(v_k)),   G(raw) from B x B Gram matrices (see k_proj_update)
+  // — no scalars at all, nothing N-sized after the first iteration; the small slices (biases, head weight) keep their
+  // explicit epilogues.  The mixed coefficient needs Rz(sum_k v_k): the head kernel sums Rz(v_k), k < K, as before, and a
+  // closing half pass (update + forward chain + head) adds Rz(v_K) — instead of bhg_mlp_neumann_mixed_coeff's R-forward over
+  // the N-sized v_K, which no longer exists.
   HoistPlan hplan;
   hplan.ok = false;
-  if (hoist_mode() == 2) hoist_plan(m, &hplan);
+  const bool want_proj = !p && K > 0 && proj_mode() != 0 && hoist_mode() != 0;
+  if (hoist_mode() == 2 || want_proj) hoist_plan(m, &hplan);
+  const bool proj = want_proj && hplan.ok && use_head(m);
+  {
+    std::lock_guard<std::mutex> lock(g_neumann_mu);
+    g_neumann_projected[fws] = proj;
+  }
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
     float* vout = (k & 1) ? v0 : v1;
@@ -3472,11 +3505,25 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     // the accumulator p is read and written every OTHER iteration (FuseArgs.x_mode): even iterations defer, odd catch up
     static const bool p_every = getenv("BHG_NEUMANN_P_EVERY_ITER") != nullptr;   // A/B switch
     cm.x_mode = p_every ? 0 : ((k & 1) ? 2 : (k + 1 < K ? 1 : 0));
-    if (!p) { cm.x_mode = 1; cm.rzx_acc = w.rzx; cm.first = k == 0; }
+    cm.first = k == 0;
+    if (!p) { cm.x_mode = 1; cm.rzx_acc = w.rzx; }
     cm.ws = &w;
     cm.hoist = hplan.ok ? &hplan : nullptr;   // every direction product in one grouped launch (k_hoist), as in the CG solver
+    cm.proj = proj ? 1 : 0;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
+  }
+  if (proj) {   // closing pass: Rz(v_K) joins the sum (G(v_K) by the recurrence, small slices of v_K from the last epilogues)
+    float* vin = (K & 1) ? v1 : v0;
+    const void* dir[2 * BHG_MLP_MAX_LAYERS];
+    for (int i = 0; i < 2 * m->L; ++i) dir[i] = vin + starts[i];
+    ChainMode cm{};
+    cm.mode = FUSE_NEUMANN;
+    cm.fa = (K & 1) ? v0 : v1; cm.fb = nullptr; cm.fd = vin; cm.starts = starts;
+    cm.alpha = alpha; cm.shift = hvp_shift;
+    cm.x_mode = 1; cm.rzx_acc = w.rzx; cm.first = 0;
+    cm.ws = &w; cm.hoist = &hplan; cm.proj = 1; cm.stop_after_head = 1;
+    if (int rc = run_chain(m, dir, cm, st)) return rc;
   }
   return BHG_OK;
 }

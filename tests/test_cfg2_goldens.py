@@ -85,7 +85,10 @@ def _arms(algo):
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
-        arms += [("autograd", dict(hvp="autograd"))]
+        # default without an accumulator vector = projected Neumann; classic chain and hoisted-every-iteration as A/B arms
+        arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
+                 ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, hoist="2", proj="0")),
+                 ("autograd", dict(hvp="autograd"))]
     return arms
 
 
