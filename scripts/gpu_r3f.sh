@@ -1,0 +1,27 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "hoisted or fused or wsk or token or structured or cfg2 or neumann" 2>&1 | grep -E "neumann.*full|passed|failed|Error|assert|rror" | tee $O/r3f_tests.log
+timeout 900 python -m pytest tests/test_cfg2_goldens.py -m gpu -q -s -k "neumann10 or metric" 2>&1 | grep -E "neumann10 fused|passed|failed|Error|assert" | tail -24
+run() { tag=$1; shift
+  timeout 300 python bench.py --cpu-steps 0 "$@" 2> $O/r3f_bench_$tag.err > $O/r3f_bench_$tag.json
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/r3f_bench_$tag.json").read().strip().splitlines()[-1])
+    r=d["roofline"] or {}; h=d["hvp_roofline"] or {}
+    print("== %-22s value %.1f steps/s ms/step %.3f iter_us %.1f (events %.1f) frac %.3f hvp_frac %.3f outside_ms %.3f" % ("$tag", d["value"], d["ms_per_step"], d.get("per_iteration_us") or 0, r.get("avg_launch_us_hip_events") or 0, r.get("frac") or 0, h.get("frac") or 0, d.get("outside_k_loop_ms") or 0))
+except Exception as e:
+    print("== $tag bench failed:", e); print(open("$O/r3f_bench_$tag.err").read()[-1500:])
+PY
+}
+for rep in a b; do
+BHG_MLP_PROJ=0 run neumann_classic_$rep --algo neumann --cg-iters 10
+run neumann_projected_$rep --algo neumann --cg-iters 10
+done
+run cg_default
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_n -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 neumann fused > /tmp/tr_n.log 2>&1; echo "trace rc=$?"
+cd $GRAFT_REPO_ROOT
+f=$(ls /tmp/tr_n/*kernel_trace.csv 2>/dev/null | head -1)
+if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f "k_proj_update" | tee $O/r3f_timeline_neumann_proj.txt; else tail -5 /tmp/tr_n.log; fi
