@@ -358,6 +358,10 @@ def main():
             solver_form = "hoisted chain on the N-sized residual every iteration (BHG_MLP_PROJ=0)"
         elif n_hoist == 0:
             solver_form = "classic chain (BHG_MLP_HOIST=0)"
+    elif fused and args.algo == "neumann":
+        solver_form = ("projected Neumann solver (libbhg default without an accumulator vector): G(v') = G(v) - alpha (G(raw) + shift G(v)) "
+                       "through B x B Gram matrices, nothing N-sized after the first iteration, closing half pass for Rz(v_K); "
+                       "bhg_mlp_proj_iterations = %d" % n_proj) if n_proj == args.steps * K else "classic chain"
     # Region 1b — the same `steps` steps with HALF the iterations, equally free of events: the difference of the two
     # regions is K/2 full iterations per step on the SAME clock as the headline (no per-launch events, no profiler), so
     # the roofline span and the headline agree by construction:  iteration = (t(K) - t(K/2)) / (K/2);
@@ -432,7 +436,7 @@ def main():
                                                                                                                 and solver_form.startswith("fully")) else
                                "bhg_mlp_cg_solve: one whole fused CG-HVP iteration (R-chain + k_cg_alpha + k_outer_all, whose "
                                "epilogue carries the r/p update)" if args.algo == "cg" else
-                               "bhg_mlp_neumann_solve: one whole fused Neumann-HVP iteration"),
+                               "bhg_mlp_neumann_solve: one whole Neumann-HVP iteration (" + ("projected form" if (solver_form or "").startswith("projected") else "classic chain") + ")"),
                     "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "algorithmic_bytes_per_launch": alg,

@@ -1819,16 +1819,21 @@ __device__ __forceinline__ void wsk_body(const WskArgs& a, const int blk) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
   // epilogue operands of this thread's two outputs: requested before the K loop, they land under it
+  // (the three-stage staged form has no registers to spare: it fetches them behind the loop)
+  constexpr bool kLateE = LDSV && D >= 3;
   float e_mask[2], e_rh[2], e_bias[2], e_add[2];
+  auto load_e = [&]() {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = threadIdx.x + 64 * kWskWaves * u;
-    const int64_t idx = (int64_t)(m0 + (e >> 5)) * a.N + n0 + (e & 31);
-    e_mask[u] = a.mask ? a.mask[idx] : 1.f;
-    e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
-    e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
-    e_add[u] = a.addend ? a.addend[idx] : 0.f;
-  }
+    for (int u = 0; u < 2; ++u) {
+      const int e = threadIdx.x + 64 * kWskWaves * u;
+      const int64_t idx = (int64_t)(m0 + (e >> 5)) * a.N + n0 + (e & 31);
+      e_mask[u] = a.mask ? a.mask[idx] : 1.f;
+      e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
+      e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
+      e_add[u] = a.addend ? a.addend[idx] : 0.f;
+    }
+  };
+  if (!kLateE) load_e();
   if (nch_w > 0) {   // (wave-uniform)
     if (LDSV) {
       float* my = wsl_smem + wave * kWslWaveFloats;
@@ -1837,6 +1842,7 @@ __device__ __forceinline__ void wsk_body(const WskArgs& a, const int blk) {
     } else if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, kbeg_w, nch_w, (float)a.scal[S_BETA], acc);
     else wsk_loop<LB, false, D>(pr, m0, n0, kbeg_w, nch_w, 0.f, acc);
   }
+  if (kLateE) load_e();
   if (LDSV) __syncthreads();   // every wave is done with its staging tile before the partial tiles overwrite them
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -1898,6 +1904,7 @@ struct WskGroupArgs {
   int do_alpha; AlphaArgs alpha;   // block blk0[n]: k_cg_alpha's work (the step length needs the same inputs as this iteration's
                                    // Gram products — the end of the R-chain — and nothing of them)
 };
+template <int D>
 __global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
   const int b = blockIdx.x;
   if (b >= g.blk0[g.n]) {
@@ -1910,7 +1917,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
   a.pr[0].A = g.p[i].A; a.pr[0].B = g.p[i].Bm; a.pr[0].lda = g.p[i].K; a.pr[0].ldb = g.p[i].K;
   a.pairs = 1; a.M = g.p[i].M; a.N = g.p[i].N; a.K = g.p[i].K; a.B = g.p[i].B;
   a.out = g.p[i].out; a.ntm = a.M / 32; a.ntn = a.N / 32;
-  wsk_body<LAYOUT_KC, false, 2, true>(a, b - g.blk0[i]);
+  wsk_body<LAYOUT_KC, false, D, true>(a, b - g.blk0[i]);
 }
 
 // BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
@@ -1974,7 +1981,17 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm_wsk<LB, false, 2, true>), grid, block, lds, st, a);
+    static const int wsl_depth = getenv("BHG_WSL_DEPTH") ? atoi(getenv("BHG_WSL_DEPTH")) : 2;   // A/B: register stages of the staged form
+    if (wsl_depth == 3) {
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr3 = true;
+      }
+      hipLaunchKernelGGL((k_gemm_wsk<LB, false, 3, true>), grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((k_gemm_wsk<LB, false, 2, true>), grid, block, lds, st, a);
+    }
     return;
   }
 #define BHG_WSK(BFV, DV) hipLaunchKernelGGL((k_gemm_wsk<LB, BFV, DV>), grid, block, 0, st, a)
@@ -1991,10 +2008,13 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
   const int lds = (int)(sizeof(float) * kWslWaveFloats * kWskWaves);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_wsk_group, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
+  static const int wsl_depth = getenv("BHG_WSL_DEPTH") ? atoi(getenv("BHG_WSL_DEPTH")) : 2;
+  if (wsl_depth == 3) hipLaunchKernelGGL(k_wsk_group<3>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
+  else hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
 
 template <int LA, int LB>

@@ -289,6 +289,10 @@ int64_t bhg_mlp_proj_iterations(void);
  * in direction v_K (`v_last`: the 2L slices of the direction buffer that holds v_K — v0 for even K, v1 for odd K) into the
  * mixed-derivative coefficient of p_final = -alpha * sum_{k=0..K} v_k  (the quantity bhg_mlp_mixed_coeff returns for a
  * materialised p).                                                                                                      */
+/* Round 3: without an accumulator vector bhg_mlp_neumann_solve runs in PROJECTED form by default (BHG_MLP_PROJ != 0, >= 3 layers,
+ * widths % 32 == 0): G(v') = G(v) - alpha (G(raw) + shift G(v)) on batch-sized arrays, nothing N-sized after the first iteration
+ * (v0 / v1 then only carry the biases' and the head weight's slices), and a closing half pass adds Rz(v_K) to the sum itself —
+ * bhg_mlp_neumann_mixed_coeff on the same `fws` then ignores `v_last` (the library remembers per workspace which form ran). */
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff,
                                 float alpha, int K, void* fws, size_t fws_bytes, void* stream);
 

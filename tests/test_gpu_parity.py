@@ -855,6 +855,28 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, monke
         assert rel_c <= tol and rel_u <= tol, (name, rel_c, rel_u)
 
 
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+@pytest.mark.parametrize("ridge,alpha,K", [(0.05, 0.5, 4), (0.0, None, 3), (0.05, None, 1), (0.05, None, 2), (0.3, 0.25, 7)],
+                         ids=lambda v: str(v))
+def test_projected_solvers_edge_cases(algo, ridge, alpha, K, monkeypatch):
+    """The default (fully projected CG / projected Neumann, no solution vector) against the classic chain where the recurrences
+    could go wrong: cg_alpha != 1 (the reference's quirk: the step length uses cg_alpha * Hp, the residual update the
+    un-scaled Hp, cg.py:42-50), no ridge (shift = 0), K = 1 (no recurrence at all), K = 2 (one), a batch that fills two
+    128-row tiles, and an odd iteration count."""
+    lib = _native.load()
+    for dims, B in (([256, 384, 128, 10], 100), ([512, 256, 256, 64, 10], 200)):
+        outs = {}
+        for arm in ("0", "1"):
+            monkeypatch.setenv("BHG_MLP_HOIST", arm)
+            p0 = lib.bhg_mlp_proj_iterations()
+            outs[arm], _ = _run_solver(algo, dims, B, ridge, K, 5 + K, True, alpha=alpha, keep=False)
+            projected = lib.bhg_mlp_proj_iterations() - p0
+            assert projected == (0 if arm == "0" else (K - 1 if algo == "cg" else K)), (arm, projected)
+        rel, _ = rel_err(outs["1"], outs["0"])
+        print(f"{algo} {dims} B={B} ridge={ridge} alpha={alpha} K={K}: projected vs classic {rel:.2e}")
+        assert rel <= 5e-5, (algo, dims, B, ridge, alpha, K, rel)
+
+
 def test_wsk_defaults_per_solver(monkeypatch):
     """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k (mode 2); the
     un-fused CG chain never does; the Neumann solver uses mode 3 (short reductions direct, long R-backward LDS-staged)
