@@ -256,6 +256,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--no-hvp-graph", action="store_true",
                     help="--hvp autograd only: eager launches of the double backward instead of the (opt-in) hipGraph replay")
+    ap.add_argument("--hvp-graph", choices=["solve", "persistent"], default="persistent",
+                    help="--hvp autograd only: capture the K HVPs once per solve, or (default) loss / gradient-with-graph and the "
+                         "HVP once for the whole run (the inner training_step is a static function here)")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
@@ -307,7 +310,7 @@ def main():
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
     else:   # opaque double backward: opt into the hipGraph replay of the K HVPs (betty_amd/hypergradient/_common.py)
-        curr.hypergradient_graph = not args.no_hvp_graph
+        curr.hypergradient_graph = False if args.no_hvp_graph else (True if args.hvp_graph == "solve" else "persistent")
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
     layout = be.layout(vector)
@@ -524,7 +527,9 @@ def main():
                 "hvp": ("analytic R-op HVP on fp32 MFMA, recurrence fused into its output kernels (one pass)" if fused else
                         "analytic R-op HVP on fp32 MFMA (bhg_mlp_hvp) + recurrence kernel" if args.hvp == "analytic" else
                         "analytic closed form on ATen/rocBLAS" if args.hvp == "analytic-aten" else
-                        "pytorch-rocm autograd double backward" + ("" if args.no_hvp_graph else ", captured once per solve and replayed as a HIP graph (opt-in)")),
+                        "pytorch-rocm autograd double backward" + ("" if args.no_hvp_graph else
+                                                                   ", K HVPs captured once per solve and replayed as a HIP graph (opt-in)" if args.hvp_graph == "solve" else
+                                                                   ", loss / gradient-with-graph and HVP captured ONCE for the run and replayed as two HIP graphs (opt-in)")),
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "solver_form": solver_form,
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else

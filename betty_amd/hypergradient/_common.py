@@ -133,7 +133,119 @@ class GraphedHVP:
         return self.out
 
 
-def mixed_vjp(in_grad, prev, neg_x_views: List[torch.Tensor], sync: bool):
+class PersistentOpaqueGraphs:
+    """Opt-in `inner_problem.hypergradient_graph = "persistent"`: the inner problem promises that its ``training_step`` is a
+    STATIC function of (parameters, upper parameters, batch) — same shapes, no data-dependent Python control flow, no host
+    side effects that matter.  Then not only the K HVPs of one solve but the steps of a whole run share two HIP graphs:
+
+        G1   loss = training_step(batch*) ; in_grad = autograd.grad(loss, params, create_graph=True)   (batch* = static copies)
+        G2   hvp  = autograd.grad(in_grad, params, grad_outputs=direction views, retain_graph=True)
+
+    A step is then: copy the batch into batch*, replay G1 (the autograd graph OBJECT of `in_grad` is the one built at capture
+    time; its saved tensors live at fixed addresses inside G1's pool and are refreshed by the replay), K x replay G2, and the
+    usual EAGER mixed second derivative through that autograd graph (with retain_graph=True, so the graph survives the step;
+    DistributedDataParallel hooks fire as always).  First step of a signature: eager (warm-up); second: capture; from the
+    third on: replay.  Anything that changes the signature (parameter storage, batch shapes, direction buffer) recaptures.
+    Not taken under DistributedDataParallel-wrapped upper modules reached inside the capture (their forward does host
+    bookkeeping).  Measured (MI355X, cfg 2, opaque HVP, CG K = 20): see DESIGN.md section 5."""
+
+    def __init__(self):
+        self.sig = None
+        self.state = 0          # 0: nothing seen | 1: warmed up eagerly | 2: captured | -1: gave up
+        self.g1 = self.g2 = None
+        self.static_leaves = self.spec = None
+        self.in_grad = self.out = None
+
+    @staticmethod
+    def _signature(curr, params, batch_leaves, views):
+        leaves = tuple((tuple(t.shape), t.dtype, str(t.device)) if torch.is_tensor(t) else ("leaf", repr(t)) for t in batch_leaves)
+        return (tuple((id(p), p.data_ptr(), tuple(p.shape)) for p in params), leaves, GraphedHVP._key(views))
+
+    def begin_step(self, curr, params, views):
+        """-> (in_grad, hvp_fn, persistent): `persistent` tells mixed_vjp to keep the autograd graph alive."""
+        from torch.utils import _pytree as pytree
+
+        leaves, spec = pytree.tree_flatten(curr.cur_batch)
+        sig = self._signature(curr, params, leaves, views)
+        dev = views[0].device
+        on_default = torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev)
+        if self.state == -1 or on_default:
+            in_grad = inner_gradient(curr)
+            return in_grad, AutogradHVP(in_grad, params), False
+        if sig != self.sig or self.state == 0:      # new signature: an eager step first (warm-up on the capture stream)
+            self.sig, self.state = sig, 1
+            self.g1 = self.g2 = self.in_grad = self.out = None
+            in_grad = inner_gradient(curr)
+            return in_grad, AutogradHVP(in_grad, params), False
+        if self.state == 1:                         # second step of this signature: capture G1 and G2
+            try:
+                self.static_leaves = [t.clone() if torch.is_tensor(t) else t for t in leaves]
+                self.spec = spec
+                static_batch = pytree.tree_unflatten(self.static_leaves, spec)
+                g1 = torch.cuda.CUDAGraph()
+                g1.capture_begin(capture_error_mode="thread_local")
+                try:
+                    loss = curr.training_step_exec(static_batch)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        in_grad = torch.autograd.grad(loss, curr.trainable_parameters(), create_graph=True)
+                finally:
+                    g1.capture_end()
+                g1.replay()
+                g2 = torch.cuda.CUDAGraph()
+                g2.capture_begin(capture_error_mode="thread_local")
+                try:
+                    out = torch.autograd.grad(in_grad, list(params), grad_outputs=views, retain_graph=True)
+                finally:
+                    g2.capture_end()
+                self.g1, self.g2, self.in_grad, self.out, self.state = g1, g2, in_grad, tuple(out), 2
+                GRAPH_STATS["captures"] += 2
+            except Exception as exc:
+                self.state = -1
+                GRAPH_STATS["fallbacks"] += 1
+                warnings.warn(f"betty_amd: persistent hipGraph capture of the inner gradient / HVP failed ({type(exc).__name__}: {exc}); "
+                              "continuing with eager launches", RuntimeWarning)
+                torch.cuda.synchronize(dev)
+                in_grad = inner_gradient(curr)
+                return in_grad, AutogradHVP(in_grad, params), False
+        else:                                       # replay: refresh the static batch, recompute loss / in_grad in place
+            for st, t in zip(self.static_leaves, leaves):
+                if torch.is_tensor(st):
+                    st.copy_(t)
+            self.g1.replay()
+            GRAPH_STATS["replays"] += 1
+
+        def hvp(direction_views):
+            if GraphedHVP._key(direction_views) != self.sig[2]:
+                raise RuntimeError("persistent HVP graph: the direction moved inside a solve")
+            self.g2.replay()
+            GRAPH_STATS["replays"] += 1
+            return self.out
+
+        return self.in_grad, hvp, True
+
+
+def _uses_ddp(problem) -> bool:
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    return any(isinstance(getattr(problem, name, None), DDP) for name in ("fwd", "module"))
+
+
+def persistent_graphs_for(curr, K: int, tensors, prev=None):
+    """The inner problem's PersistentOpaqueGraphs when it opted in with hypergradient_graph = "persistent", else None."""
+    if os.environ.get("BHG_HVP_GRAPH", "") == "0" or K < 1 or not tensors or not tensors[0].is_cuda:
+        return None
+    if _uses_ddp(curr) or (prev is not None and _uses_ddp(prev)):   # a DDP forward does host bookkeeping: not capturable
+        return None
+    if getattr(curr, "hypergradient_graph", False) != "persistent":
+        return None
+    cache = getattr(curr, "_bhg_persistent_graphs", None)
+    if cache is None:
+        cache = curr._bhg_persistent_graphs = PersistentOpaqueGraphs()
+    return cache
+
+
+def mixed_vjp(in_grad, prev, neg_x_views: List[torch.Tensor], sync: bool, retain_graph: bool = False):
     """Final hop to the upper parameters (cg.py:58-68, neumann.py:44-54).
 
     ``neg_x_views`` already holds ``-(alpha * x)``; by linearity of the VJP
@@ -142,6 +254,6 @@ def mixed_vjp(in_grad, prev, neg_x_views: List[torch.Tensor], sync: bool):
     returns None; ``sync=False`` returns the list for ``Problem.set_grads``."""
     upper = prev.trainable_parameters()
     if sync:
-        torch.autograd.backward(in_grad, inputs=upper, grad_tensors=neg_x_views)
+        torch.autograd.backward(in_grad, inputs=upper, grad_tensors=neg_x_views, retain_graph=retain_graph)
         return None
-    return list(torch.autograd.grad(in_grad, upper, grad_outputs=neg_x_views))
+    return list(torch.autograd.grad(in_grad, upper, grad_outputs=neg_x_views, retain_graph=retain_graph))

@@ -11,7 +11,7 @@ streaming kernels (40*N bytes) instead of ~10*T ATen launches moving ~140*N byte
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, solve_stream
+from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, persistent_graphs_for, solve_stream
 from .structured import structured_hvp_for
 
 
@@ -25,26 +25,32 @@ def cg(vector, curr, prev, sync):
     K = int(curr.config.cg_iterations)
     # opaque double backward (no structure, or a structure whose HVP is an autograd callback): replayed as a HIP graph
     graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector, curr)
-    with solve_stream(vector[0].device if vector else None, graphed):
-        return _cg(vector, curr, prev, sync, provider, K, graphed)
+    # hypergradient_graph = "persistent": loss / gradient-with-graph AND the HVP captured once for the whole run
+    persist = persistent_graphs_for(curr, K, vector, prev) if provider is None else None
+    with solve_stream(vector[0].device if vector else None, graphed or persist is not None):
+        return _cg(vector, curr, prev, sync, provider, K, graphed, persist)
 
 
-def _cg(vector, curr, prev, sync, provider, K, graphed):
+def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
     config = curr.config
     be = get_backend()
+    layout = be.layout(vector)
+    x, r, p = layout.state(3)
+    keep_graph = False
     if provider is None:
-        in_grad = inner_gradient(curr)
-        hvp_fn = AutogradHVP(in_grad, curr.parameters())
+        if persist is not None:
+            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.parameters()), layout.views(p, vector))
+        else:
+            in_grad = inner_gradient(curr)
+            hvp_fn = AutogradHVP(in_grad, curr.parameters())
     else:
         in_grad = None
         hvp_fn = provider.prepare()
-    if graphed:
+    if graphed and persist is None:
         hvp_fn = GraphedHVP(hvp_fn)
 
     alpha = float(config.cg_alpha)
     fused = getattr(provider, "fused_cg", None)
-    layout = be.layout(vector)
-    x, r, p = layout.state(3)
     # a provider whose fused solver derives the mixed derivative from batch-sized factors never touches x (see
     # WeightedCEMLP.keep_solution): then x is not even zeroed
     skips = getattr(provider, "fused_cg_skips_solution", None)
@@ -73,4 +79,4 @@ def _cg(vector, curr, prev, sync, provider, K, graphed):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_x, sync, solve=solve)
         return provider.mixed_vjp(neg_x, sync)
-    return mixed_vjp(in_grad, prev, neg_x, sync)
+    return mixed_vjp(in_grad, prev, neg_x, sync, retain_graph=keep_graph)

@@ -8,7 +8,7 @@ ATen launches; the final ``alpha*p`` and the negation are folded into the last i
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, solve_stream
+from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, persistent_graphs_for, solve_stream
 from .structured import structured_hvp_for
 
 
@@ -19,27 +19,32 @@ def neumann(vector, curr, prev, sync):
     K = int(curr.config.neumann_iterations)
     # opaque double backward: captured once per solve, replayed as a HIP graph (see _common.GraphedHVP)
     graphed = (provider is None or getattr(provider, "hvp_is_autograd", False)) and hvp_graph_wanted(K, vector, curr)
-    with solve_stream(vector[0].device if vector else None, graphed):
-        return _neumann(vector, curr, prev, sync, provider, K, graphed)
+    persist = persistent_graphs_for(curr, K, vector, prev) if provider is None else None   # see cg.py
+    with solve_stream(vector[0].device if vector else None, graphed or persist is not None):
+        return _neumann(vector, curr, prev, sync, provider, K, graphed, persist)
 
 
-def _neumann(vector, curr, prev, sync, provider, K, graphed):
+def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
     config = curr.config
     be = get_backend()
+    layout = be.layout(vector)
+    v, p = layout.state(2)
+    keep_graph = False
     if provider is None:
-        in_grad = inner_gradient(curr)
         # neumann.py:39 differentiates w.r.t. trainable_parameters() (cg uses parameters())
-        hvp_fn = AutogradHVP(in_grad, curr.trainable_parameters())
+        if persist is not None:
+            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.trainable_parameters()), layout.views(v, vector))
+        else:
+            in_grad = inner_gradient(curr)
+            hvp_fn = AutogradHVP(in_grad, curr.trainable_parameters())
     else:
         in_grad = None
         hvp_fn = provider.prepare()
-    if graphed:
+    if graphed and persist is None:
         hvp_fn = GraphedHVP(hvp_fn)
 
     alpha = float(config.neumann_alpha)
     fused = getattr(provider, "fused_neumann", None)
-    layout = be.layout(vector)
-    v, p = layout.state(2)
     # a provider whose fused solver derives the mixed derivative from batch-sized factors never touches the accumulator
     skips = getattr(provider, "fused_neumann_skips_solution", None)
     skip_p = bool(fused is not None and alpha != 0.0 and skips is not None and skips(layout, K))
@@ -63,4 +68,4 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_p, sync, solve=solve)
         return provider.mixed_vjp(neg_p, sync)
-    return mixed_vjp(in_grad, prev, neg_p, sync)
+    return mixed_vjp(in_grad, prev, neg_p, sync, retain_graph=keep_graph)

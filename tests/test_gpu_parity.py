@@ -692,6 +692,50 @@ def test_opaque_hvp_replayed_as_a_hip_graph(algo, K, be):
     assert rel <= 2e-5, rel
 
 
+@pytest.mark.parametrize("algo,K", [("cg", 6), ("neumann", 5)])
+def test_opaque_solve_with_persistent_graphs(algo, K, be):
+    """Opt-in `curr.hypergradient_graph = "persistent"`: loss + gradient-with-graph (G1) and the HVP (G2) are captured on the
+    second step and replayed on every later one, while the BATCH and the inner WEIGHTS change from step to step — the
+    hypergradient of every step equals the eager one on the same inputs (sync=False and sync=True), and the counters show the
+    graphs really ran (2 captures; per replayed step 1 + K replays)."""
+    from betty_amd.hypergradient import _common
+
+    dims, B = [256, 384, 128, 10], 100
+    g = torch.Generator().manual_seed(3)
+    runs = {}
+    for arm in ("eager", "persistent"):
+        curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=31)
+        curr.config = Config(type=algo, cg_iterations=K, cg_alpha=1.0, neumann_iterations=K, neumann_alpha=0.05)
+        curr.hypergradient_graph = "persistent" if arm == "persistent" else False
+        vec = [0.1 * d for d in direction]
+        before = dict(_common.GRAPH_STATS)
+        outs = []
+        gg = torch.Generator().manual_seed(77)
+        for step in range(5):
+            x = torch.randn(B, dims[0], generator=gg).to(DEV)
+            y = torch.randint(0, dims[-1], (B,), generator=gg).to(DEV)
+            curr.cur_batch = (x, y)                                      # a NEW batch every step
+            with torch.no_grad():
+                for prm in curr.module.parameters():                     # the optimizer moved the weights in place
+                    prm.add_(0.01 * torch.randn(prm.shape, generator=gg).to(DEV))
+            if step == 4:
+                for q in prev.trainable_parameters():
+                    q.grad = None
+                assert hg.jvp_fn_mapping[algo](vec, curr, prev, True) is None          # sync=True through the kept graph
+                outs.append(_np([q.grad for q in prev.trainable_parameters()]))
+            else:
+                outs.append(_np(hg.jvp_fn_mapping[algo](vec, curr, prev, False)))
+        runs[arm] = outs
+        d = {k: _common.GRAPH_STATS[k] - before[k] for k in before}
+        if arm == "persistent":
+            assert d["captures"] == 2 and d["fallbacks"] == 0 and d["replays"] == 3 * (1 + K) + K, d   # step 1: K, steps 2-4: 1 + K
+        else:
+            assert d == {"captures": 0, "replays": 0, "fallbacks": 0}, d
+    for step, (a, b) in enumerate(zip(runs["persistent"], runs["eager"])):
+        rel, _ = rel_err(a, b)
+        assert rel <= 2e-5, (step, rel)
+
+
 def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
     """A classifier head wider than 32 outputs: the once-per-step passes (forward, deltas, mixed coefficient) run on ATen, the
     K HVPs on the MFMA kernels (no fused solver: bhg_mlp_supports_fused_solve is false) — against the opaque autograd
