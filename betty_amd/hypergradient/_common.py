@@ -155,13 +155,31 @@ class PersistentOpaqueGraphs:
         self.g1 = self.g2 = None
         self.static_leaves = self.spec = None
         self.in_grad = self.out = None
+        self.tracked, self.versions = [], []
+
+    @contextlib.contextmanager
+    def saved_versions(self):
+        """The eager backward through the CAPTURED autograd graph checks that the tensors it saved (weights, upper weights,
+        the static batch) still carry the version numbers of capture time — but optimizers and the batch refresh have written
+        to them in place since (that is the point: same storage, new values, refreshed by the replay of G1).  Around that one
+        backward the version counters are set to their capture-time values and restored afterwards, so every OTHER autograd
+        graph that holds these tensors (the upper loss of the step, say) sees the numbers it expects."""
+        if self.state != 2 or not self.tracked:
+            yield
+            return
+        now = [t._version for t in self.tracked]
+        torch._C._autograd._unsafe_set_version_counter(self.tracked, self.versions)
+        try:
+            yield
+        finally:
+            torch._C._autograd._unsafe_set_version_counter(self.tracked, now)
 
     @staticmethod
     def _signature(curr, params, batch_leaves, views):
         leaves = tuple((tuple(t.shape), t.dtype, str(t.device)) if torch.is_tensor(t) else ("leaf", repr(t)) for t in batch_leaves)
         return (tuple((id(p), p.data_ptr(), tuple(p.shape)) for p in params), leaves, GraphedHVP._key(views))
 
-    def begin_step(self, curr, params, views):
+    def begin_step(self, curr, params, views, prev=None):
         """-> (in_grad, hvp_fn, persistent): `persistent` tells mixed_vjp to keep the autograd graph alive."""
         from torch.utils import _pytree as pytree
 
@@ -199,6 +217,18 @@ class PersistentOpaqueGraphs:
                 finally:
                     g2.capture_end()
                 self.g1, self.g2, self.in_grad, self.out, self.state = g1, g2, in_grad, tuple(out), 2
+                tracked = list(params) + [t for t in self.static_leaves if torch.is_tensor(t)]
+                if prev is not None:
+                    mod = getattr(prev, "module", None)
+                    tracked += list(prev.trainable_parameters()) + (list(mod.buffers()) if mod is not None else [])
+                cmod = getattr(curr, "module", None)
+                tracked += list(cmod.buffers()) if cmod is not None else []
+                seen, uniq = set(), []
+                for t in tracked:
+                    if id(t) not in seen:
+                        seen.add(id(t))
+                        uniq.append(t)
+                self.tracked, self.versions = uniq, [t._version for t in uniq]
                 GRAPH_STATS["captures"] += 2
             except Exception as exc:
                 self.state = -1

@@ -39,7 +39,7 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
     keep_graph = False
     if provider is None:
         if persist is not None:
-            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.parameters()), layout.views(p, vector))
+            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.parameters()), layout.views(p, vector), prev)
         else:
             in_grad = inner_gradient(curr)
             hvp_fn = AutogradHVP(in_grad, curr.parameters())
@@ -79,4 +79,7 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_x, sync, solve=solve)
         return provider.mixed_vjp(neg_x, sync)
-    return mixed_vjp(in_grad, prev, neg_x, sync, retain_graph=keep_graph)
+    if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
+        with persist.saved_versions():
+            return mixed_vjp(in_grad, prev, neg_x, sync, retain_graph=True)
+    return mixed_vjp(in_grad, prev, neg_x, sync)

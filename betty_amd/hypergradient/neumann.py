@@ -33,7 +33,7 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
     if provider is None:
         # neumann.py:39 differentiates w.r.t. trainable_parameters() (cg uses parameters())
         if persist is not None:
-            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.trainable_parameters()), layout.views(v, vector))
+            in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.trainable_parameters()), layout.views(v, vector), prev)
         else:
             in_grad = inner_gradient(curr)
             hvp_fn = AutogradHVP(in_grad, curr.trainable_parameters())
@@ -68,4 +68,7 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_p, sync, solve=solve)
         return provider.mixed_vjp(neg_p, sync)
-    return mixed_vjp(in_grad, prev, neg_p, sync, retain_graph=keep_graph)
+    if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
+        with persist.saved_versions():
+            return mixed_vjp(in_grad, prev, neg_p, sync, retain_graph=True)
+    return mixed_vjp(in_grad, prev, neg_p, sync)
