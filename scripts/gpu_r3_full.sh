@@ -28,12 +28,15 @@ run() { tag=$1; shift; timeout 400 python bench.py --cpu-steps 0 "$@" 2> $O/benc
 import json
 d=json.loads(open('$O/bench_$tag.json').read().strip().splitlines()[-1]); print('== %-18s %.1f steps/s  %.3f ms/step  iter_us %s' % ('$tag', d['value'], d['ms_per_step'], d.get('per_iteration_us')))" 2>&1 | tail -1; }
 run neumann_fused --algo neumann --cg-iters 10
+BHG_MLP_PROJ=0 run neumann_classic_chain --algo neumann --cg-iters 10
 run cg_nofuse --no-fuse
 BHG_MLP_HOIST=0 run cg_classic_chain
 BHG_MLP_PROJ=0 run cg_hoisted_not_projected
 run cg_keep_solution --keep-solution
-run cg_autograd_graph --hvp autograd --steps 60
+run cg_autograd_graph_persistent --hvp autograd --steps 60
+run cg_autograd_graph_per_solve --hvp autograd --steps 60 --hvp-graph solve
 run cg_autograd_eager --hvp autograd --steps 60 --no-hvp-graph
+run neumann_autograd_graph_persistent --hvp autograd --steps 60 --algo neumann --cg-iters 10
 run darts --algo darts
 run cg_global_ws1 --mode global
 bash scripts/gpu_pmc3.sh 2>&1 | tail -40
