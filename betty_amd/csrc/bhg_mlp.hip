@@ -237,8 +237,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   float4 rq0[TN / 32], rq1[TN / 32];   // BF: the second N-side operand of the stage (previous direction)
   float bs0 = 0.f, bs1 = 0.f;          // BF: its weight for the stage's pair (beta or 0), workgroup-uniform
   const float beta = BF ? (float)a.scal[S_BETA] : 0.f;
-  const GemmPair pr0 = a.pr[first];
-  const GemmPair pr1 = a.pr[npairs > 1 ? 1 : first];   // operand bases live in SGPRs, not re-fetched per step
+  // (selects, not indices: a descriptor built inside a kernel — k_hoist — must not be pushed to scratch memory)
+  const GemmPair pr0 = first ? a.pr[1] : a.pr[0];
+  const GemmPair pr1 = (npairs > 1 || first) ? a.pr[1] : a.pr[0];   // operand bases live in SGPRs, not re-fetched per step
   auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32], float4 (&rq)[TN / 32], float& bs) {
     step = min(step, nsteps - 1);
     const bool second = step >= nsteps_pair;          // workgroup-uniform
@@ -2326,7 +2327,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   GemmArgs a{};
   a.pr[0].A = ha.p[i].A; a.pr[0].B = ha.p[i].Bm; a.pr[0].lda = ha.p[i].lda; a.pr[0].ldb = ha.p[i].ldb;
   a.pairs = 1;
-  if (ha.p[i].A2) { a.pr[1].A = ha.p[i].A2; a.pr[1].B = ha.p[i].B2m; a.pr[1].lda = ha.p[i].lda; a.pr[1].ldb = ha.p[i].ldb; a.pairs = 2; }
+  if (ha.p[i].A2) {
+    a.pr[1].A = ha.p[i].A2; a.pr[1].B = ha.p[i].B2m; a.pr[1].lda = ha.p[i].lda; a.pr[1].ldb = ha.p[i].ldb; a.pairs = 2;
+    if (ha.p[i].splits == 2) a.pair_split = 1;   // one workgroup per operand pair: two slabs, half the K loop each
+  }
   a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
   a.out = ha.p[i].slabs; a.ldo = a.N; a.out_rows = ha.Bp; a.nt_out = 1; a.xpose_out = 1;
   const int ntn = a.N / 32, ntm = ha.Bp / kTM;
@@ -2492,7 +2496,7 @@ __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
 // on the well-conditioned full-size variant like every other arm (tests/test_cfg2_goldens.py); fp32 emulation on the CPU
 // beforehand: 1e-6 from the fp64 truth, the same as the direct form and as the reference itself.
 struct ProjProb {
-  float* Gr; float* Gp; const float* Graw; int N;
+  float* Gr; float* Gp; const float* Graw; const float* Graw2 /* second slab of G(raw) or NULL */; int N;
   const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (Gp + bias)   (first layer: Rh_0)
 };
 struct ProjArgs {
@@ -2515,7 +2519,9 @@ __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
   const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
   float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gp = gr;
   if (m < pa.B) {
-    const float4 r0 = ld16(pr.Gr + idx * 4), p0 = ld16(pr.Gp + idx * 4), w0 = ld16(pr.Graw + idx * 4);
+    const float4 r0 = ld16(pr.Gr + idx * 4), p0 = ld16(pr.Gp + idx * 4);
+    float4 w0 = ld16(pr.Graw + idx * 4);
+    if (pr.Graw2) { const float4 w1 = ld16(pr.Graw2 + idx * 4); w0.x += w1.x; w0.y += w1.y; w0.z += w1.z; w0.w += w1.w; }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
     const float alpha = pa.scal ? (float)pa.scal[S_ALPHA_RING + pa.kpar_prev] : pa.alpha, beta = pa.scal ? (float)pa.scal[S_BETA] : 0.f;
@@ -2612,6 +2618,10 @@ struct HoistPlan {
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
+inline bool graw_split() {   // G(raw) products with two operand pairs: one workgroup per pair (A/B: BHG_PROJ_GRAW_SPLIT=0)
+  static const bool on = !(getenv("BHG_PROJ_GRAW_SPLIT") && atoi(getenv("BHG_PROJ_GRAW_SPLIT")) == 0);
+  return on;
+}
 inline int proj_mode() {
   const char* e = getenv("BHG_MLP_PROJ");   // read on every call (A/B in one process); default on
   return e ? atoi(e) : 1;
@@ -2659,7 +2669,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->slab_off[i] = off; off += (size_t)sp * Bp * hp->N[i];
     hp->g_off[i] = off;    off += (size_t)Bp * hp->N[i];
     hp->gr_off[i] = off;   off += (size_t)Bp * hp->N[i];
-    hp->graw_off[i] = off; off += (size_t)Bp * hp->N[i];
+    hp->graw_off[i] = off; off += (size_t)2 * Bp * hp->N[i];   // up to two slabs (one per operand pair)
   }
   hp->dot_blocks = 0;
   for (int i = 0; i < n; ++i) hp->dot_blocks += (Bp * (hp->N[i] / 4) + 255) / 256;
@@ -2855,6 +2865,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       for (int i = 0; i < hp->n; ++i) {
         ProjProb& q = pa.p[i];
         q.Gr = hbase + (cg ? hp->gr_off[i] : hp->g_off[i]); q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
+        // (products with two operand pairs leave one slab per pair, see the G(raw) launch)
+        if (graw_split() && !(hp->bwd[i] == 0 && hp->layer[i] == 0)) q.Graw2 = q.Graw + (size_t)Bp * hp->N[i];
         if (!hp->bwd[i] && hp->layer[i] == 0) { q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0]; }
         pa.blk0[i] = ra.blk0[i];
       }
@@ -3153,8 +3165,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
         }
         q.slabs = hbase + hp->graw_off[i];
-        q.K = Bp; q.N = hp->N[i]; q.splits = 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
-        ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm;
+        q.K = Bp; q.N = hp->N[i]; q.splits = (q.A2 && graw_split()) ? 2 : 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
+        ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm * q.splits;
       }
       ga.blk0[hp->n] = gblk;
       ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
