@@ -1896,7 +1896,7 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) { wsk_bo
 // Several small K-contiguous x K-contiguous products in ONE launch of the LDS-staged form (projected CG: the B x B Gram
 // products T_l = h_l Rh_{l-1}^T, E_l = delta_l Rd_l^T of an iteration, or S_l = h_l h_l^T, D_l = delta_l delta_l^T once per
 // solve): blocks [blk0[i], blk0[i+1]) are the 32 x 32 tiles of problem i.
-constexpr int kWskGroupMax = 32;
+constexpr int kWskGroupMax = 40;   // first iteration of the deepest hoistable net (8 layers): 12 + 13 + 13 problems
 struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; };
 struct WskGroupArgs {
   WskGroupProb p[kWskGroupMax];
@@ -2846,20 +2846,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       if (proj && cg) for (int i = 0; i < hp->n; ++i) ra.p[i].G2 = hbase + hp->gr_off[i];
       ra.n = hp->n; ra.Bp = Bp; ra.B = B; ra.first = cg ? cm.first : 1; ra.scal = cm.scal;
       hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
-      if (proj) {   // the iteration-invariant Gram matrices S_l = h_l h_l^T, D_l = delta_l delta_l^T (once per solve)
-        WskGroupArgs g{};
-        int blk = 0;
-        for (int l = 0; l + 1 < L; ++l) {
-          g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B};
-          g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
-          if (l >= 1) {
-            g.p[g.n] = {m->delta[l], m->delta[l], hbase + hp->d_off[l], Bp, Bp, m->dims[l + 1], B};
-            g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
-          }
-        }
-        g.blk0[g.n] = blk;
-        launch_wsk_group(g, blk, st);
-      }
+      // (projected forms: the iteration-invariant Gram matrices S_l = h_l h_l^T, D_l = delta_l delta_l^T are formed once per
+      //  solve — in the FIRST iteration's Gram launch, below, beside T_l and E_l: nothing needs them before its G(raw) products)
     } else {                   // projected CG: G(r), G(p) from their batch-sized recurrences — nothing N-sized is read
       ProjArgs pa{};
       for (int i = 0; i < hp->n; ++i) {
@@ -3138,6 +3126,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
         g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->e_off[l], Bp, Bp, m->dims[l + 1], B};    // E_l = delta_l Rd_l^T
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+      }
+      for (int l = 0; cm.first && l + 1 < L; ++l) {   // once per solve: S_l, D_l
+        g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B};
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        if (l >= 1) {
+          g.p[g.n] = {m->delta[l], m->delta[l], hbase + hp->d_off[l], Bp, Bp, m->dims[l + 1], B};
+          g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        }
       }
       const bool full = cg && cm.proj >= 2;   // fully projected CG: also Rd_l Rd_l^T and Rh_{l-1} Rh_{l-1}^T (-> raw.raw, k_proj_scalars)
       for (int l = 0; full && l + 1 < L; ++l) {

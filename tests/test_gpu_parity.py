@@ -847,6 +847,7 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
 @pytest.mark.parametrize(
     "dims,B,K",
     [([256, 384, 128, 10], 100, 5), ([512, 256, 256, 64, 10], 128, 4), ([256, 256, 256, 256, 128, 10], 100, 6), ([512, 1024, 64, 10], 200, 3),
+     ([64, 96, 64, 32, 64, 96, 32, 64, 10], 50, 4),   # eight layers: the deepest net the hoisted / projected forms take
      ([3072, 2048, 1536, 384, 10], 100, 20)],
     ids=lambda v: str(v),
 )
