@@ -255,6 +255,42 @@ class PersistentOpaqueGraphs:
         return self.in_grad, hvp, True
 
 
+def _persistent_mixed(self, prev, neg_x_views, sync: bool):
+    """Final hop of a step whose `in_grad` lives in the persistent graph G1: the mixed second derivative (cg.py:58-68) as a THIRD
+    captured graph, G3 = autograd.grad(in_grad, upper, grad_outputs=views) — captured on the first replayed step, replayed
+    afterwards.  `sync=True` accumulates the replayed result into `.grad` (the upper modules are not DDP-wrapped here —
+    persistent graphs are not taken under DDP — so there is no reducer hook a `backward` would have to fire)."""
+    upper = list(prev.trainable_parameters())
+    key = (tuple((id(p), p.data_ptr()) for p in upper), GraphedHVP._key(neg_x_views))
+    if getattr(self, "g3", None) is None or self.g3_key != key:
+        with self.saved_versions():
+            try:
+                g3 = torch.cuda.CUDAGraph()
+                g3.capture_begin(capture_error_mode="thread_local")
+                try:
+                    outs = torch.autograd.grad(self.in_grad, upper, grad_outputs=neg_x_views, retain_graph=True)
+                finally:
+                    g3.capture_end()
+                self.g3, self.g3_key, self.g3_out = g3, key, tuple(outs)
+                GRAPH_STATS["captures"] += 1
+            except Exception as exc:   # stay eager for this hop
+                self.g3 = None
+                warnings.warn(f"betty_amd: hipGraph capture of the mixed second derivative failed ({type(exc).__name__}: {exc})", RuntimeWarning)
+                torch.cuda.synchronize(neg_x_views[0].device)
+                return mixed_vjp(self.in_grad, prev, neg_x_views, sync, retain_graph=True)
+    self.g3.replay()
+    GRAPH_STATS["replays"] += 1
+    grads = [g.clone() for g in self.g3_out]
+    if sync:
+        for p, g in zip(upper, grads):
+            p.grad = g if p.grad is None else p.grad + g
+        return None
+    return grads
+
+
+PersistentOpaqueGraphs.mixed = _persistent_mixed
+
+
 def _uses_ddp(problem) -> bool:
     from torch.nn.parallel import DistributedDataParallel as DDP
 

@@ -80,6 +80,5 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
             return provider.mixed_vjp(neg_x, sync, solve=solve)
         return provider.mixed_vjp(neg_x, sync)
     if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
-        with persist.saved_versions():
-            return mixed_vjp(in_grad, prev, neg_x, sync, retain_graph=True)
+        return persist.mixed(prev, neg_x, sync)
     return mixed_vjp(in_grad, prev, neg_x, sync)

@@ -69,6 +69,5 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
             return provider.mixed_vjp(neg_p, sync, solve=solve)
         return provider.mixed_vjp(neg_p, sync)
     if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
-        with persist.saved_versions():
-            return mixed_vjp(in_grad, prev, neg_p, sync, retain_graph=True)
+        return persist.mixed(prev, neg_p, sync)
     return mixed_vjp(in_grad, prev, neg_p, sync)
