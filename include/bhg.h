@@ -255,6 +255,15 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
  *   hypergradient only needs Rz(x), which the solver accumulates from batch-sized factors (bhg_mlp_cg_mixed_coeff).
  * bhg_mlp_neumann_solve: call bhg_neumann_init(vec, ..., v0, p, ...) first; v0 / v1 ping-pong as the direction (the
  *   R-backward GEMMs of an HVP still read v while its epilogues write v'); on return p = -alpha * p_K.              */
+/* Round 3 — how bhg_mlp_cg_solve runs by default (>= 3 layers, every hidden width and the input width % 32 == 0; otherwise the
+ * round-2 "classic chain" with the recurrence fused into the weight-shaped outputs):
+ *   - the products of the batch with the direction (h_l V_l^T, delta_l V_l) are HOISTED out of the R-chain (BHG_MLP_HOIST) and
+ *   - PROJECTED (BHG_MLP_PROJ): since H p's weight-shaped outputs are outer products of batch-sized factors, those products of
+ *     the residual, and — without a solution vector (x == NULL) — also r.r, p.p, p.Hp, obey batch-sized recurrences through
+ *     B x B Gram matrices.  After the first iteration no N-sized state vector is read or written: r and p then only carry the
+ *     biases' and the head weight's slices; on return they do NOT hold the final residual / direction of the big slices.
+ *   With x != NULL the N-sized r, p, x are maintained as cg.py:49-53 has them (projection level 1).
+ * Same results to fp32 rounding (tests/test_cfg2_goldens.py holds every arm to the reference's CPU run at full size).        */
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m);
 size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m);
 int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
