@@ -412,6 +412,11 @@ def main():
     if not finite:
         raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
     out = None
+    one_pass_solves = 0
+    if args.mode == "global":
+        from betty_amd.global_hvp import ONE_PASS_STATS
+
+        one_pass_solves = ONE_PASS_STATS["solves"]
     if rank == 0:
         # replica mode: every rank completes `steps` independent hypergradient steps; global mode: the ranks share ONE
         # problem (global batch = world x local batch) and complete `steps` steps together
@@ -535,7 +540,10 @@ def main():
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else
                                     "not materialised: the mixed second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), "
                                     "accumulated from batch-sized factors"),
-                "parallelism": ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world)
+                "parallelism": (("global batch over %d rank(s), one-pass form: replicated x / r / p, per iteration ONE 8-byte all-reduce (p.H_data p) "
+                                 "and ONE 4N-byte all-reduce (mean of the locally updated residuals); %d solves took it" % (world, one_pass_solves))
+                                if one_pass_solves else
+                                ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world))
                 if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,
                 "lib_sha256": lib_sha256()[:16],

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("BHG_LIB") or os.path.join(_HERE, "csrc", "libbhg.so")
 BHG_CHUNK_ELEMS = 4096
 BHG_FLAT_ALIGN = 64
 BHG_CG_AUTO, BHG_CG_STREAM, BHG_CG_RESIDENT = 0, 1, 2
+BHG_CG_GLOBAL_CHAIN, BHG_CG_GLOBAL_UPDATE, BHG_CG_GLOBAL_DOTS = 0, 1, 2   # phases of bhg_mlp_cg_global_phase
 
 
 class NativeLibraryError(RuntimeError):
@@ -121,6 +122,11 @@ SYMBOLS = {
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_float, c_float, c_void_p,
          c_void_p, c_size_t, c_void_p],
+    ),
+    "bhg_mlp_cg_global_phase": (
+        c_int,
+        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
+         c_float, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_neumann_solve": (

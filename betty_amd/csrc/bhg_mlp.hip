@@ -836,6 +836,9 @@ struct AlphaArgs {
   // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
   const float* rz; double* rzx; int nrz; int first;
   int kpar;   // iteration parity (S_ALPHA_RING slot)
+  // global-batch CG (bhg_mlp_cg_global_phase): the data part of p.Hp is the SUM over the ranks of what k_php_local left on
+  // each of them (all-reduced by the caller), times inv_world — the T partials of this rank alone are not read
+  const double* php_ext; double inv_world;
 };
 // (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
 //  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
@@ -884,7 +887,8 @@ __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool wr
     }
     const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
     const double pp = a.nPP > 0 ? tot[3] : a.scal[S_PP];
-    const double php = (tot[0] + tot[1] + tot[2]) + (double)a.shift * pp;
+    const double php_data = a.php_ext ? a.php_ext[0] * a.inv_world : (tot[0] + tot[1] + tot[2]);
+    const double php = php_data + (double)a.shift * pp;
     const double den = (double)a.cg_alpha * php;
     const float alpha = (float)rr / (float)den;
     if (writer) {
@@ -910,6 +914,72 @@ __device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool wr
   return s_alpha;
 }
 __global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) { (void)alpha_compute(a, true); }
+
+// Global-batch CG: this rank's share of p.H_data p — the three partial arrays of the R-chain summed exactly as alpha_compute
+// sums them (same strides, same combine order), left as ONE double for the caller's all-reduce.
+__global__ __launch_bounds__(kThreads) void k_php_local(AlphaArgs a, double* __restrict__ out) {
+  __shared__ double red[3][kWaves];
+  const int tid = threadIdx.x;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = tid; i < a.B; i += kThreads) acc[0] += a.partT1[i];
+  if (a.partT2h) for (int i = tid; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
+  for (int i = tid; i < a.nT2; i += kThreads) acc[2] += a.partT2[i];
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double v = wave_sum(acc[q]);
+    if (lane == 0) red[q][w] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWaves; ++i) t += red[q][i];
+      tot[q] = t;
+    }
+    out[0] = (tot[0] + tot[1]) + tot[2];
+  }
+}
+
+// Global-batch CG, after the residual's all-reduce: r'.r', r'.p, p.p over the whole flat vectors (p = the direction of the
+// iteration just finished) in the slot layout k_cg_beta reads — what the fused epilogues' partials are in the one-rank
+// solver, where every tile sees the final r' (here it only exists after the exchange).  8*N bytes; fixed order per block.
+__global__ __launch_bounds__(kThreads) void k_cg_global_dots(const bhg_chunk* __restrict__ chunks, int n_chunks,
+                                                             const float* __restrict__ r, const float* __restrict__ p,
+                                                             double* __restrict__ part, int stride, int nslots) {
+  __shared__ double red[kWaves];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const bhg_chunk ck = chunks[c];
+    float4 a[kVecPerThread], q[kVecPerThread];
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      const int e = 4 * (threadIdx.x + kThreads * i);
+      a[i] = ld4(r + ck.flat_off, e, ck.len);
+      q[i] = ld4(p + ck.flat_off, e, ck.len);
+    }
+#pragma unroll
+    for (int i = 0; i < kVecPerThread; ++i) {
+      a0 += (double)a[i].x * a[i].x + (double)a[i].y * a[i].y + (double)a[i].z * a[i].z + (double)a[i].w * a[i].w;
+      a1 += (double)a[i].x * q[i].x + (double)a[i].y * q[i].y + (double)a[i].z * q[i].z + (double)a[i].w * q[i].w;
+      a2 += (double)q[i].x * q[i].x + (double)q[i].y * q[i].y + (double)q[i].z * q[i].z + (double)q[i].w * q[i].w;
+    }
+  }
+  const double s0 = block_sum(a0, red);
+  const double s1 = block_sum(a1, red);
+  const double s2 = block_sum(a2, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s0;
+    part[stride + blockIdx.x] = s1;
+    part[2 * (int64_t)stride + blockIdx.x] = s2;
+    for (int i = gridDim.x + blockIdx.x; i < nslots; i += gridDim.x) {   // the slots no block of this launch owns
+      part[i] = 0.0; part[stride + i] = 0.0; part[2 * (int64_t)stride + i] = 0.0;
+    }
+  }
+}
 
 // R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
 // G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
@@ -2752,6 +2822,10 @@ struct ChainMode {
   const BetaArgs* beta; int beta_blocks;   // hoisted form: k_cg_beta's work rides in k_hoist's launch (iterations > 0)
   int proj;                     // hoisted: direction products from batch-sized recurrences (k_proj_update); CG: 1 / 2, Neumann: 1
   int stop_after_head;          // projected Neumann: the closing pass that only adds Rz(v_K) to the accumulated Rz sums
+  // global-batch CG (bhg_mlp_cg_global_phase): the iteration is cut where the ranks must talk.
+  //   gphase 1: the R-chain only; this rank's share of p.H_data p -> php[0] (k_php_local)
+  //   gphase 2: step length from the all-reduced php[0] * inv_world, then the outputs with their epilogues
+  int gphase; double* php; double inv_world;
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2813,7 +2887,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   // ---- hoisted form: every direction product in ONE grouped launch, then the chain with the constant weights only ---------
   HeadFuse head_fuse{};
   bool fuse_head = false;
-  if (hp) {
+  const bool do_chain = cm.gphase != 2;
+  if (hp && do_chain) {
     float* hbase = cm.ws->hoist;
     HoistArgs ha{};
     HoistRedArgs ra{};
@@ -2907,7 +2982,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
   }
   // ---- R-forward ------------------------------------------------------------------------------------
-  for (int l = 0; l < L && !hp; ++l) {
+  for (int l = 0; l < L && !hp && do_chain; ++l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
@@ -3045,9 +3120,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     aa.partRR = cm.partRR_old; aa.nRR = cm.nRR_old;
     aa.cg_alpha = cm.cg_alpha; aa.shift = cm.shift; aa.scal = cm.scal;
     aa.rz = cm.ws->rz; aa.rzx = cm.ws->rzx; aa.nrz = B * m->dims[L]; aa.first = cm.first; aa.kpar = cm.kpar;
+    if (cm.gphase == 2) { aa.php_ext = cm.php; aa.inv_world = cm.inv_world; }
   }
   // ---- R-backward (main stream) [overlapped with the weight-shaped outputs on the side stream unless FUSE_CG] ----------
-  for (int l = L - 1; l >= 1 && !hp; --l) {
+  for (int l = L - 1; l >= 1 && !hp && do_chain; --l) {
     if (!single) {   // Rd_l is ready on the main stream here: hand H(W_l) to the side stream
       if (no_side) {
         launch_outer(l, st);
@@ -3103,6 +3179,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
   }
 
+  if (cg && cm.gphase == 1) {   // global-batch CG: the chain is done; this rank's p.H_data p for the caller's all-reduce
+    hipLaunchKernelGGL(k_php_local, dim3(1), dim3(kThreads), 0, st, aa, cm.php);
+    BHG_HIP_CHECK(hipGetLastError());
+    return BHG_OK;
+  }
   if (single) {
     // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
     // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
@@ -3395,6 +3476,103 @@ static int solve_common_checks(const bhg_mlp* m, const int64_t* starts, const vo
   return BHG_OK;
 }
 
+// Everything one iteration of the fused CG solver needs besides its index (built per call: a few hundred bytes of host work).
+struct CgCtx {
+  const bhg_mlp* m; float* x; float* r; float* p; const int64_t* starts; const bhg_chunk* chunks_dev; int n_chunks, K;
+  float cg_alpha, shift;
+  FusedWs w; double* scal; const double* partR0; int n_init, pgrid, bgrid;
+  bool lazy, hoist; int proj_level;
+  BetaArgs ba; HoistPlan hplan;
+  const void* dir[2 * BHG_MLP_MAX_LAYERS];
+};
+// global: the global-batch solver (bhg_mlp_cg_global_phase) — lazy direction, N-sized residual (it is what the ranks exchange)
+static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
+                        int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws, void* fws, bool global) {
+  c->m = m; c->x = x; c->r = r; c->p = p; c->starts = starts; c->chunks_dev = chunks_dev; c->n_chunks = n_chunks; c->K = K;
+  c->cg_alpha = cg_alpha; c->shift = hvp_shift;
+  carve_fused_ws(m, fws, &c->w);
+  char* wsb = static_cast<char*>(ws);
+  c->scal = reinterpret_cast<double*>(wsb + kWsScal);
+  c->partR0 = reinterpret_cast<const double*>(wsb + kWsPartR);   // r.r partials of bhg_cg_init (r = p there)
+  c->n_init = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
+  for (int i = 0; i < 2 * m->L; ++i) c->dir[i] = p + starts[i];
+  c->pgrid = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
+  // Direction update between two iterations: lazy (default; see k_cg_beta) or the 12*N-byte k_cg_pdir pass (A/B switch)
+  static const bool eager = getenv("BHG_CG_EAGER_P") != nullptr;
+  c->lazy = global || !eager;
+  BetaArgs& ba = c->ba;
+  ba = BetaArgs{};
+  int small_total = 0;
+  {
+    const bool head = use_head(m);
+    ba.stride = c->w.nRR; ba.n = c->w.nRR; ba.scal = c->scal; ba.r = r; ba.p = p;
+    for (int l = 0; l < m->L; ++l) {   // biases
+      ba.off[ba.nt] = starts[2 * l + 1]; ba.len[ba.nt] = m->dims[l + 1]; small_total += ba.len[ba.nt]; ++ba.nt;
+    }
+    if (head) {                        // narrow head weight
+      ba.off[ba.nt] = starts[2 * (m->L - 1)]; ba.len[ba.nt] = m->dims[m->L] * m->dims[m->L - 1]; small_total += ba.len[ba.nt]; ++ba.nt;
+    }
+  }
+  c->bgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;   // one element of the small slices per thread
+  c->hplan.ok = false;
+  if (c->lazy && hoist_mode() != 0) hoist_plan(m, &c->hplan);
+  c->hoist = c->lazy && c->hplan.ok;
+  // projection level: 1 = G(r) by recurrence, the N-sized r / p still updated by k_outer_all (needed when the caller wants x);
+  // 2 = fully projected (default without a solution vector): no N-sized state after the first iteration
+  // (BHG_MLP_PROJ: 0 off | 1 default | 9 level 1 even without a solution vector — the A/B arm of level 2)
+  c->proj_level = (!c->hoist || proj_mode() == 0 || global) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
+}
+// gphase 0: the whole iteration (one rank) | 1: up to this rank's p.H_data p | 2: from the step length on (see ChainMode)
+static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_world, hipStream_t st) {
+  const bhg_mlp* m = c->m;
+  FusedWs& w = c->w;
+  const int K = c->K;
+  const bool lazy = c->lazy, hoist = c->hoist;
+  hipEvent_t ta, tb, tc, td;
+  const bool timed = gphase == 0 && span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
+  const bool timed_it = gphase == 0 && span_begin(BHG_TIMING_MLP_CG_ITER, &tc, &td);
+  if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
+  if (lazy && k > 0 && gphase != 2) {   // beta, p.p of the coming direction, direction update of the small slices
+    c->ba.part = w.partRR[k & 1];
+    // hoisted, not projected: inside k_hoist; fully projected: k_proj_scalars (end of the last iteration) + k_proj_update
+    if (!hoist || c->proj_level == 1) hipLaunchKernelGGL(k_cg_beta, dim3(c->bgrid), dim3(kThreads), 0, st, c->ba);
+  }
+  if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
+  ChainMode cm{};
+  cm.mode = FUSE_CG;
+  cm.fa = c->r; cm.fb = c->x; cm.fd = c->p; cm.starts = c->starts;
+  cm.shift = c->shift; cm.cg_alpha = c->cg_alpha;
+  cm.apply_out = k == K - 1; cm.out_scale = -c->cg_alpha;   // cg.py:56 and the negation of cg.py:59/68
+  cm.ws = &w; cm.scal = c->scal;
+  cm.partRR_old = c->partR0;            // k > 0: r.r is the scalar scal[S_RR_NEW] (k_cg_beta / k_cg_pdir of the last iteration)
+  cm.nRR_old = k == 0 ? c->n_init : 0;
+  cm.partPP = k == 0 ? c->partR0 : w.partPP;   // p = r after the init, so p.p = r.r
+  cm.nPP = k == 0 ? c->n_init : (lazy ? 0 : c->pgrid);
+  cm.partRR_new = w.partRR[(k + 1) & 1];
+  // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
+  cm.lazy = lazy;
+  // x is read and written every other iteration (FuseArgs.x_mode): even iterations defer, odd ones catch up
+  static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
+  cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
+  if (!c->x) cm.x_mode = 1;
+  // Without a solution vector the LAST iteration ends with its step length: alpha_{K-1} completes Rz(x) (k_cg_alpha), and
+  // nothing reads the residual, the direction or x of cg.py:49-53 after it — the weight-shaped outputs are not computed.
+  cm.skip_outputs = (!c->x && k == K - 1) ? 1 : 0;
+  cm.first = k == 0;
+  cm.kpar = k & 1;
+  cm.hoist = hoist ? &c->hplan : nullptr;
+  cm.beta = &c->ba; cm.beta_blocks = c->bgrid;
+  cm.proj = c->proj_level;
+  cm.gphase = gphase; cm.php = php; cm.inv_world = inv_world;
+  if (int rc = run_chain(m, c->dir, cm, st)) return rc;
+  if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
+  if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
+    hipLaunchKernelGGL(k_cg_pdir, dim3(c->pgrid), dim3(kThreads), 0, st, c->chunks_dev, c->n_chunks, (const float*)c->r, c->p,
+                       (const double*)w.partRR[(k + 1) & 1], w.nRR, w.partPP, c->scal);
+  if (timed_it) BHG_HIP_CHECK(hipEventRecord(td, st));
+  return BHG_OK;
+}
+
 int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
                      const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
                      void* fws, size_t fws_bytes, void* stream) {
@@ -3407,82 +3585,49 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   BHG_REQUIRE(K >= 0 && n_chunks > 0, "bad size");
   if (K == 0) return BHG_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  FusedWs w;
-  carve_fused_ws(m, fws, &w);
-  char* wsb = static_cast<char*>(ws);
-  double* scal = reinterpret_cast<double*>(wsb + kWsScal);
-  const double* partR0 = reinterpret_cast<const double*>(wsb + kWsPartR);   // r.r partials of bhg_cg_init (r = p there)
-  const int n_init = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
-  const void* dir[2 * BHG_MLP_MAX_LAYERS];
-  for (int i = 0; i < 2 * m->L; ++i) dir[i] = p + starts[i];
-  const int pgrid = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
-  // Direction update between two iterations: lazy (default; see k_cg_beta) or the 12*N-byte k_cg_pdir pass (A/B switch)
-  static const bool eager = getenv("BHG_CG_EAGER_P") != nullptr;
-  const bool lazy = !eager;
-  BetaArgs ba{};
-  int small_total = 0;
-  {
-    const bool head = use_head(m);
-    ba.stride = w.nRR; ba.n = w.nRR; ba.scal = scal; ba.r = r; ba.p = p;
-    for (int l = 0; l < m->L; ++l) {   // biases
-      ba.off[ba.nt] = starts[2 * l + 1]; ba.len[ba.nt] = m->dims[l + 1]; small_total += ba.len[ba.nt]; ++ba.nt;
-    }
-    if (head) {                        // narrow head weight
-      ba.off[ba.nt] = starts[2 * (m->L - 1)]; ba.len[ba.nt] = m->dims[m->L] * m->dims[m->L - 1]; small_total += ba.len[ba.nt]; ++ba.nt;
-    }
+  CgCtx c;
+  cg_ctx_init(&c, m, x, r, p, starts, chunks_dev, n_chunks, K, cg_alpha, hvp_shift, ws, fws, false);
+  for (int k = 0; k < K; ++k)
+    if (int rc = cg_iteration(&c, k, 0, nullptr, 1.0, st)) return rc;
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// ---- global-batch CG: ONE inner problem whose batch is spread over `world` ranks (one process per GPU) --------------------------
+// State x, r, p REPLICATED on every rank (bit-identical: every scalar below is computed from identical or all-reduced data);
+// the Hessian is the mean over the ranks of the local ones (+ shift * I).  With the same r, p and step length on every rank,
+//     r - alpha (mean_g H_g) p  =  mean_g ( r - alpha H_g p ):
+// the one-pass chain with its fused epilogues runs on every rank AS IS on the local batch, and the MEAN of the locally updated
+// residuals is the global one.  Per iteration the ranks exchange
+//     8 bytes   this rank's p.H_data p (batch-sized factors of the R-chain)      SUM   before the step length
+//     4*N bytes the locally updated residual                                     MEAN  after the outputs
+// and nothing else: x += alpha p is replicated work on identical data; r'.r', r'.p, p.p come from one 8*N-byte pass over the
+// exchanged residual (identical on every rank, so beta is too).  The last iteration exchanges the 8 bytes only (nothing reads its
+// residual).  The caller drives, per iteration k:
+//     phase BHG_CG_GLOBAL_CHAIN;  all-reduce(SUM) php[0];  phase BHG_CG_GLOBAL_UPDATE;
+//     if (k + 1 < K) { all-reduce(MEAN) r;  phase BHG_CG_GLOBAL_DOTS; }
+// on ONE stream (the collectives ordered with it).  world == 1 needs no collective and gives bhg_mlp_cg_solve's iteration with
+// the residual's dot products taken in a pass of their own.
+int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
+                            int n_chunks, int k, int K, int phase, int world, double* php, float cg_alpha, float hvp_shift,
+                            void* ws, void* fws, size_t fws_bytes, void* stream) {
+  if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
+  BHG_REQUIRE(r && p && ws && chunks_dev && php, "NULL argument");
+  BHG_REQUIRE(K > 0 && k >= 0 && k < K && n_chunks > 0 && world >= 1, "bad size");
+  BHG_REQUIRE(phase == BHG_CG_GLOBAL_CHAIN || phase == BHG_CG_GLOBAL_UPDATE || phase == BHG_CG_GLOBAL_DOTS, "unknown phase");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CgCtx c;
+  cg_ctx_init(&c, m, x, r, p, starts, chunks_dev, n_chunks, K, cg_alpha, hvp_shift, ws, fws, true);
+  if (phase == BHG_CG_GLOBAL_DOTS) {
+    BHG_REQUIRE(k + 1 < K, "the last iteration has no direction update");
+    int grid = n_chunks < c.w.nRR ? n_chunks : c.w.nRR;
+    if (grid > kMaxBlocks) grid = kMaxBlocks;
+    hipLaunchKernelGGL(k_cg_global_dots, dim3(grid), dim3(kThreads), 0, st, chunks_dev, n_chunks, (const float*)r, (const float*)p,
+                       c.w.partRR[(k + 1) & 1], c.w.nRR, c.w.nRR);
+    BHG_HIP_CHECK(hipGetLastError());
+    return BHG_OK;
   }
-  const int bgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;   // one element of the small slices per thread
-  HoistPlan hplan;
-  hplan.ok = false;
-  if (lazy && hoist_mode() != 0) hoist_plan(m, &hplan);
-  const bool hoist = lazy && hplan.ok;
-  // projection level: 1 = G(r) by recurrence, the N-sized r / p still updated by k_outer_all (needed when the caller wants x);
-  // 2 = fully projected (default without a solution vector): no N-sized state after the first iteration
-  // (BHG_MLP_PROJ: 0 off | 1 default | 9 level 1 even without a solution vector — the A/B arm of level 2)
-  const int proj_level = (!hoist || proj_mode() == 0) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
-  for (int k = 0; k < K; ++k) {
-    hipEvent_t ta, tb, tc, td;
-    const bool timed = span_begin(BHG_TIMING_MLP_HVP, &ta, &tb);
-    const bool timed_it = span_begin(BHG_TIMING_MLP_CG_ITER, &tc, &td);
-    if (timed_it) BHG_HIP_CHECK(hipEventRecord(tc, st));
-    if (lazy && k > 0) {   // beta, p.p of the coming direction, direction update of the small slices
-      ba.part = w.partRR[k & 1];
-      // hoisted, not projected: inside k_hoist; fully projected: k_proj_scalars (end of the last iteration) + k_proj_update
-      if (!hoist || proj_level == 1) hipLaunchKernelGGL(k_cg_beta, dim3(bgrid), dim3(kThreads), 0, st, ba);
-    }
-    if (timed) BHG_HIP_CHECK(hipEventRecord(ta, st));
-    ChainMode cm{};
-    cm.mode = FUSE_CG;
-    cm.fa = r; cm.fb = x; cm.fd = p; cm.starts = starts;
-    cm.shift = hvp_shift; cm.cg_alpha = cg_alpha;
-    cm.apply_out = k == K - 1; cm.out_scale = -cg_alpha;   // cg.py:56 and the negation of cg.py:59/68
-    cm.ws = &w; cm.scal = scal;
-    cm.partRR_old = partR0;            // k > 0: r.r is the scalar scal[S_RR_NEW] (k_cg_beta / k_cg_pdir of the last iteration)
-    cm.nRR_old = k == 0 ? n_init : 0;
-    cm.partPP = k == 0 ? partR0 : w.partPP;   // p = r after the init, so p.p = r.r
-    cm.nPP = k == 0 ? n_init : (lazy ? 0 : pgrid);
-    cm.partRR_new = w.partRR[(k + 1) & 1];
-    // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
-    cm.lazy = lazy;
-    // x is read and written every other iteration (FuseArgs.x_mode): even iterations defer, odd ones catch up
-    static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
-    cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
-    if (!x) cm.x_mode = 1;
-    // Without a solution vector the LAST iteration ends with its step length: alpha_{K-1} completes Rz(x) (k_cg_alpha), and
-    // nothing reads the residual, the direction or x of cg.py:49-53 after it — the weight-shaped outputs are not computed.
-    cm.skip_outputs = (!x && k == K - 1) ? 1 : 0;
-    cm.first = k == 0;
-    cm.kpar = k & 1;
-    cm.hoist = hoist ? &hplan : nullptr;
-    cm.beta = &ba; cm.beta_blocks = bgrid;
-    cm.proj = proj_level;
-    if (int rc = run_chain(m, dir, cm, st)) return rc;
-    if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
-    if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
-      hipLaunchKernelGGL(k_cg_pdir, dim3(pgrid), dim3(kThreads), 0, st, chunks_dev, n_chunks, (const float*)r, p,
-                         (const double*)w.partRR[(k + 1) & 1], w.nRR, w.partPP, scal);
-    if (timed_it) BHG_HIP_CHECK(hipEventRecord(td, st));
-  }
+  if (int rc = cg_iteration(&c, k, phase == BHG_CG_GLOBAL_CHAIN ? 1 : 2, php, 1.0 / (double)world, st)) return rc;
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

@@ -19,6 +19,19 @@ layers and all ranks hold equally sized batches):
 Collectives run on torch.distributed's stream for the group (RCCL over xGMI with backend "nccl"); the next HVP cannot
 start before the direction is gathered, so the overlap available inside one solve is RCCL's own pipelining; the final
 M-sized exchange overlaps with the caller's next kernels like any asynchronous collective.
+
+ONE-PASS form (round 3; taken whenever the inner problem's structure has a fused solver — ``provider.fused_cg_global_ready``):
+the state is REPLICATED instead of sharded, and the one-pass iteration of ``bhg_mlp_cg_solve`` (recurrence in the epilogues
+of the weight-shaped outputs, no N-sized H p) runs on every rank's batch unchanged.  With identical r, p and step length,
+
+    r - alpha * mean_g(H_g) p  ==  mean_g (r - alpha * H_g p),
+
+so per iteration the ranks exchange 8 bytes (all-reduce SUM of p.H_data p, which is a sum over samples of batch-sized
+factors) before the step length and 4*N bytes (all-reduce MEAN of the locally updated residual) after the outputs — two
+collectives, none in the last iteration but the 8-byte one; x += alpha p and the dot products of the exchanged residual are
+replicated work on identical data (include/bhg.h: bhg_mlp_cg_global_phase).  CG is a chain — the next matvec needs the
+whole exchanged residual's beta — so inside a solve the large collective has nothing to hide behind; what it buys is one
+collective of N instead of reduce-scatter + all-gather + two partial all-reduces, and the fused kernels.
 """
 from __future__ import annotations
 
@@ -73,6 +86,65 @@ class _State:
 _STATES = {}
 
 
+def all_reduce_mean(flat: torch.Tensor, world: int, group) -> None:
+    """flat <- mean over ranks, bit-identical on every rank.  RCCL: one all-reduce with the AVG operator; gloo (CPU tests)
+    has no AVG."""
+    if _backend_name(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+
+
+class _OnePassState:
+    def __init__(self, full_layout):
+        self.v = full_layout.new_flat()
+        self.php = torch.zeros(1, dtype=torch.float64, device=full_layout.device)
+
+
+_ONE_PASS = {}
+ONE_PASS_STATS = {"solves": 0, "scalar_all_reduces": 0, "residual_all_reduces": 0}   # test / measurement hook
+
+
+def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: float, G: int, group):
+    """The replicated-state form described in the module docstring; returns what cg_global returns."""
+    from . import _native  # noqa: PLC0415
+
+    st = _ONE_PASS.get(id(full))
+    if st is None:
+        st = _ONE_PASS[id(full)] = _OnePassState(full)
+    x, r, p = full.state(3)
+    skip_x = bool(provider.fused_cg_global_skips_solution(full, K))
+    # right-hand side: the mean over the ranks of the local gradients of the upper loss
+    be.flatten(full, vector, st.v, 1.0 / G)
+    if G > 1:
+        dist.all_reduce(st.v, op=dist.ReduceOp.SUM, group=group)
+    be.cg_init(full, full.views(st.v, vector), None if skip_x else x, r, p)     # x = 0, r = p = v, partials of r.r
+    ONE_PASS_STATS["solves"] += 1
+    for k in range(K):
+        provider.cg_global_phase(full, x, r, p, k, K, _native.BHG_CG_GLOBAL_CHAIN, G, st.php, alpha)
+        if G > 1:
+            dist.all_reduce(st.php, op=dist.ReduceOp.SUM, group=group)          # 8 bytes
+            ONE_PASS_STATS["scalar_all_reduces"] += 1
+        provider.cg_global_phase(full, x, r, p, k, K, _native.BHG_CG_GLOBAL_UPDATE, G, st.php, alpha)
+        if k + 1 < K:
+            if G > 1:
+                all_reduce_mean(r, G, group)                                    # 4*N bytes
+                ONE_PASS_STATS["residual_all_reduces"] += 1
+            provider.cg_global_phase(full, x, r, p, k, K, _native.BHG_CG_GLOBAL_DOTS, G, st.php, alpha)
+    solve = provider.cg_global_finish(full, K, alpha)
+    neg_x = full.views(x, vector)
+    if solve is not True:
+        out = provider.mixed_vjp(neg_x, sync, solve=solve)
+    else:
+        out = provider.mixed_vjp(neg_x, sync)
+    if sync:
+        return None
+    from .distributed import exchange_async  # noqa: PLC0415
+
+    return [t.clone() for t in exchange_async(out, group).wait()]
+
+
 def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = None):
     """Same signature and result convention as ``cg`` (betty/hypergradient/cg.py:8-70); ``vector`` is this rank's
     gradient of ITS share of the upper loss (the global one is the mean over ranks).  Returns the GLOBAL hypergradient
@@ -94,6 +166,11 @@ def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = Non
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
 
     full = be.layout(vector)
+    K = int(config.cg_iterations)
+    alpha = float(config.cg_alpha)
+    ready = getattr(provider, "fused_cg_global_ready", None)
+    if ready is not None and K > 0 and alpha != 0.0 and ready(full, K):
+        return _cg_global_one_pass(vector, prev, sync, provider, be, full, K, alpha, G, group)
     key = (id(full), G)
     st = _STATES.get(key)
     if st is None:
@@ -108,8 +185,6 @@ def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = Non
     all_gather_flat(st.p, st.p_full, group)
     p_views = full.views(st.p_full, vector)
 
-    K = int(config.cg_iterations)
-    alpha = float(config.cg_alpha)
     for k in range(K):
         hvp = hvp_fn(p_views)                                        # H_local p (cg.py:39-41), this rank's batch
         be.flatten(full, hvp, st.h_full, 1.0 / G)

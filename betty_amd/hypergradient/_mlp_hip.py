@@ -231,6 +231,29 @@ class HipMLPState:
         self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=keep_x)
         return self._solve
 
+    # ---- global-batch CG (csrc/bhg_mlp.hip: bhg_mlp_cg_global_phase; driven by betty_amd/global_hvp.py) --------------------
+    solution_free = True   # keep_x=False is honoured: the mixed coefficient then comes from the accumulated Rz(x)
+
+    def cg_global_phase(self, layout, x, r, p, k: int, K: int, phase: int, world: int, php, cg_alpha: float, shift: float,
+                        keep_x: bool = True) -> None:
+        """One phase of one iteration of the global-batch CG solver on THIS rank's share of the batch (include/bhg.h);
+        ``php`` is a one-element float64 device tensor the caller all-reduces between CHAIN and UPDATE."""
+        fws, starts = self._fused_args(layout)
+        if k == 0 and phase == _native.BHG_CG_GLOBAL_CHAIN:
+            self._solve = None   # the workspace an earlier solve's token refers to is being rewritten
+        _native.check(
+            self.lib.bhg_mlp_cg_global_phase(ctypes.byref(self.desc), x.data_ptr() if keep_x else None, r.data_ptr(), p.data_ptr(),
+                                             starts, layout.chunks_dev.data_ptr(), layout.n_chunks, int(k), int(K), int(phase),
+                                             int(world), php.data_ptr(), float(cg_alpha), float(shift),
+                                             layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
+            "bhg_mlp_cg_global_phase",
+        )
+
+    def cg_global_finish(self, layout, K: int, cg_alpha: float, keep_x: bool = True) -> FusedSolve:
+        """Token of the global solve that just ran its K iterations through cg_global_phase."""
+        self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=keep_x)
+        return self._solve
+
     def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> FusedSolve:
         """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'.
         keep_p=False: the library gets p = NULL; mixed_coeff() of this solve is then formed from the Rz sums the head

@@ -128,6 +128,23 @@ class WeightedCEMLP:
             return False
         return self._state.cg_solve(layout, x, r, p, K, cg_alpha, self.hvp_shift, keep_x=self.keep_solution)
 
+    # Global-batch CG (betty_amd/global_hvp.py): the same one-pass iteration, cut where the ranks must talk.
+    def fused_cg_global_ready(self, layout, K: int) -> bool:
+        st = self._state
+        return K > 0 and self.fused and hasattr(st, "cg_global_phase") and st.fused_supported(layout)
+
+    def fused_cg_global_skips_solution(self, layout, K: int) -> bool:
+        return (not self.keep_solution) and self.fused_cg_global_ready(layout, K) and bool(getattr(self._state, "solution_free", False))
+
+    def cg_global_phase(self, layout, x, r, p, k: int, K: int, phase: int, world: int, php, cg_alpha: float) -> None:
+        keep = not self.fused_cg_global_skips_solution(layout, K)
+        self._state.cg_global_phase(layout, x, r, p, k, K, phase, world, php, cg_alpha, self.hvp_shift, keep_x=keep)
+
+    def cg_global_finish(self, layout, K: int, cg_alpha: float):
+        """The token of the solve (hand it to mixed_vjp(..., solve=token)), or True."""
+        keep = not self.fused_cg_global_skips_solution(layout, K)
+        return self._state.cg_global_finish(layout, K, cg_alpha, keep_x=keep)
+
     def fused_neumann_ready(self, layout, K: int) -> bool:
         st = self._state
         return K > 0 and self.fused and hasattr(st, "neumann_solve") and st.fused_supported(layout)
@@ -220,6 +237,52 @@ class _TorchMLPState:
     def mixed_coeff(self, dir_views):
         Rz, _ = self._r_forward(dir_views[0::2], dir_views[1::2])
         return (self.err * Rz).sum(1) / self.B
+
+    # ---- global-batch CG, phase by phase: the math bhg_mlp_cg_global_phase implements, in ATen (tests: gloo, CPU) -----------------
+    def fused_supported(self, layout) -> bool:
+        want = []
+        for W in self.Ws:
+            want += [W.numel(), W.shape[0]]
+        return tuple(want) == tuple(layout.numels)
+
+    def cg_global_phase(self, layout, x, r, p, k, K, phase, world, php, cg_alpha, shift, keep_x=True):
+        f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+        shapes = []
+        for W in self.Ws:
+            shapes += [W.shape, (W.shape[0],)]
+        views = lambda flat: [flat[s: s + n].view(sh) for s, n, sh in zip(layout.starts, layout.numels, shapes)]
+        dot = lambda a, b: float((a.double() * b.double()).sum())
+        if phase == 0:      # BHG_CG_GLOBAL_CHAIN
+            if k == 0:
+                self._g = {"rr": dot(r, r)}
+                self._g["pp"] = self._g["rr"]
+            else:
+                g = self._g
+                beta = f32(g["rr_new"]) / f32(g["rr"])
+                p.mul_(beta).add_(r)                    # cg.py:53 (the kernels form it lazily where they read it)
+                b = float(beta)
+                g["pp"] = g["rr_new"] + 2.0 * b * g["rp"] + b * b * g["pp_old"]
+                g["rr"] = g["rr_new"]
+            hv = self.hvp(views(p))
+            self._hv = torch.zeros_like(p)
+            for dst, h in zip(views(self._hv), hv):
+                dst.copy_(h)
+            php[0] = dot(p, self._hv)                   # this rank's p . H_data p
+        elif phase == 1:    # BHG_CG_GLOBAL_UPDATE
+            g = self._g
+            den = float(cg_alpha) * (float(php[0]) / world + float(shift) * g["pp"])
+            alpha = f32(g["rr"]) / f32(den)             # cg.py:47
+            hp = self._hv + f32(shift) * p
+            r.sub_(alpha * hp)                          # cg.py:50 on the local Hessian: the ranks' mean is the global r'
+            x.add_(alpha * p)                           # cg.py:49
+            if k == K - 1:
+                x.mul_(-float(cg_alpha))                # cg.py:56 and the negation of cg.py:59/68
+        else:               # BHG_CG_GLOBAL_DOTS, after the residual's exchange
+            g = self._g
+            g["rr_new"], g["rp"], g["pp_old"] = dot(r, r), dot(r, p), dot(p, p)
+
+    def cg_global_finish(self, layout, K, cg_alpha, keep_x=True):
+        return True
 
 
 class LogisticRegressionL2:

@@ -271,6 +271,27 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
                      void* fws, size_t fws_bytes, void* stream);
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K,
                           float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* stream);
+/* Global-batch CG (extension; not in the reference, whose DDP mode replicates the whole solve,
+ * betty/problems/problem.py:253-262): ONE inner problem whose batch is spread over `world` ranks, one process per GPU; `m`
+ * describes THIS rank's share of the batch.  The oracle is cg.py:8-70 run in one process on the concatenated batch.
+ * The flat x, r, p are REPLICATED (bit-identical on every rank).  Because every rank holds the same r, p and step length,
+ *     r - alpha (mean_g H_g) p = mean_g (r - alpha H_g p),
+ * so bhg_mlp_cg_solve's one-pass iteration runs on each rank's batch unchanged, cut at the two points where the ranks talk:
+ *   phase BHG_CG_GLOBAL_CHAIN   (k > 0: beta and the direction's small slices;) the R-chain; php[0] = this rank's p.H_data p
+ *       -> caller: all-reduce(SUM) of php[0]                                              (8 bytes)
+ *   phase BHG_CG_GLOBAL_UPDATE  alpha = r.r / (cg_alpha (php[0] / world + shift p.p)); the weight-shaped outputs with
+ *                               r <- r - alpha H_g p, x += alpha p in their epilogues      (x == NULL: as bhg_mlp_cg_solve)
+ *       -> caller, unless k == K - 1: all-reduce(MEAN) of r                               (4*N bytes)
+ *   phase BHG_CG_GLOBAL_DOTS    r'.r', r'.p, p.p over the exchanged residual (one 8*N-byte pass) for the next beta
+ * Two collectives per iteration, one of them 8 bytes; the last iteration has the 8-byte one only.  Before k = 0:
+ * bhg_cg_init on the MEAN over the ranks of the local right-hand sides.  All on one stream, the collectives ordered with it.
+ * php: one double of device memory owned by the caller.  world == 1 needs no collective.                                */
+#define BHG_CG_GLOBAL_CHAIN 0
+#define BHG_CG_GLOBAL_UPDATE 1
+#define BHG_CG_GLOBAL_DOTS 2
+int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
+                            int n_chunks, int k, int K, int phase, int world, double* php, float cg_alpha, float hvp_shift,
+                            void* ws, void* fws, size_t fws_bytes, void* stream);
 /* Mixed-derivative coefficient (see bhg_mlp_mixed_coeff) of the solution of the LAST bhg_mlp_cg_solve on `fws`,
  * without another R-forward pass: x is a linear combination of the CG directions, and the solver accumulated
  * Rz(x) = sum_k alpha_k Rz(p_k) from the Rz every iteration's head kernel computes anyway.                          */

@@ -454,11 +454,13 @@ def _global_worker(rank, world, port, case_name, structured, q):
         with use_backend(CpuCheckerBackend()):
             curr, prev, vector = zoo.build_case(case, mine, Config)
             if structured:
-                zoo.attach_mlp_structure(curr, case.family, impl="torch")
+                zoo.attach_mlp_structure(curr, case.family, impl="torch", fused=structured == "onepass")
             got = cg_global(vector, curr, prev, False)
             got = torch.cat([t.reshape(-1) for t in got]).detach()
             # sync=True: lands in .grad through backward (no DDP wrapper here: the local share of the mean)
             curr2, prev2, vector2 = zoo.build_case(case, mine, Config)
+            if structured:
+                zoo.attach_mlp_structure(curr2, case.family, impl="torch", fused=structured == "onepass")
             ret = cg_global(vector2, curr2, prev2, True)
             local = torch.cat([p.grad.reshape(-1) for p in prev2.trainable_parameters()]).detach()
             gathered = [torch.zeros_like(local) for _ in range(world)]
@@ -470,17 +472,22 @@ def _global_worker(rank, world, port, case_name, structured, q):
         others = [torch.zeros_like(got) for _ in range(world)]
         dist.all_gather(others, got)
         same = all(torch.equal(o, got) for o in others)
-        q.put((rank, rel, rel_sync, ret is None, same))
+        from betty_amd.global_hvp import ONE_PASS_STATS
+        K = int(curr.config.cg_iterations)
+        stats = (ONE_PASS_STATS["solves"], ONE_PASS_STATS["scalar_all_reduces"], ONE_PASS_STATS["residual_all_reduces"], K)
+        q.put((rank, rel, rel_sync, ret is None, same, stats))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("case_name,structured", [("reweight_cg20", False), ("reweight_cg20", True), ("logreg_cg5", False),
-                                                  ("logreg_cg3_a01", False)])
+@pytest.mark.parametrize("case_name,structured", [("reweight_cg20", False), ("reweight_cg20", "sharded"), ("reweight_cg20", "onepass"),
+                                                  ("logreg_cg5", False), ("logreg_cg3_a01", False)])
 def test_global_hvp_cg_matches_single_process_oracle(world, case_name, structured):
     """Sharded x, r, p; reduce-scatter of the data-parallel HVPs; partial-sum all-reduces between the CG phases;
-    all-gather of the direction: the result equals the reference's cg on the concatenated batch."""
+    all-gather of the direction: the result equals the reference's cg on the concatenated batch.
+    "onepass": the replicated-state form (bhg_mlp_cg_global_phase's protocol, its math in ATen here): two collectives per
+    iteration — 8 bytes before the step length, the residual after the outputs — and only the 8 bytes in the last one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -490,7 +497,12 @@ def test_global_hvp_cg_matches_single_process_oracle(world, case_name, structure
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
-    for rank, rel, rel_sync, returned_none, same in sorted(q.get(timeout=5) for _ in range(world)):
+    for rank, rel, rel_sync, returned_none, same, stats in sorted(q.get(timeout=5) for _ in range(world)):
         assert rel <= 1e-4, (rank, rel)            # north_star tolerance vs the single-process reference algorithm
         assert rel_sync <= 1e-4, (rank, rel_sync)  # sync=True: mean over ranks of what landed in .grad
         assert returned_none and same
+        solves, n_scalar, n_resid, K = stats
+        if structured == "onepass":                # two solves ran (sync False / True)
+            assert (solves, n_scalar, n_resid) == (2, 2 * K, 2 * (K - 1)), stats
+        else:
+            assert solves == 0, stats

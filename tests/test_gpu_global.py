@@ -1,0 +1,179 @@
+"""GPU tests of the global-batch one-pass CG solver (bhg_mlp_cg_global_phase through betty_amd/global_hvp.py).
+
+gpurun boxes have ONE GPU, so the multi-rank protocol is exercised two ways:
+  * world size 1 through ``cg_global`` itself (a one-rank process group): every phase kernel runs, no collective;
+  * TWO ranks emulated in one process on one GPU — two copies of the inner network, each with half of the batch, their
+    own flat state / workspaces, the two all-reduces done by hand between the phase calls — against the ONE-rank solver on
+    the concatenated batch (itself held to the reference by tests/test_gpu_parity.py and tests/test_cfg2_goldens.py).
+The real collectives (gloo, world size 2 and 4) run the same protocol on CPU in tests/test_distributed_cpu.py.
+"""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import zoo
+from conftest import rel_err
+
+from betty_amd import Config, _native
+from betty_amd import hypergradient as hg
+from betty_amd.backend import get_backend
+from betty_amd.flat import FlatLayout
+from betty_amd.hypergradient.structured import WeightedCEMLP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        yield None
+        return
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        yield None
+    finally:
+        dist.destroy_process_group()
+
+
+def _problem(dims, B, ridge, seed, K, keep):
+    """Inner MLP + meta-weight-net on the GPU with a batch of B samples; the structure hook is attached."""
+    g = torch.Generator().manual_seed(seed)
+    inner, upper = zoo.MLP(dims), zoo.MWN(16)
+    with torch.no_grad():
+        for p in list(inner.parameters()) + list(upper.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (1.0 / max(p.shape[-1], 4) ** 0.5))
+    inner, upper = inner.to(DEV), upper.to(DEV)
+    x = torch.randn(B, dims[0], generator=g).to(DEV)
+    y = torch.randint(0, dims[-1], (B,), generator=g).to(DEV)
+    vec = [0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()]
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    return inner, prev, x, y, vec
+
+
+def _attach(inner, prev, x, y, ridge, K, keep, alpha=1.0):
+    curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=K, cg_alpha=alpha),
+                           loss_fn=zoo.make_reweight_loss(prev, ridge), batch=(x, y))
+    curr.hypergradient_structure = lambda prev_: WeightedCEMLP(
+        curr, prev_, layers=list(inner.layers), weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=ridge, impl="hip",
+        fused=True, keep_solution=keep)
+    return curr
+
+
+@pytest.mark.parametrize("keep", [True, False], ids=["x-materialised", "solution-free"])
+@pytest.mark.parametrize("dims,B,K", [([256, 384, 128, 10], 100, 5), ([70, 130, 36, 10], 100, 4), ([64, 10], 50, 3),
+                                      ([128, 96, 64, 32, 10], 128, 1)], ids=lambda v: str(v))
+def test_world_size_one_is_the_one_rank_solver(dims, B, K, keep, one_rank_group):
+    """cg_global at world size 1: the phase-cut iteration (chain | step length + outputs | dots of the residual) gives what
+    bhg_mlp_cg_solve gives — the dot products of the residual are taken per chunk instead of per output tile, so equality is to
+    fp32 summation noise, not bitwise."""
+    from betty_amd.global_hvp import ONE_PASS_STATS
+
+    inner, prev, x, y, vec = _problem(dims, B, 0.05, sum(dims) + B + K, K, keep)
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vec, _attach(inner, prev, x, y, 0.05, K, keep), prev, False)]
+    n0 = ONE_PASS_STATS["solves"]
+    got = [t.clone() for t in hg.jvp_fn_mapping["cg_global"](vec, _attach(inner, prev, x, y, 0.05, K, keep), prev, False)]
+    assert ONE_PASS_STATS["solves"] == n0 + 1, "the one-pass form must be the one that ran"
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 5e-5, rel   # (the one-rank solver projects its direction products when it can; this one never does)
+
+
+def _emulate(parts, prev, vecs, K, alpha, keep):
+    """Drive the protocol of betty_amd/global_hvp.py::_cg_global_one_pass for len(parts) ranks living in this process."""
+    be = get_backend()
+    G = len(parts)
+    lays, provs, st = [], [], []
+    for curr, vec in zip(parts, vecs):
+        lay = FlatLayout([t.numel() for t in vec], vec[0].device)     # NOT the cached layout: every "rank" owns its state
+        lays.append(lay)
+        prov = curr.hypergradient_structure(prev)
+        prov.prepare()
+        assert prov.fused_cg_global_ready(lay, K)
+        provs.append(prov)
+        st.append(dict(v=lay.new_flat(), php=torch.zeros(1, dtype=torch.float64, device=DEV), xrp=lay.state(3)))
+    skip_x = [bool(p.fused_cg_global_skips_solution(l, K)) for p, l in zip(provs, lays)]
+    assert all(s == (not keep) for s in skip_x)
+    # right-hand side: mean of the local vectors ("all-reduce" by hand)
+    for lay, vec, s in zip(lays, vecs, st):
+        be.flatten(lay, vec, s["v"], 1.0 / G)
+    total = sum(s["v"] for s in st)
+    for lay, vec, s in zip(lays, vecs, st):
+        s["v"].copy_(total)
+        x, r, p = s["xrp"]
+        if not keep:
+            x.fill_(float("nan"))
+        be.cg_init(lay, lay.views(s["v"], vec), x if keep else None, r, p)
+    for k in range(K):
+        for prov, lay, s in zip(provs, lays, st):
+            prov.cg_global_phase(lay, *s["xrp"], k, K, _native.BHG_CG_GLOBAL_CHAIN, G, s["php"], alpha)
+        tot = sum(s["php"] for s in st)
+        for s in st:
+            s["php"].copy_(tot)
+        for prov, lay, s in zip(provs, lays, st):
+            prov.cg_global_phase(lay, *s["xrp"], k, K, _native.BHG_CG_GLOBAL_UPDATE, G, s["php"], alpha)
+        if k + 1 < K:
+            mean_r = sum(s["xrp"][1] for s in st) * (1.0 / G)
+            for s in st:
+                s["xrp"][1].copy_(mean_r)
+            for prov, lay, s in zip(provs, lays, st):
+                prov.cg_global_phase(lay, *s["xrp"], k, K, _native.BHG_CG_GLOBAL_DOTS, G, s["php"], alpha)
+    outs = []
+    for prov, lay, vec, s in zip(provs, lays, vecs, st):
+        token = prov.cg_global_finish(lay, K, alpha)
+        outs.append([t.clone() for t in prov.mixed_vjp(lay.views(s["xrp"][0], vec), False, solve=token)])
+    xs = [s["xrp"][0].clone() for s in st]
+    if not keep:
+        for xx in xs:
+            assert torch.isnan(xx).all(), "the solution vector must not be touched"
+    hyper = [sum(o[i] for o in outs) / G for i in range(len(outs[0]))]
+    return hyper, xs
+
+
+@pytest.mark.parametrize("hoist", [None, "0"], ids=["hoisted-default", "classic-chain"])
+@pytest.mark.parametrize("keep", [True, False], ids=["x-materialised", "solution-free"])
+@pytest.mark.parametrize("dims,B,K,alpha", [([256, 384, 128, 10], 100, 6, 1.0), ([70, 130, 36, 10], 64, 4, 0.5),
+                                            ([512, 256, 128, 64, 10], 128, 8, 1.0)], ids=lambda v: str(v))
+def test_two_emulated_ranks_match_the_one_rank_solver_on_the_concatenated_batch(dims, B, K, alpha, keep, hoist, monkeypatch):
+    """mean_g (r - alpha H_g p) = r - alpha H p: two half batches, two states, the 8-byte and the N-sized exchange done by hand,
+    against bhg_mlp_cg_solve on the whole batch (2B rows: other tile counts, other summation trees — fp32 noise, tolerance
+    north_star's 1e-4 with ridge 0.05 keeping the K-step recurrence well inside it)."""
+    if hoist is None:
+        monkeypatch.delenv("BHG_MLP_HOIST", raising=False)
+    else:
+        monkeypatch.setenv("BHG_MLP_HOIST", hoist)
+    ridge = 0.05
+    inner, prev, x, y, _ = _problem(dims, 2 * B, ridge, 7 * sum(dims) + B + K, K, keep)
+    g = torch.Generator().manual_seed(99)
+    vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(2)]
+    vmean = [0.5 * (a + b) for a, b in zip(*vecs)]
+    # the one-rank solver on the concatenated batch, right-hand side = mean of the ranks' vectors
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
+    want_x = get_backend().layout(vmean).state(3)[0].clone()
+    # two ranks: the same weights (separate module objects => separate activation buffers), half of the batch each
+    inner2 = copy.deepcopy(inner)
+    parts = [_attach(inner, prev, x[:B], y[:B], ridge, K, keep, alpha), _attach(inner2, prev, x[B:], y[B:], ridge, K, keep, alpha)]
+    lib = _native.load()
+    h0 = lib.bhg_mlp_hoist_launches()
+    got, xs = _emulate(parts, prev, vecs, K, alpha, keep)
+    hoisted = lib.bhg_mlp_hoist_launches() > h0
+    assert hoisted == (hoist is None and all(d % 32 == 0 for d in dims[:-1]) and len(dims) >= 4), (hoisted, dims)
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 1e-4, rel
+    if keep:
+        assert torch.equal(xs[0], xs[1]), "replicated state: both ranks must hold the same bits"
+        a, b = xs[0].double().cpu().numpy(), want_x.double().cpu().numpy()
+        assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
