@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--hvp-graph", choices=["solve", "persistent"], default="persistent",
                     help="--hvp autograd only: capture the K HVPs once per solve, or (default) loss / gradient-with-graph and the "
                          "HVP once for the whole run (the inner training_step is a static function here)")
+    ap.add_argument("--tunableop", action="store_true",
+                    help="--hvp autograd only: let PyTorch's TunableOp pick the GEMM kernel of every shape of the double backward "
+                         "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's); nothing is written to disk")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
@@ -310,6 +313,10 @@ def main():
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
     else:   # opaque double backward: opt into the hipGraph replay of the K HVPs (betty_amd/hypergradient/_common.py)
+        if args.tunableop:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(True)
+            torch.cuda.tunable.write_file_on_exit(False)
         curr.hypergradient_graph = False if args.no_hvp_graph else (True if args.hvp_graph == "solve" else "persistent")
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
@@ -535,6 +542,7 @@ def main():
                         "pytorch-rocm autograd double backward" + ("" if args.no_hvp_graph else
                                                                    ", K HVPs captured once per solve and replayed as a HIP graph (opt-in)" if args.hvp_graph == "solve" else
                                                                    ", loss / gradient-with-graph and HVP captured ONCE for the run and replayed as two HIP graphs (opt-in)")),
+                "blas_of_the_opaque_hvp": ("PyTorch TunableOp (tuned during the warm-up)" if args.tunableop else "PyTorch default") if args.hvp == "autograd" else None,
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "solver_form": solver_form,
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else

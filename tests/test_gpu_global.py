@@ -177,3 +177,59 @@ def test_two_emulated_ranks_match_the_one_rank_solver_on_the_concatenated_batch(
         assert torch.equal(xs[0], xs[1]), "replicated state: both ranks must hold the same bits"
         a, b = xs[0].double().cpu().numpy(), want_x.double().cpu().numpy()
         assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+
+
+# ---- two real processes, real collectives (gloo stages the device buffers through the host), one GPU ------------------------------
+def _two_process_worker(rank, world, port, q):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from betty_amd.global_hvp import ONE_PASS_STATS, cg_global
+
+        torch.cuda.set_device(0)
+        dims, B, K, ridge = [256, 384, 128, 10], 100, 6, 0.05
+        inner, prev, x, y, _ = _problem(dims, world * B, ridge, 4242, K, False)       # same seed: same weights, same full batch
+        g = torch.Generator().manual_seed(99)
+        vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+        vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+        want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True), prev, False)]
+        mine = _attach(inner, prev, x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B], ridge, K, False)
+        got = cg_global(vecs[rank], mine, prev, False)
+        rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+        flat = torch.cat([t.reshape(-1) for t in got]).cpu()
+        others = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(others, flat)
+        same = all(torch.equal(o, flat) for o in others)
+        q.put((rank, rel, same, ONE_PASS_STATS["solves"], ONE_PASS_STATS["scalar_all_reduces"], ONE_PASS_STATS["residual_all_reduces"], K))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_one_gpu_over_gloo():
+    """The whole of cg_global — right-hand-side exchange, K x (8-byte SUM, N-sized MEAN), final M-sized exchange — between two
+    processes (both on cuda:0; gloo moves the device buffers through the host): every rank returns the same bits, equal to the
+    one-rank solver on the concatenated batch to north_star's tolerance."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_two_process_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, same, solves, n_scalar, n_resid, K in sorted(q.get(timeout=5) for _ in range(world)):
+        assert rel <= 1e-4, (rank, rel)
+        assert same
+        assert (solves, n_scalar, n_resid) == (1, K, K - 1)
