@@ -1083,6 +1083,7 @@ struct BiasArgs {
   int L, B;
   float rho2;
   int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
+  const float* d0;                   // != NULL: the first bias's slice of the direction lives HERE, not at fz.d + foff[0] (k_proj_step)
 };
 template <int MODE, class BA = BiasArgs>
 __device__ __forceinline__ void bias_body(const BA& a, const FuseArgs& fz, const int bx, float* red_base) {
@@ -1119,7 +1120,8 @@ __device__ __forceinline__ void bias_body(const BA& a, const FuseArgs& fz, const
     } else {
       const float hv = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
       const int64_t off = a.foff[l] + col;
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = fz.d[off];
+      const float* dsrc = (l == 0 && a.d0) ? a.d0 + col : fz.d + off;
+      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = *dsrc;
       fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), hv, nd, na, nb, racc);
       fz.a[off] = na;
       if (fz.b) fz.b[off] = nb;
@@ -2318,6 +2320,7 @@ constexpr int kSmallL = kHoistMax / 2 + 1;
 struct BiasArgsC {
   const float* rd[kSmallL]; const float* c[kSmallL]; float* out[kSmallL];
   int n[kSmallL]; int blk0[kSmallL + 1]; int L, B; float rho2; int64_t foff[kSmallL];
+  const float* d0;   // see BiasArgs
 };
 struct SmallOutArgs {
   HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
@@ -2491,22 +2494,26 @@ struct ProjScalArgs {
 // A few blocks (one thread per element of the small slices); every block recomputes the same scalars from the same partials in
 // the same order, block 0 publishes them (like k_cg_beta).  The previous iteration's {rr, rp, pp} are read from the OTHER
 // parity slot of pscal, so no block can see block 0's new values.
-__global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
-  __shared__ double red[kWaves];
+// (bias 0 of the direction may be read at p0_rd and written at p0_wr instead of in place: k_proj_step)
+__device__ __forceinline__ float proj_scalars_body(const ProjScalArgs& a, const int bx, const bool publish, const bool small,
+                                                   const float* __restrict__ p0_rd, float* __restrict__ p0_wr) {
+  __shared__ double red[6][kWaves];
   __shared__ float s_beta;
   const int t = threadIdx.x;
   // this thread's element of the small slices: loads first (independent of the sums)
-  const int gi = blockIdx.x * kThreads + t;
+  const int gi = bx * kThreads + t;
   int64_t eoff = -1;
-  {
+  int etensor = -1, eidx = 0;
+  if (small) {
     int base = 0;
     for (int tt = 0; tt < a.snt; ++tt) {
-      if (eoff < 0 && gi < base + a.slen[tt]) eoff = a.soff[tt] + (gi - base);
+      if (eoff < 0 && gi < base + a.slen[tt]) { eoff = a.soff[tt] + (gi - base); etensor = tt; eidx = gi - base; }
       base += a.slen[tt];
     }
   }
+  const bool alt0 = etensor == 0 && p0_rd != nullptr;
   float rv = 0.f, pv = 0.f;
-  if (eoff >= 0) { rv = a.r_small[eoff]; pv = a.p_small[eoff]; }
+  if (eoff >= 0) { rv = a.r_small[eoff]; pv = alt0 ? p0_rd[eidx] : a.p_small[eoff]; }
   double ar = 0.0, ap = 0.0, ag = 0.0;
   for (int i = t; i < a.dot_blocks; i += kThreads) {
     ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; ag += a.part_dot[2 * (int64_t)a.dot_blocks + i];
@@ -2516,15 +2523,29 @@ __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
     const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
     s0 += a.part[j]; s1 += a.part[a.part_stride + j]; s2 += a.part[2 * (int64_t)a.part_stride + j];
   }
-  const double r_raw = block_sum(ar, red);
-  const double p_raw = block_sum(ap, red);
-  const double raw_raw = block_sum(ag, red);
-  const double rr_s = block_sum(s0, red);
-  const double rp_s = block_sum(s1, red);
-  const double pp_s = block_sum(s2, red);
+  // six fixed-order sums with ONE barrier (wave sums, then the waves in order: block_sum's order, value for value)
+  {
+    const double v[6] = {ar, ap, ag, s0, s1, s2};
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double ws = wave_sum(v[q]);
+      if (lane == 0) red[q][wv] = ws;
+    }
+  }
+  __syncthreads();
   if (t == 0) {
+    double tot[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWaves; ++i) acc += red[q][i];
+      tot[q] = acc;
+    }
+    const double r_raw = tot[0], p_raw = tot[1], raw_raw = tot[2], rr_s = tot[3], rp_s = tot[4], pp_s = tot[5];
     const double rr_old = a.scal[S_RR_OLD];          // r.r of this iteration (k_cg_alpha)
-    const double al = a.scal[S_ALPHA], sh = (double)a.shift;
+    const double al = a.scal[S_ALPHA_RING + a.kpar], sh = (double)a.shift;
     const double* pin = a.pscal + 4 * (a.kpar ^ 1);
     double* pout = a.pscal + 4 * a.kpar;
     double rr_b, rp_b, pp_b;
@@ -2537,7 +2558,7 @@ __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
     const double rr1 = rr_b1 + rr_s, rp1 = rp_b1 + rp_s, pp = pp_b + pp_s;
     const float beta = (float)rr1 / (float)rr_old;     // fp32 division of the fp32-rounded dots, as the reference (cg.py:51-52)
     const double b = (double)beta;
-    if (blockIdx.x == 0) {
+    if (publish) {
       a.scal[S_RR_NEW] = rr1;
       a.scal[S_BETA] = b;
       a.scal[S_PP] = rr1 + 2.0 * b * rp1 + b * b * pp;
@@ -2548,9 +2569,17 @@ __global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
     s_beta = beta;
   }
   __syncthreads();
-  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p.  Here, in a launch that runs alone: the chain of the
-  // next iteration and k_proj_update (Rh_0 needs the first bias direction) read them.
-  if (eoff >= 0) a.p_small[eoff] = fz_add(rv, fz_mul(s_beta, pv));
+  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p
+  if (eoff >= 0) {
+    const float np = fz_add(rv, fz_mul(s_beta, pv));
+    if (alt0) p0_wr[eidx] = np; else a.p_small[eoff] = np;
+  }
+  return s_beta;
+}
+// The scalars as a launch of their own (BHG_PROJ_STEP_ALONE; the default merges them into the next iteration's k_proj_step): it
+// runs alone because the chain of the next iteration and k_proj_update (Rh_0 needs the first bias direction) read the slices.
+__global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
+  (void)proj_scalars_body(a, blockIdx.x, blockIdx.x == 0, true, nullptr, nullptr);
 }
 
 // ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
@@ -2577,8 +2606,10 @@ struct ProjArgs {
   const double* scal;   // CG: alpha_{k-1}, beta_{k-1}.  NULL: Neumann — G(v') = G(v) - alpha (G(raw) + shift G(v)) with the constant
   float alpha;          // step `alpha` (Gr and Gp then name the same array)
 };
-__global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
-  const int b = blockIdx.x;
+// b0: bias 0 of the coming direction is formed here, r'_b0 + beta * p_b0_old (k_proj_step; the very roundings of the small slices'
+// update), instead of read from pr.bias
+__device__ __forceinline__ void proj_update_body(const ProjArgs& pa, const int b, const bool own_beta, const float beta_in,
+                                                 const float* __restrict__ r_b0, const float* __restrict__ p_b0_old) {
   int i = 0;
   while (i + 1 < pa.n && b >= pa.blk0[i + 1]) ++i;
   const ProjProb pr = pa.p[i];
@@ -2593,8 +2624,18 @@ __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
     float4 w0 = ld16(pr.Graw + idx * 4);
     if (pr.Graw2) { const float4 w1 = ld16(pr.Graw2 + idx * 4); w0.x += w1.x; w0.y += w1.y; w0.z += w1.z; w0.w += w1.w; }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
-    const float alpha = pa.scal ? (float)pa.scal[S_ALPHA_RING + pa.kpar_prev] : pa.alpha, beta = pa.scal ? (float)pa.scal[S_BETA] : 0.f;
+    const float alpha = pa.scal ? (float)pa.scal[S_ALPHA_RING + pa.kpar_prev] : pa.alpha;
+    const float beta = own_beta ? beta_in : (pa.scal ? (float)pa.scal[S_BETA] : 0.f);
+    if (pr.out) {
+      if (pr.bias && r_b0) {
+        const float4 rb = ld16(r_b0 + n), pb = ld16(p_b0_old + n);
+        bv.x = fz_add(rb.x, fz_mul(beta, pb.x)); bv.y = fz_add(rb.y, fz_mul(beta, pb.y));
+        bv.z = fz_add(rb.z, fz_mul(beta, pb.z)); bv.w = fz_add(rb.w, fz_mul(beta, pb.w));
+      } else if (pr.bias) {
+        bv = ld16(pr.bias + n);
+      }
+      if (pr.mask) mv = ld16(pr.mask + idx * 4);
+    }
     // the rounding sequence of the N-sized recurrences (fuse_elem): Hp = raw + shift p; r' = r - alpha Hp; p' = r' + beta p
 #define BHG_PROJ1(c)                                                                  \
     {                                                                                 \
@@ -2615,6 +2656,27 @@ __global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) {
   } else if (pr.out) {
     *reinterpret_cast<float4*>(pr.out + idx * 4) = gr;
   }
+}
+__global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) { proj_update_body(pa, blockIdx.x, false, 0.f, nullptr, nullptr); }
+
+// Fully projected CG, default: the scalars of iteration k-1 and the recurrences of iteration k in ONE launch (one dependent
+// launch less per iteration).  Every block sums the same partials in the same order to the same beta (a few KB out of L2);
+// the blocks behind the update blocks own the small slices' direction update and the first of them publishes the scalars.
+// Nothing in this launch reads what another block of it writes: the update blocks of the first layer need the coming first
+// bias direction — they form it themselves from r'_b0 and the OLD p_b0, which the small blocks leave alone (the new one goes to
+// the other of two slots, p0_wr; every later reader of that slice is pointed at the slot of its iteration's parity).
+struct ProjStepArgs {
+  ProjArgs pa; ProjScalArgs sa;
+  int update_blocks;
+  const float* r_b0; const float* p0_rd; float* p0_wr;
+};
+static_assert(sizeof(ProjStepArgs) <= 3800, "kernel arguments of k_proj_step must fit the kernarg segment");
+__global__ __launch_bounds__(256) void k_proj_step(ProjStepArgs g) {
+  const int b = blockIdx.x;
+  const bool small = b >= g.update_blocks;
+  const int sb = small ? b - g.update_blocks : 0;
+  const float beta = proj_scalars_body(g.sa, sb, small && sb == 0, small, g.p0_rd, g.p0_wr);
+  if (!small) proj_update_body(g.pa, b, true, beta, g.r_b0, g.p0_rd);
 }
 
 // ---- per-device side stream + events -------------------------------------------------------------------------------
@@ -2759,6 +2821,13 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
   hp->ok = true;
 }
 
+// Fully projected CG: scalars of iteration k-1 + recurrences of iteration k in one launch (k_proj_step); BHG_PROJ_STEP_ALONE=1
+// keeps them as two launches (k_proj_scalars at the end of an iteration, k_proj_update at the top of the next): the A/B arm.
+bool proj_step_merged() {
+  const char* e = getenv("BHG_PROJ_STEP_ALONE");
+  return !(e && *e && *e != '0');
+}
+
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
 struct FusedWs {
   double* partT1; double* partT2h; double* partT2; double* partPP; double* partRR[2];
@@ -2767,6 +2836,7 @@ struct FusedWs {
   int nRR, nT2;
   float* hoist;                     // slabs + G arrays of the hoisted direction products (HoistPlan offsets)
   double* part_dot; double* pscal;  // fully projected CG: [2][dot_blocks] partials of r.raw / p.raw; {rr, rp, pp} over the MFMA layers
+  float* pb0[2];                    // fully projected CG: the first bias's slice of the direction, two slots by iteration parity (k_proj_step)
   size_t bytes;
 };
 void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
@@ -2793,6 +2863,7 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
   w->part_dot = static_cast<double*>(take(sizeof(double) * 3 * (hp.ok ? hp.dot_blocks : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
+  for (int i = 0; i < 2; ++i) w->pb0[i] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[1]));
   w->bytes = off;
 }
 
@@ -2826,6 +2897,7 @@ struct ChainMode {
   //   gphase 1: the R-chain only; this rank's share of p.H_data p -> php[0] (k_php_local)
   //   gphase 2: step length from the all-reduced php[0] * inv_world, then the outputs with their epilogues
   int gphase; double* php; double inv_world;
+  int second;                   // fully projected CG: iteration 1 (the scalars k_proj_step completes are those of the FIRST iteration)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -2935,7 +3007,26 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       pa.blk0[hp->n] = rblk;
       pa.n = hp->n; pa.Bp = Bp; pa.B = B; pa.kpar_prev = cm.kpar ^ 1; pa.shift = cm.shift; pa.scal = cg ? cm.scal : nullptr; pa.alpha = cm.alpha;
-      hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
+      if (cg && cm.proj >= 2 && proj_step_merged()) {   // + the scalars and the small slices' direction update of the LAST iteration
+        ProjStepArgs g{};
+        g.pa = pa;
+        ProjScalArgs& sa = g.sa;
+        sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
+        sa.part = cm.beta->part; sa.part_stride = cm.ws->nRR;   // the last iteration's epilogue partials (= its partRR_new)
+        sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blocks(m);
+        sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
+        int small_total = 0;
+        for (int t = 0; t < cm.beta->nt; ++t) { sa.soff[t] = cm.beta->off[t]; sa.slen[t] = cm.beta->len[t]; small_total += cm.beta->len[t]; }
+        sa.scal = cm.scal; sa.pscal = cm.ws->pscal; sa.shift = cm.shift; sa.first = cm.second; sa.kpar = cm.kpar ^ 1;
+        const int sgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;
+        g.update_blocks = rblk;
+        g.r_b0 = cm.fa + cm.starts[1];
+        g.p0_rd = cm.second ? cm.fd + cm.starts[1] : cm.ws->pb0[cm.kpar ^ 1];
+        g.p0_wr = cm.ws->pb0[cm.kpar];
+        hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
+      } else {
+        hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
+      }
       ++g_proj_iterations;
     }
     static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
@@ -3102,6 +3193,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       bias_blk += (m->dims[l + 1] + 63) / 64;
     }
     ba.blk0[L] = bias_blk;
+    // fully projected CG (k_proj_step): the first bias's slice of the direction lives in the slot dir[1] names
+    if (cg && cm.proj >= 2 && hp && proj_step_merged()) ba.d0 = static_cast<const float*>(dir[1]);
   }
   FuseArgs bias_fz = fbase;
   bias_fz.a = cm.fa; bias_fz.b = cm.fb; bias_fz.d = cm.fd; bias_fz.part_base = part_base_bias;   // offsets travel in ba.foff
@@ -3281,6 +3374,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           so.ba.foff[l] = ba.foff[l];
         }
         so.ba.blk0[L] = ba.blk0[L];
+        so.ba.d0 = ba.d0;
         so.bf = bias_fz;
         so.bias_blocks = bias_blk;
         ga.small_blocks = so.head_blocks + bias_blk;
@@ -3342,7 +3436,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
     }
-    if (proj_full && cg) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
+    if (proj_full && cg && !proj_step_merged()) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
       BHG_REQUIRE(all_fast || small_in_graw, "the fully projected CG solver needs the single-launch output path");
       ProjScalArgs sa{};
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
@@ -3564,6 +3658,9 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
   cm.beta = &c->ba; cm.beta_blocks = c->bgrid;
   cm.proj = c->proj_level;
   cm.gphase = gphase; cm.php = php; cm.inv_world = inv_world;
+  cm.second = k == 1;
+  if (c->proj_level == 2 && proj_step_merged())   // the first bias's direction: flat p in iteration 0, then the slot of the parity
+    c->dir[1] = k == 0 ? static_cast<const void*>(c->p + c->starts[1]) : static_cast<const void*>(w.pb0[k & 1]);
   if (int rc = run_chain(m, c->dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

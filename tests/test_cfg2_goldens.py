@@ -81,7 +81,9 @@ def _arms(algo):
                  # hoisted, every iteration on the N-sized residual (the default projects: G(r) by batch-sized recurrences)
                  ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, proj="0")),
                  # G(r) projected, r / p still N-sized (the default projects everything: "fused-default")
-                 ("fused-proj-level1", dict(hvp="hip", fused=True, wsk=None, proj="9"))]
+                 ("fused-proj-level1", dict(hvp="hip", fused=True, wsk=None, proj="9")),
+                 # fully projected with the scalars and the recurrences as two launches (default: one, k_proj_step)
+                 ("fused-proj-2launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PROJ_STEP_ALONE": "1"}))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
@@ -111,6 +113,10 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
         monkeypatch.delenv("BHG_MLP_PROJ", raising=False)
     else:
         monkeypatch.setenv("BHG_MLP_PROJ", arm["proj"])
+    for key in ("BHG_PROJ_STEP_ALONE",):
+        monkeypatch.delenv(key, raising=False)
+    for key, val in arm.get("env", {}).items():
+        monkeypatch.setenv(key, val)
     saved = be.cg_variant
     be.cg_variant = {"stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}.get(arm.get("variant"), _native.BHG_CG_AUTO)
     try:
