@@ -261,7 +261,7 @@ def main():
                          "HVP once for the whole run (the inner training_step is a static function here)")
     ap.add_argument("--tunableop", action="store_true",
                     help="--hvp autograd only: let PyTorch's TunableOp pick the GEMM kernel of every shape of the double backward "
-                         "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's); nothing is written to disk")
+                         "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's)")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     args = ap.parse_args()
@@ -316,7 +316,10 @@ def main():
         if args.tunableop:
             torch.cuda.tunable.enable(True)
             torch.cuda.tunable.tuning_enable(True)
-            torch.cuda.tunable.write_file_on_exit(False)
+            if hasattr(torch.cuda.tunable, "write_file_on_exit"):
+                torch.cuda.tunable.write_file_on_exit(False)
+            else:   # keep the results file out of the working tree
+                torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bhg_tunableop_results.csv"))
         curr.hypergradient_graph = False if args.no_hvp_graph else (True if args.hvp_graph == "solve" else "persistent")
     N = sum(p.numel() for p in curr.parameters())
     M = sum(p.numel() for p in prev.parameters())
@@ -467,7 +470,7 @@ def main():
                                                                       "so this counts bytes the kernels do not move — yardstick only"},
                     "note": mall_note + "; `achieved` is SURVEY 8(d)'s yardstick — the 28*N bytes the REFERENCE's recurrence moves per "
                             "iteration divided by this solver's iteration time; the projected solver itself moves far fewer bytes (`traffic`), "
-                            "its iteration is a chain of ~9 dependent launches on batch-sized data plus one pass over the constant weights"}
+                            "its iteration is a chain of 8 dependent launches on batch-sized data plus one pass over the constant weights"}
         elif ("cg_step" if args.algo == "cg" else "neumann_step") in spans:
             us, n = spans["cg_step" if args.algo == "cg" else "neumann_step"]
             roof = {

@@ -11,4 +11,4 @@ c $g/smoke.log $p/r03_smoke.log
 c $g/timeline_fused.txt $p/r03_timeline_fused_fully_projected.txt
 c $g/outside_fused.txt $p/r03_outside_the_k_loop.txt
 c $g/pmc/r03_pmc_traffic.json $p/r03_pmc_traffic.json
-for t in neumann_fused neumann_classic_chain cg_nofuse cg_classic_chain cg_hoisted_not_projected cg_keep_solution cg_autograd_graph_persistent cg_autograd_graph_per_solve cg_autograd_eager neumann_autograd_graph_persistent darts cg_global_ws1; do c $g/bench_$t.json $p/r03_bench_$t.json; done
+for t in neumann_fused neumann_classic_chain cg_nofuse cg_classic_chain cg_hoisted_not_projected cg_keep_solution cg_proj_two_launches cg_autograd_tunableop cg_global_ws1_classic_chain cg_autograd_graph_persistent cg_autograd_graph_per_solve cg_autograd_eager neumann_autograd_graph_persistent darts cg_global_ws1; do c $g/bench_$t.json $p/r03_bench_$t.json; done

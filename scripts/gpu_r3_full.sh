@@ -23,7 +23,7 @@ PY
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_f -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused > /tmp/tr_f.log 2>&1; echo "trace rc=$?"
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr_f/*kernel_trace.csv 2>/dev/null | head -1)
-if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f "k_proj_update" | tee $O/timeline_fused.txt; python scripts/print_step_outside.py $f > $O/outside_fused.txt 2>&1; tail -1 $O/outside_fused.txt; fi
+if [ -n "$f" ]; then python scripts/print_iter_timeline.py $f "k_proj_step" | tee $O/timeline_fused.txt; python scripts/print_step_outside.py $f > $O/outside_fused.txt 2>&1; tail -1 $O/outside_fused.txt; fi
 run() { tag=$1; shift; timeout 400 python bench.py --cpu-steps 0 "$@" 2> $O/bench_$tag.err > $O/bench_$tag.json; python -c "
 import json
 d=json.loads(open('$O/bench_$tag.json').read().strip().splitlines()[-1]); print('== %-18s %.1f steps/s  %.3f ms/step  iter_us %s' % ('$tag', d['value'], d['ms_per_step'], d.get('per_iteration_us')))" 2>&1 | tail -1; }
@@ -33,10 +33,13 @@ run cg_nofuse --no-fuse
 BHG_MLP_HOIST=0 run cg_classic_chain
 BHG_MLP_PROJ=0 run cg_hoisted_not_projected
 run cg_keep_solution --keep-solution
+BHG_PROJ_STEP_ALONE=1 run cg_proj_two_launches
 run cg_autograd_graph_persistent --hvp autograd --steps 60
 run cg_autograd_graph_per_solve --hvp autograd --steps 60 --hvp-graph solve
 run cg_autograd_eager --hvp autograd --steps 60 --no-hvp-graph
+run cg_autograd_tunableop --hvp autograd --steps 60 --tunableop
 run neumann_autograd_graph_persistent --hvp autograd --steps 60 --algo neumann --cg-iters 10
 run darts --algo darts
 run cg_global_ws1 --mode global
+BHG_MLP_HOIST=0 run cg_global_ws1_classic_chain --mode global
 bash scripts/gpu_pmc3.sh 2>&1 | tail -40

@@ -126,6 +126,13 @@ def test_argument_validation_without_gpu():
     d.L, d.Bp = 2, 100  # Bp must be a multiple of 128
     assert lib.bhg_mlp_hvp(ctypes.byref(d), tab, tab, None) == -1
     assert b"multiple of 128" in lib.bhg_last_error()
+    # global-batch CG phases: descriptor checked before anything else (a NULL descriptor never reaches a launch)
+    assert lib.bhg_mlp_cg_global_phase(None, None, None, None, None, None, 1, 0, 1, _native.BHG_CG_GLOBAL_CHAIN, 1, None, 1.0, 0.0,
+                                       None, None, 0, None) == -1
+    d.L, d.Bp = 2, 100
+    assert lib.bhg_mlp_cg_global_phase(ctypes.byref(d), None, None, None, None, None, 1, 0, 1, _native.BHG_CG_GLOBAL_DOTS, 2, None, 1.0,
+                                       0.0, None, None, 0, None) == -1
+    assert b"multiple of 128" in lib.bhg_last_error()
     # timing API
     tot, cnt = ctypes.c_double(1.0), ctypes.c_int(7)
     assert lib.bhg_timing_enable(0) == 0
