@@ -2313,6 +2313,9 @@ constexpr int kHoistMax = 14;
 // batch-sized arrays (see k_proj_scalars).  One float4 per thread, one (r.raw, p.raw) pair of fp64 partials per block.
 // A Gram problem (w != 0) contributes w * <X or X^T, Gr> to raw.raw instead: <S_l, Rd_l Rd_l^T>, <D_l, Rh Rh^T>, 2 <E_l^T, T_l>.
 struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; float w; int xT; };
+// One dot block takes kDotUnroll x 256 float4 of its problem: a quarter of the partials k_proj_step's blocks each sum again.
+constexpr int kDotUnroll = 4;
+constexpr int dot_blocks_of(int float4s) { return ((float4s + 255) / 256 + kDotUnroll - 1) / kDotUnroll; }
 constexpr int kProjDotMax = kHoistMax + 3 * (kHoistMax / 2);   // products + three Gram dots per MFMA layer
 // The small slices' outputs (head weight, biases) with their fused CG epilogue, as block classes of k_hoist (fully projected CG:
 // they are all that is left of k_outer_all).  Compact twin of BiasArgs (the hoisted forms take at most 8 layers).
@@ -2369,8 +2372,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     while (i + 1 < ha.nd && d >= ha.dblk0[i + 1]) ++i;
     const ProjDotProb q = ha.dp[i];
     const int nv = q.N / 4;
-    const int64_t idx = (int64_t)(d - ha.dblk0[i]) * 256 + threadIdx.x;
     double ar = 0.0, ap = 0.0, ag = 0.0;
+#pragma unroll
+    for (int u = 0; u < kDotUnroll; ++u) {
+    const int64_t idx = ((int64_t)(d - ha.dblk0[i]) * kDotUnroll + u) * 256 + threadIdx.x;
     if (idx < (int64_t)ha.Bp * nv && (int)(idx / nv) < ha.B) {
       const float4 gr = ld16(q.Gr + idx * 4);
       if (q.w != 0.f) {   // Gram problem (N = Bp): elementwise product of two B x B matrices, the first possibly transposed
@@ -2380,12 +2385,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           xv = make_float4(q.X[(int64_t)n * q.N + mrow], q.X[(int64_t)(n + 1) * q.N + mrow], q.X[(int64_t)(n + 2) * q.N + mrow],
                            q.X[(int64_t)(n + 3) * q.N + mrow]);
         } else xv = ld16(q.X + idx * 4);
-        ag = (double)q.w * ((double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w);
+        ag += (double)q.w * ((double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w);
       } else {
         const float4 xv = ld16(q.X + idx * 4), gp = ld16(q.Gp + idx * 4);
-        ar = (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
-        ap = (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
+        ar += (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
+        ap += (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
       }
+    }
     }
     double* red = reinterpret_cast<double*>(smem);
     const double sr = block_sum(ar, red);
@@ -2804,8 +2810,8 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->graw_off[i] = off; off += (size_t)2 * Bp * hp->N[i];   // up to two slabs (one per operand pair)
   }
   hp->dot_blocks = 0;
-  for (int i = 0; i < n; ++i) hp->dot_blocks += (Bp * (hp->N[i] / 4) + 255) / 256;
-  hp->dot_blocks += (3 * (L - 2) + 1) * ((Bp * (Bp / 4) + 255) / 256);   // the Gram dots of raw.raw
+  for (int i = 0; i < n; ++i) hp->dot_blocks += dot_blocks_of(Bp * (hp->N[i] / 4));
+  hp->dot_blocks += (3 * (L - 2) + 1) * dot_blocks_of(Bp * (Bp / 4));   // the Gram dots of raw.raw
   for (int l = 0; l + 1 < L; ++l) {
     hp->s_off[l] = off; off += (size_t)Bp * Bp;
     hp->q_off[l] = off; off += (size_t)Bp * Bp;
@@ -3345,9 +3351,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         for (int i = 0; i < hp->n; ++i) {
           const int l = hp->layer[i];
           ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i], 0.f, 0};
-          ga.dblk0[nd++] = dblk; dblk += (Bp * (hp->N[i] / 4) + 255) / 256;
+          ga.dblk0[nd++] = dblk; dblk += dot_blocks_of(Bp * (hp->N[i] / 4));
         }
-        const int gblocks = (Bp * (Bp / 4) + 255) / 256;
+        const int gblocks = dot_blocks_of(Bp * (Bp / 4));
         for (int l = 0; l + 1 < L; ++l) {   // raw.raw from the Gram matrices (see k_proj_scalars)
           ga.dp[nd] = {hbase + hp->q_off[l], nullptr, hbase + hp->s_off[l], Bp, 1.f, 0};
           ga.dblk0[nd++] = dblk; dblk += gblocks;
@@ -3360,6 +3366,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         }
         ga.dblk0[nd] = dblk;
         ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
+        BHG_REQUIRE(dblk == hp->dot_blocks, "dot block count of the plan and of the launch disagree");
       }
       if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of this launch
         SmallOutArgs& so = ga.so;
