@@ -47,6 +47,9 @@ struct GemmPair {
   // so the new CG direction p = r' + beta * p_old is never written out by a kernel of its own (cg.py:53).
   const float* B2;
   int mix;
+  // gemm_body<..., AS = true>: the M-side operand arrives as a_slabs K-split slabs (a_slab_stride floats apart) and is summed
+  // in the order 0, 1, ... while it is staged (k_wsk_group's T_l / E_l feeding the G(raw) products)
+  int a_slabs, a_slab_stride;
 };
 struct GemmArgs {
   GemmPair pr[2];
@@ -64,6 +67,8 @@ struct GemmArgs {
   int xpose_out;        // k_gemm FAST 128 x 32: slab tile transposed through LDS -> 16-B stores
   int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
                         // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
+  const float* dotX;    // xpose_out tiles only: also emit <X tile, this workgroup's output tile> (X: [M][ldo] like a slab) as
+  double* dot_out;      // ONE fp64 partial at *dot_out — linear in the slabs, so the partials of all splits just add up
 };
 
 // The workgroups that share a CU start together and would run in lock step — all in their MFMA phase, then all waiting
@@ -186,7 +191,7 @@ struct GemmLds {
   static constexpr int B_ELEMS = (LB == LAYOUT_KC) ? TN * kPadK : kTK * TN;
   static constexpr int FLOATS = 2 * A_ELEMS + 2 * B_ELEMS;
 };
-template <int LA, int LB, int TN, bool FAST, bool BF>
+template <int LA, int LB, int TN, bool FAST, bool BF, bool AS = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* __restrict__ smem) {
   static_assert(TN == 64 || TN == 32, "tile width");
   constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
@@ -252,6 +257,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     const bool fb = FAST || (kfull && n0 + TN <= a.N && (ldb & 3) == 0);
     if (LA == LAYOUT_KC) load_kc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
     else load_rc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
+    if (AS) {   // K-split slabs of the M-side operand, summed in slab order (workgroup-uniform count)
+      const int ns = second ? pr1.a_slabs : pr0.a_slabs, stride = second ? pr1.a_slab_stride : pr0.a_slab_stride;
+      for (int sl = 1; sl < ns; ++sl) {
+        float4 rs[kTM / 32];
+        if (LA == LAYOUT_KC) load_kc<kTM>(gA + (int64_t)sl * stride, lda, m0, a.M, k0, kend, fa, rs);
+        else load_rc<kTM>(gA + (int64_t)sl * stride, lda, m0, a.M, k0, kend, fa, rs);
+#pragma unroll
+        for (int i = 0; i < kTM / 32; ++i) { ra[i].x += rs[i].x; ra[i].y += rs[i].y; ra[i].z += rs[i].z; ra[i].w += rs[i].w; }
+      }
+    }
     if (LB == LAYOUT_KC) load_kc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
     else load_rc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
     if (BF) {
@@ -349,6 +364,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       sC[row * kPadK + li] = acc[0][rg] + acc[1][rg];
     }
     __syncthreads();
+    double dacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = threadIdx.x + 256 * i;
@@ -357,6 +373,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)(m0 + row) * a.ldo + n0 + c4);
       if (a.nt_out) __builtin_nontemporal_store(v, dst);
       else *dst = v;
+      if (a.dotX) {   // workgroup-uniform
+        const float4 xv = ld16(a.dotX + (int64_t)(m0 + row) * a.ldo + n0 + c4);
+        dacc += (double)xv.x * v.x + (double)xv.y * v.y + (double)xv.z * v.z + (double)xv.w * v.w;
+      }
+    }
+    if (a.dotX) {
+      const double tot = block_sum(dacc, reinterpret_cast<double*>(sB[0]));   // (the B buffers are free; sC is the A buffer)
+      if (threadIdx.x == 0) *a.dot_out = tot;
     }
     return;
   }
@@ -1968,8 +1992,13 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) { wsk_bo
 // Several small K-contiguous x K-contiguous products in ONE launch of the LDS-staged form (projected CG: the B x B Gram
 // products T_l = h_l Rh_{l-1}^T, E_l = delta_l Rd_l^T of an iteration, or S_l = h_l h_l^T, D_l = delta_l delta_l^T once per
 // solve): blocks [blk0[i], blk0[i+1]) are the 32 x 32 tiles of problem i.
-constexpr int kWskGroupMax = 40;   // first iteration of the deepest hoistable net (8 layers): 12 + 13 + 13 problems
-struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; };
+constexpr int kWskGroupMax = 26;   // first iteration of the deepest hoistable net (8 layers): 12 (T, E) + 13 (S, D) problems
+// K split over `nsplit` WORKGROUPS per tile (per-iteration Gram products: a few tiles with a long K would otherwise leave most of
+// the chip idle while each runs its whole K loop): split s takes K chunks [s, s+1) * nct / nsplit and leaves its tile in slab s
+// of `out` ([nsplit][M][N]); the CONSUMER sums the slabs in the order 0, 1, ... as it loads them (gemm_body<..., AS>: the A-side
+// loader of the G(raw) products).  (Measured, not kept: summing inside this launch by the last-arriving workgroup of a tile —
+// agent-scope fence + ticket: the fences write back and invalidate the L2s, 109.6 vs 88.4 us per iteration.)
+struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; int nsplit; };
 struct WskGroupArgs {
   WskGroupProb p[kWskGroupMax];
   int blk0[kWskGroupMax + 1];
@@ -1986,11 +2015,17 @@ __global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
   }
   int i = 0;
   while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
+  const WskGroupProb q = g.p[i];
+  const int tiles = (q.M / 32) * (q.N / 32);
+  const int t = b - g.blk0[i];
+  const int tile = q.nsplit > 1 ? t % tiles : t, sp = q.nsplit > 1 ? t / tiles : 0;
+  const int nct = q.K / 32;
+  const int cb = q.nsplit > 1 ? (int)(((int64_t)sp * nct) / q.nsplit) : 0, ce = q.nsplit > 1 ? (int)(((int64_t)(sp + 1) * nct) / q.nsplit) : nct;
   WskArgs a{};
-  a.pr[0].A = g.p[i].A; a.pr[0].B = g.p[i].Bm; a.pr[0].lda = g.p[i].K; a.pr[0].ldb = g.p[i].K;
-  a.pairs = 1; a.M = g.p[i].M; a.N = g.p[i].N; a.K = g.p[i].K; a.B = g.p[i].B;
-  a.out = g.p[i].out; a.ntm = a.M / 32; a.ntn = a.N / 32;
-  wsk_body<LAYOUT_KC, false, D, true>(a, b - g.blk0[i]);
+  a.pr[0].A = q.A + 32 * cb; a.pr[0].B = q.Bm + 32 * cb; a.pr[0].lda = q.K; a.pr[0].ldb = q.K;
+  a.pairs = 1; a.M = q.M; a.N = q.N; a.K = 32 * (ce - cb); a.B = q.B;
+  a.out = q.out + (size_t)sp * q.M * q.N; a.ntm = a.M / 32; a.ntn = a.N / 32;
+  wsk_body<LAYOUT_KC, false, D, true>(a, tile);
 }
 
 // BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
@@ -2306,17 +2341,21 @@ struct HoistProb {
   int K, N, splits, rc, lda, ldb;
   const float* A2;     // optional second operand pair with the same layouts and leading dimensions (projected CG:
   const float* B2m;    // G(raw) = S Rd + T delta, two B x B Gram matrices times two batch-sized arrays); NULL = one pair
+  const float* X;      // fully projected CG: the tiles also emit <X, G(raw)> — raw.raw's share of this product (GemmArgs.dotX)
+  int a_slabs, a2_slabs, a_slab_stride;   // > 1: A / A2 arrive as K-split slabs (GemmPair.a_slabs)
 };
 constexpr int kHoistMax = 14;
 // Fully projected CG: partials of  r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>  and  p.raw (the same with G(p)) over the
 // MFMA layers' weight slices — the inner products of the N-sized residual / direction with the N-sized outer products, from
 // batch-sized arrays (see k_proj_scalars).  One float4 per thread, one (r.raw, p.raw) pair of fp64 partials per block.
-// A Gram problem (w != 0) contributes w * <X or X^T, Gr> to raw.raw instead: <S_l, Rd_l Rd_l^T>, <D_l, Rh Rh^T>, 2 <E_l^T, T_l>.
-struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; float w; int xT; };
+// (raw.raw has the same form with G(raw) in place of G(r): <raw_l, raw_l> = <Rd_l, Gf_l(raw)> + <Rh_{l-1}, Gb_l(raw)> — the tiles that
+//  form G(raw) emit it themselves, GemmArgs.dotX.  Round 3's first form took it from Gram matrices, <S_l, Rd_l Rd_l^T> +
+//  2 <E_l^T, T_l> + <D_l, Rh Rh^T>: five more B x B x K products per iteration.)
+struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; };
 // One dot block takes kDotUnroll x 256 float4 of its problem: a quarter of the partials k_proj_step's blocks each sum again.
 constexpr int kDotUnroll = 4;
 constexpr int dot_blocks_of(int float4s) { return ((float4s + 255) / 256 + kDotUnroll - 1) / kDotUnroll; }
-constexpr int kProjDotMax = kHoistMax + 3 * (kHoistMax / 2);   // products + three Gram dots per MFMA layer
+constexpr int kProjDotMax = kHoistMax;
 // The small slices' outputs (head weight, biases) with their fused CG epilogue, as block classes of k_hoist (fully projected CG:
 // they are all that is left of k_outer_all).  Compact twin of BiasArgs (the hoisted forms take at most 8 layers).
 constexpr int kSmallL = kHoistMax / 2 + 1;
@@ -2338,7 +2377,8 @@ struct HoistArgs {
   int dot_blocks, nd, B;         // then dot_blocks blocks of the projected inner products (fully projected CG)
   ProjDotProb dp[kProjDotMax];
   int dblk0[kProjDotMax + 1];
-  double* part_dot;              // [3][dot_blocks]: r.raw, p.raw, raw.raw
+  double* part_dot;              // [2][dot_blocks]: r.raw, p.raw
+  double* part_raw;              // [gemm_blocks]: raw.raw, one partial per G(raw) tile (HoistProb.X)
   int small_blocks;              // then the small slices' output blocks (head_blocks + bias_blocks)
   SmallOutArgs so;
 };
@@ -2372,32 +2412,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     while (i + 1 < ha.nd && d >= ha.dblk0[i + 1]) ++i;
     const ProjDotProb q = ha.dp[i];
     const int nv = q.N / 4;
-    double ar = 0.0, ap = 0.0, ag = 0.0;
+    double ar = 0.0, ap = 0.0;
 #pragma unroll
     for (int u = 0; u < kDotUnroll; ++u) {
     const int64_t idx = ((int64_t)(d - ha.dblk0[i]) * kDotUnroll + u) * 256 + threadIdx.x;
     if (idx < (int64_t)ha.Bp * nv && (int)(idx / nv) < ha.B) {
       const float4 gr = ld16(q.Gr + idx * 4);
-      if (q.w != 0.f) {   // Gram problem (N = Bp): elementwise product of two B x B matrices, the first possibly transposed
-        float4 xv;
-        if (q.xT) {
-          const int mrow = (int)(idx / nv), n = (int)(idx - (int64_t)mrow * nv) * 4;
-          xv = make_float4(q.X[(int64_t)n * q.N + mrow], q.X[(int64_t)(n + 1) * q.N + mrow], q.X[(int64_t)(n + 2) * q.N + mrow],
-                           q.X[(int64_t)(n + 3) * q.N + mrow]);
-        } else xv = ld16(q.X + idx * 4);
-        ag += (double)q.w * ((double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w);
-      } else {
-        const float4 xv = ld16(q.X + idx * 4), gp = ld16(q.Gp + idx * 4);
-        ar += (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
-        ap += (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
-      }
+      const float4 xv = ld16(q.X + idx * 4), gp = ld16(q.Gp + idx * 4);
+      ar += (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
+      ap += (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
     }
     }
     double* red = reinterpret_cast<double*>(smem);
     const double sr = block_sum(ar, red);
     const double sp = block_sum(ap, red);
-    const double sg = block_sum(ag, red);
-    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; ha.part_dot[2 * (int64_t)ha.dot_blocks + d] = sg; }
+    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; }
     return;
   }
   int i = 0;
@@ -2412,10 +2441,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
   a.out = ha.p[i].slabs; a.ldo = a.N; a.out_rows = ha.Bp; a.nt_out = 1; a.xpose_out = 1;
+  if (ha.p[i].X && ha.part_raw) { a.dotX = ha.p[i].X; a.dot_out = ha.part_raw + b; }
   const int ntn = a.N / 32, ntm = ha.Bp / kTM;
   const int bx = t % ntn, by = (t / ntn) % ntm, bz = t / (ntn * ntm);
-  if (ha.p[i].rc) gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false>(a, bx, by, bz, smem);
-  else gemm_body<LAYOUT_KC, LAYOUT_KC, 32, true, false>(a, bx, by, bz, smem);
+  a.pr[0].a_slabs = ha.p[i].a_slabs; a.pr[1].a_slabs = ha.p[i].a2_slabs;
+  a.pr[0].a_slab_stride = a.pr[1].a_slab_stride = ha.p[i].a_slab_stride;
+  if (ha.p[i].rc) {
+    if (ha.p[i].a_slabs > 1 || ha.p[i].a2_slabs > 1) gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false, true>(a, bx, by, bz, smem);
+    else gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false>(a, bx, by, bz, smem);
+  } else gemm_body<LAYOUT_KC, LAYOUT_KC, 32, true, false>(a, bx, by, bz, smem);
 }
 
 // G(p_k)[m][n] = sum_s slabs[s][m][n] + beta * G(p_{k-1})[m][n]   (rows >= B zero; first iteration: no second term), and for
@@ -2490,7 +2524,8 @@ __global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
 // the reference's fp64 run at full size: 1e-7 ... 2e-6 on the well-conditioned variant, r.r falling smoothly through
 // twenty orders of magnitude; GPU: tests/test_cfg2_goldens.py.)  One workgroup.
 struct ProjScalArgs {
-  const double* part_dot; int dot_blocks;                        // [3][dot_blocks]: r.raw, p.raw, raw.raw (k_hoist's dot blocks)
+  const double* part_dot; int dot_blocks;                        // [2][dot_blocks]: r.raw, p.raw (k_hoist's dot blocks)
+  const double* part_raw; int raw_blocks;                        // raw.raw: one partial per tile of the G(raw) launch
   const double* part; int part_stride; int off0, n0, off1, n1;   // the small slices' epilogue partials [3][stride]
   const float* r_small; float* p_small;                          // flat r / p (small slices only)
   int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
@@ -2521,9 +2556,8 @@ __device__ __forceinline__ float proj_scalars_body(const ProjScalArgs& a, const 
   float rv = 0.f, pv = 0.f;
   if (eoff >= 0) { rv = a.r_small[eoff]; pv = alt0 ? p0_rd[eidx] : a.p_small[eoff]; }
   double ar = 0.0, ap = 0.0, ag = 0.0;
-  for (int i = t; i < a.dot_blocks; i += kThreads) {
-    ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; ag += a.part_dot[2 * (int64_t)a.dot_blocks + i];
-  }
+  for (int i = t; i < a.dot_blocks; i += kThreads) { ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; }
+  for (int i = t; i < a.raw_blocks; i += kThreads) ag += a.part_raw[i];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int i = t; i < a.n0 + a.n1; i += kThreads) {
     const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
@@ -2743,6 +2777,15 @@ int reduce_blocks(int slab, int N) {
 // Plan of the hoisted direction products (see k_hoist): which products, their split-K factors — the smallest K-steps-per-
 // workgroup target whose workgroups all fit one resident wave of the chip (3 per CU) — and where their slabs and their
 // persistent G arrays live inside the fused workspace.
+// K split of the per-iteration Gram products over workgroups (k_wsk_group): about 512 k per workgroup, at most kGramSplitMax
+// (BHG_GRAM_KSPLIT=0: one workgroup per tile, the A/B arm)
+constexpr int kGramSplitMax = 4;
+inline int gram_ksplit(int K) {
+  const char* e = getenv("BHG_GRAM_KSPLIT");
+  if (e && atoi(e) == 0) return 1;
+  const int s = K / 512;
+  return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
+}
 struct HoistPlan {
   bool ok;
   int n;
@@ -2750,9 +2793,9 @@ struct HoistPlan {
   int blk0[kHoistMax + 1];
   size_t slab_off[kHoistMax], g_off[kHoistMax];   // float offsets inside the hoist region
   size_t gr_off[kHoistMax], graw_off[kHoistMax];  // projected CG: G(r) and G(raw) of every product
-  size_t s_off[BHG_MLP_MAX_LAYERS], d_off[BHG_MLP_MAX_LAYERS], t_off[BHG_MLP_MAX_LAYERS], e_off[BHG_MLP_MAX_LAYERS];   // B x B Gram matrices
-  size_t q_off[BHG_MLP_MAX_LAYERS], p_off[BHG_MLP_MAX_LAYERS];   // fully projected CG: Rd_l Rd_l^T, Rh_{l-1} Rh_{l-1}^T
-  int dot_blocks;
+  size_t s_off[BHG_MLP_MAX_LAYERS], d_off[BHG_MLP_MAX_LAYERS];   // B x B Gram matrices, constant over a solve
+  int dot_blocks, raw_blocks;   // fully projected CG: dot blocks of r.raw / p.raw; tiles of the G(raw) launch (raw.raw partials)
+  size_t tslab_off[BHG_MLP_MAX_LAYERS], eslab_off[BHG_MLP_MAX_LAYERS];   // K-split slabs of T_l / E_l (kGramSplitMax each)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
@@ -2811,20 +2854,30 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
   }
   hp->dot_blocks = 0;
   for (int i = 0; i < n; ++i) hp->dot_blocks += dot_blocks_of(Bp * (hp->N[i] / 4));
-  hp->dot_blocks += (3 * (L - 2) + 1) * dot_blocks_of(Bp * (Bp / 4));   // the Gram dots of raw.raw
+  hp->raw_blocks = 0;
+  for (int i = 0; i < n; ++i) hp->raw_blocks += (hp->N[i] / 32) * ntm * 2;   // at most two workgroups (operand pairs) per tile
   for (int l = 0; l + 1 < L; ++l) {
     hp->s_off[l] = off; off += (size_t)Bp * Bp;
-    hp->q_off[l] = off; off += (size_t)Bp * Bp;
     if (l >= 1) {
-      hp->p_off[l] = off; off += (size_t)Bp * Bp;
       hp->d_off[l] = off; off += (size_t)Bp * Bp;
-      hp->t_off[l] = off; off += (size_t)Bp * Bp;
-      hp->e_off[l] = off; off += (size_t)Bp * Bp;
+      hp->tslab_off[l] = off; off += (size_t)kGramSplitMax * Bp * Bp;   // T_l, E_l: up to kGramSplitMax K-split slabs each
+      hp->eslab_off[l] = off; off += (size_t)kGramSplitMax * Bp * Bp;
     }
   }
   hp->blk0[n] = blk;
   hp->floats = off;
   hp->ok = true;
+}
+
+// Workgroups (= raw.raw partials) of the G(raw) launch: a product with two operand pairs takes one workgroup per pair and tile
+// unless BHG_PROJ_GRAW_SPLIT=0 (only the first layer's forward product has a single pair).
+int graw_blocks(const HoistPlan* hp, int Bp) {
+  int n = 0;
+  for (int i = 0; i < hp->n; ++i) {
+    const bool two = !(hp->bwd[i] == 0 && hp->layer[i] == 0);
+    n += (hp->N[i] / 32) * (Bp / kTM) * ((two && graw_split()) ? 2 : 1);
+  }
+  return n;
 }
 
 // Fully projected CG: scalars of iteration k-1 + recurrences of iteration k in one launch (k_proj_step); BHG_PROJ_STEP_ALONE=1
@@ -2842,6 +2895,7 @@ struct FusedWs {
   int nRR, nT2;
   float* hoist;                     // slabs + G arrays of the hoisted direction products (HoistPlan offsets)
   double* part_dot; double* pscal;  // fully projected CG: [2][dot_blocks] partials of r.raw / p.raw; {rr, rp, pp} over the MFMA layers
+  double* part_raw;                 // fully projected CG: [raw_blocks] partials of raw.raw (tiles of the G(raw) launch)
   float* pb0[2];                    // fully projected CG: the first bias's slice of the direction, two slots by iteration parity (k_proj_step)
   size_t bytes;
 };
@@ -2867,7 +2921,8 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   HoistPlan hp;
   hoist_plan(m, &hp);
   w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
-  w->part_dot = static_cast<double*>(take(sizeof(double) * 3 * (hp.ok ? hp.dot_blocks : 1)));
+  w->part_dot = static_cast<double*>(take(sizeof(double) * 2 * (hp.ok ? hp.dot_blocks : 1)));
+  w->part_raw = static_cast<double*>(take(sizeof(double) * (hp.ok ? hp.raw_blocks : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   for (int i = 0; i < 2; ++i) w->pb0[i] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[1]));
   w->bytes = off;
@@ -3018,6 +3073,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         g.pa = pa;
         ProjScalArgs& sa = g.sa;
         sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
+        sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
         sa.part = cm.beta->part; sa.part_stride = cm.ws->nRR;   // the last iteration's epilogue partials (= its partRR_new)
         sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blocks(m);
         sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
@@ -3302,28 +3358,21 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       WskGroupArgs g{};
       int blk = 0;
       for (int l = 1; l + 1 < L; ++l) {
-        g.p[g.n] = {m->h[l], m->Rh[l - 1], hbase + hp->t_off[l], Bp, Bp, m->dims[l], B};        // T_l = h_l Rh_{l-1}^T
-        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
-        g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->e_off[l], Bp, Bp, m->dims[l + 1], B};    // E_l = delta_l Rd_l^T
-        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
+        const int st_ = gram_ksplit(m->dims[l]), se_ = gram_ksplit(m->dims[l + 1]);
+        g.p[g.n] = {m->h[l], m->Rh[l - 1], hbase + hp->tslab_off[l], Bp, Bp, m->dims[l], B, st_};       // T_l = h_l Rh_{l-1}^T
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32) * st_;
+        g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->eslab_off[l], Bp, Bp, m->dims[l + 1], B, se_};   // E_l = delta_l Rd_l^T
+        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32) * se_;
       }
       for (int l = 0; cm.first && l + 1 < L; ++l) {   // once per solve: S_l, D_l
-        g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B};
+        g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B, 1};
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
         if (l >= 1) {
-          g.p[g.n] = {m->delta[l], m->delta[l], hbase + hp->d_off[l], Bp, Bp, m->dims[l + 1], B};
+          g.p[g.n] = {m->delta[l], m->delta[l], hbase + hp->d_off[l], Bp, Bp, m->dims[l + 1], B, 1};
           g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
         }
       }
-      const bool full = cg && cm.proj >= 2;   // fully projected CG: also Rd_l Rd_l^T and Rh_{l-1} Rh_{l-1}^T (-> raw.raw, k_proj_scalars)
-      for (int l = 0; full && l + 1 < L; ++l) {
-        g.p[g.n] = {m->Rd[l], m->Rd[l], hbase + hp->q_off[l], Bp, Bp, m->dims[l + 1], B};
-        g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
-        if (l >= 1) {
-          g.p[g.n] = {m->Rh[l - 1], m->Rh[l - 1], hbase + hp->p_off[l], Bp, Bp, m->dims[l], B};
-          g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
-        }
-      }
+      const bool full = cg && cm.proj >= 2;   // fully projected CG: r.raw, p.raw, raw.raw from batch-sized arrays (k_proj_step)
       g.blk0[g.n] = blk;
       if (alpha_in_gram) { g.do_alpha = 1; g.alpha = aa; }
       launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
@@ -3335,12 +3384,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         HoistProb& q = ga.p[i];
         if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
           q.A = hbase + hp->s_off[l]; q.Bm = m->Rd[l];
-          if (l >= 1) { q.A2 = hbase + hp->t_off[l]; q.B2m = m->delta[l]; }
+          if (l >= 1) { q.A2 = hbase + hp->tslab_off[l]; q.B2m = m->delta[l]; q.a2_slabs = gram_ksplit(m->dims[l]); }
         } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
-          q.A = hbase + hp->e_off[l]; q.Bm = m->h[l];
+          q.A = hbase + hp->eslab_off[l]; q.Bm = m->h[l]; q.a_slabs = gram_ksplit(m->dims[l + 1]);
           q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
         }
         q.slabs = hbase + hp->graw_off[i];
+        q.a_slab_stride = Bp * Bp;
+        if (full) q.X = hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l];   // raw.raw's share: <X, G(raw)>
         q.K = Bp; q.N = hp->N[i]; q.splits = (q.A2 && graw_split()) ? 2 : 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
         ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm * q.splits;
       }
@@ -3350,22 +3401,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         int dblk = 0, nd = 0;
         for (int i = 0; i < hp->n; ++i) {
           const int l = hp->layer[i];
-          ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i], 0.f, 0};
+          ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i]};
           ga.dblk0[nd++] = dblk; dblk += dot_blocks_of(Bp * (hp->N[i] / 4));
         }
-        const int gblocks = dot_blocks_of(Bp * (Bp / 4));
-        for (int l = 0; l + 1 < L; ++l) {   // raw.raw from the Gram matrices (see k_proj_scalars)
-          ga.dp[nd] = {hbase + hp->q_off[l], nullptr, hbase + hp->s_off[l], Bp, 1.f, 0};
-          ga.dblk0[nd++] = dblk; dblk += gblocks;
-          if (l >= 1) {
-            ga.dp[nd] = {hbase + hp->p_off[l], nullptr, hbase + hp->d_off[l], Bp, 1.f, 0};
-            ga.dblk0[nd++] = dblk; dblk += gblocks;
-            ga.dp[nd] = {hbase + hp->t_off[l], nullptr, hbase + hp->e_off[l], Bp, 2.f, 1};
-            ga.dblk0[nd++] = dblk; dblk += gblocks;
-          }
-        }
         ga.dblk0[nd] = dblk;
-        ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot;
+        ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot; ga.part_raw = cm.ws->part_raw;
+        BHG_REQUIRE(gblk == graw_blocks(hp, Bp), "tile count of the G(raw) launch and of its raw.raw partials disagree");
         BHG_REQUIRE(dblk == hp->dot_blocks, "dot block count of the plan and of the launch disagree");
       }
       if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of this launch
@@ -3447,6 +3488,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       BHG_REQUIRE(all_fast || small_in_graw, "the fully projected CG solver needs the single-launch output path");
       ProjScalArgs sa{};
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
+      sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
       sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
       sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;
       sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;

@@ -5,7 +5,7 @@ on the CPU in fp64 where it must hold to rounding: for a ReLU-MLP with per-sampl
         Gf_l(raw) = (h_l h_l^T) Rd_l + (h_l Rh_{l-1}^T) delta_l ,   Gb_l(raw) = (delta_l Rd_l^T) h_l + (delta_l delta_l^T) Rh_{l-1}
     because the weight-shaped outputs of H p are outer products of batch-sized factors, raw(W_l) = Rd_l^T h_l + delta_l^T Rh_{l-1};
   * r'.r', r'.p and p'.p' follow from  r.raw = sum <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>,  p.raw alike, and
-    raw.raw = sum <Rd_l Rd_l^T, S_l> + 2 <E_l^T, T_l> + <D_l, Rh_{l-1} Rh_{l-1}^T>  (small slices explicit);
+    raw.raw = sum <Rd_l, Gf_l(raw)> + <Rh_{l-1}, Gb_l(raw)>  (= sum <Rd_l Rd_l^T, S_l> + 2 <E_l^T, T_l> + <D_l, Rh_{l-1} Rh_{l-1}^T>; small slices explicit);
   * so CG (cg.py:34-56, including the cg_alpha quirk) and the Neumann series (neumann.py:59-66) can run WITHOUT the N-sized
     residual / direction after the first iteration and give the reference's hypergradient.
 
@@ -104,9 +104,14 @@ def _projected(curr, prev, vector, ridge, algo, K, alpha):
             Rzx += a_k * Rz
             r_raw = sum(dd(Rd[l], Gfr[l]) for l in range(L - 1)) + sum(dd(Rh[l - 1], Gbr[l]) for l in range(1, L - 1)) \
                 + sum(dd(cr[l], raw_c[l]) for l in range(L)) + dd(Vhr, raw_Vh)
-            raw_raw = sum(dd(Rd[l] @ Rd[l].t(), S[l]) for l in range(L - 1)) \
+            # <raw_l, raw_l> = <raw_l, Rd_l^T h_l> + <raw_l, delta_l^T Rh_{l-1}> = <Rd_l, Gf_l(raw)> + <Rh_{l-1}, Gb_l(raw)>:
+            # the same form as r.raw, with the products the iteration forms anyway (the tiles of the G(raw) launch emit it)
+            raw_raw = sum(dd(Rd[l], graw_f[l]) for l in range(L - 1)) + sum(dd(Rh[l - 1], graw_b[l]) for l in range(1, L - 1)) \
+                + sum(dd(raw_c[l], raw_c[l]) for l in range(L)) + dd(raw_Vh, raw_Vh)
+            gram_route = sum(dd(Rd[l] @ Rd[l].t(), S[l]) for l in range(L - 1)) \
                 + sum(2 * dd(Em[l].t(), Tm[l]) + dd(D[l], Rh[l - 1] @ Rh[l - 1].t()) for l in range(1, L - 1)) \
                 + sum(dd(raw_c[l], raw_c[l]) for l in range(L)) + dd(raw_Vh, raw_Vh)
+            assert abs(float(raw_raw - gram_route)) <= 1e-9 * abs(float(gram_route)) + 1e-300   # round 3's first form: Gram matrices
             p_raw = pHp - shift * pp
             r_Hp, Hp_Hp = r_raw + shift * rp, raw_raw + 2 * shift * p_raw + shift * shift * pp
             rr_new = rr - 2 * a_k * r_Hp + a_k * a_k * Hp_Hp          # (... the residual update the un-scaled Hp: cg.py:50)
