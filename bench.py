@@ -498,7 +498,7 @@ def main():
             # what the projected iteration actually executes on the matrix pipe (useful rows only): the constant-weight chain,
             # the B x B Gram products and the batch-deep G(raw) products
             chain = sum(2.0 * BATCH * d[l] * d[l + 1] * 2 for l in range(1, len(d) - 2)) + 2.0 * BATCH * d[-2] * d[-1] * 4
-            gram = sum(2.0 * BATCH * BATCH * (2 * d[l] + 2 * d[l + 1]) for l in range(1, len(d) - 2)) + 2.0 * BATCH * BATCH * d[1]
+            gram = sum(2.0 * BATCH * BATCH * (d[l] + d[l + 1]) for l in range(1, len(d) - 2))   # T_l, E_l per MFMA layer behind the first
             graw = sum(2.0 * BATCH * BATCH * d[l + 1] * (1 if l == 0 else 2) for l in range(len(d) - 2)) + \
                 sum(2.0 * BATCH * BATCH * d[l] * 2 for l in range(1, len(d) - 2))
             hvp_roof = {

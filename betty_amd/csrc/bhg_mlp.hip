@@ -2777,13 +2777,15 @@ int reduce_blocks(int slab, int N) {
 // Plan of the hoisted direction products (see k_hoist): which products, their split-K factors — the smallest K-steps-per-
 // workgroup target whose workgroups all fit one resident wave of the chip (3 per CU) — and where their slabs and their
 // persistent G arrays live inside the fused workspace.
-// K split of the per-iteration Gram products over workgroups (k_wsk_group): about 512 k per workgroup, at most kGramSplitMax
+// K split of the per-iteration Gram products over workgroups (k_wsk_group): about 512 k per workgroup (BHG_GRAM_KCHUNK), at most kGramSplitMax
 // (BHG_GRAM_KSPLIT=0: one workgroup per tile, the A/B arm)
-constexpr int kGramSplitMax = 4;
+constexpr int kGramSplitMax = 8;
 inline int gram_ksplit(int K) {
   const char* e = getenv("BHG_GRAM_KSPLIT");
   if (e && atoi(e) == 0) return 1;
-  const int s = K / 512;
+  const char* c = getenv("BHG_GRAM_KCHUNK");   // k per workgroup (A/B)
+  const int per = c && atoi(c) >= 32 ? atoi(c) : 512;
+  const int s = K / per;
   return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
 }
 struct HoistPlan {

@@ -83,13 +83,18 @@ def _arms(algo):
                  # G(r) projected, r / p still N-sized (the default projects everything: "fused-default")
                  ("fused-proj-level1", dict(hvp="hip", fused=True, wsk=None, proj="9")),
                  # fully projected with the scalars and the recurrences as two launches (default: one, k_proj_step)
-                 ("fused-proj-2launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PROJ_STEP_ALONE": "1"}))]
+                 ("fused-proj-2launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PROJ_STEP_ALONE": "1"})),
+                 # the per-iteration Gram products with one workgroup per tile (default: K split over workgroups, slabs summed
+                 # by the consumer's loader) and with 256 k per workgroup (eight slabs on the longest)
+                 ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
+                 ("fused-gram-256", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KCHUNK": "256"}))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
         # default without an accumulator vector = projected Neumann; classic chain and hoisted-every-iteration as A/B arms
         arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
                  ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, hoist="2", proj="0")),
+                 ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
                  ("autograd", dict(hvp="autograd"))]
     return arms
 
@@ -113,7 +118,7 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
         monkeypatch.delenv("BHG_MLP_PROJ", raising=False)
     else:
         monkeypatch.setenv("BHG_MLP_PROJ", arm["proj"])
-    for key in ("BHG_PROJ_STEP_ALONE",):
+    for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK"):
         monkeypatch.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         monkeypatch.setenv(key, val)
