@@ -16,6 +16,11 @@
 // 128 x 64 selectable), k_outer 128 x 64, both on v_mfma_f32_32x32x2_f32 (exact fp32), staged through
 // LDS with coalesced 16-B global loads; the skinny GEMMs are split along K across ~768 workgroups to
 // fill the 256 CUs (deterministic: partial slabs are summed in fixed order, no atomics).
+//
+// Layout of this translation unit: the device code lives in the fragments mlp/*.inc, #included below inside the anonymous
+// namespace in dependency order (one TU: every kernel sees the same inlined helpers); this file keeps the host side — launch
+// helpers, the plan of the hoisted / projected forms (hoist_plan), the workspace carve-up, run_chain (one HVP chain with its
+// outputs stored or consumed), and the C entry points bhg_mlp_* of include/bhg.h.
 #include <stdlib.h>
 
 #include <mutex>
@@ -25,2008 +30,15 @@
 
 namespace bhg {
 namespace {
+#include "mlp/gemm.inc"   // tile constants, GemmArgs, LDS tile loaders, gemm_body / k_gemm (split-K skinny GEMM on v_mfma_f32_32x32x2_f32)
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+#include "mlp/outer.inc"   // fused CG / Neumann epilogues (fuse_elem), k_outer (weight-shaped outputs), split-K reduce kernels
 
-constexpr int kTM = 128;  // workgroup tile rows
-constexpr int kTN = 64;   // workgroup tile cols
-constexpr int kTK = 32;   // K step
-constexpr int kPadK = kTK + 4;  // LDS row stride (36 floats = 144 B) of K-contiguous tiles: rows stay 16-B aligned so
-                                // tiles are written with ds_write_b128 and fragments read with ds_read_b128, and
-                                // 36*i mod 64 is a distinct multiple of 4 for i < 16 => conflict-free 16-lane groups
+#include "mlp/scalars.inc"   // step length from batch-sized factors (alpha_compute), global-batch scalars, T2 / softmax reduces, bias outputs
 
-// Operand layouts in global memory.
-enum : int { LAYOUT_KC = 0 /* [rows][K], K contiguous */, LAYOUT_RC = 1 /* [K][rows], rows contiguous */ };
+#include "mlp/head.inc"   // narrow classifier head kernels and k_outer_all (every weight-shaped output in one launch)
 
-struct GemmPair {
-  const float* A;  // "M side" operand
-  const float* B;  // "N side" operand
-  int lda, ldb;    // leading dimensions (elements)
-  // "lazy direction" of the fused CG solver (k_gemm<..., BF = true>): the N-side operand is formed while it is staged,
-  //   Beff = B + (mix ? beta : 0) * B2,  beta = scal[S_BETA]     (B = r slice, B2 = previous direction slice)
-  // so the new CG direction p = r' + beta * p_old is never written out by a kernel of its own (cg.py:53).
-  const float* B2;
-  int mix;
-  // gemm_body<..., AS = true>: the M-side operand arrives as a_slabs K-split slabs (a_slab_stride floats apart) and is summed
-  // in the order 0, 1, ... while it is staged (k_wsk_group's T_l / E_l feeding the G(raw) products)
-  int a_slabs, a_slab_stride;
-};
-struct GemmArgs {
-  GemmPair pr[2];
-  int pairs;
-  int M, N, K;     // logical sizes (K per pair)
-  int splits;      // split-K factor (gridDim.z); each split handles a contiguous K range of every pair
-  float* out;      // splits == 1 && !partial: C [M][ldo]; else partial slabs [split][Mpad][ldo]
-  int ldo;
-  int out_rows;    // rows per partial slab
-  const float* addend;  // optional: out = acc + addend_scale * addend[m][n] (same ld as out)
-  float addend_scale;
-  int kstages;          // k_outer only: pipeline stages per operand pair (>= 2), each <= 64 rows of K
-  const double* scal;   // BF instances: device scalars (beta)
-  int nt_out;           // k_gemm: non-temporal stores of the partial slabs
-  int xpose_out;        // k_gemm FAST 128 x 32: slab tile transposed through LDS -> 16-B stores
-  int pair_split;       // k_gemm only, 2 pairs: > 0 -> splits [0, pair_split) work on pair 0 ALONE (over all of K), the
-                        // rest on pair 1 alone, so a consumer can sum the two products separately (fused CG: T2)
-  const float* dotX;    // xpose_out tiles only: also emit <X tile, this workgroup's output tile> (X: [M][ldo] like a slab) as
-  double* dot_out;      // ONE fp64 partial at *dot_out — linear in the slabs, so the partials of all splits just add up
-};
-
-// The workgroups that share a CU start together and would run in lock step — all in their MFMA phase, then all waiting
-// on memory.  Distinct wave priorities per dispatch round let the first-dispatched workgroup take the matrix pipe first
-// and reach its memory phase while the others compute.  mode 1: round = (linear workgroup id / 256) % per_cu;
-// mode 2: round = the wave's slot on its SIMD (HW_ID.wave_id).  k_outer_all: 53.6 vs 55.8 us, 288.7 vs 284.5 steps/s
-// (same-box A/B x 4, both modes alike; BHG_OUTER_STAGGER=0 turns it off).  The split-K GEMMs gain nothing from it
-// (measured: their K loop is already double-buffered inside each workgroup) and do not use it.
-__device__ __forceinline__ void stagger_prio(int mode, int lin, int per_cu) {
-  if (mode == 0) return;
-  const int slot = mode == 1 ? (lin >> 8) % per_cu : (int)__builtin_amdgcn_s_getreg((3 << 11) | 4);
-  if (slot == 0) __builtin_amdgcn_s_setprio(3);
-  else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-  else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-}
-
-// LDS tile loaders -----------------------------------------------------------------------------------
-// Every loader has two forms selected by a WORKGROUP-UNIFORM flag: `fast` (tile fully inside the
-// operand, leading dimension a multiple of 4 -> unconditional 16-B loads, no control flow, so all
-// loads of a step are in flight together) and a branch-free edge form (clamped addresses + selects,
-// scalar loads) for ragged tiles and odd leading dimensions.
-// 16-B load through a native vector type: `regs[i] = *(const float4*)p` on the HIP struct type becomes a
-// memcpy into a private ARRAY that SROA then leaves in scratch memory when nothing else touches the array.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ float4 ld16(const float* __restrict__ p) {
-  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float ld_guard(const float* __restrict__ g, int64_t idx, bool ok) {
-  const float v = g[ok ? idx : 0];
-  return ok ? v : 0.f;
-}
-// K-contiguous operand ([rows][K]): tile ROWS x 32, stored [row][kPadK].
-template <int ROWS>
-__device__ __forceinline__ void load_kc(const float* __restrict__ g, int ld, int row0, int nrows, int k0, int kend,
-                                        bool fast, float4 (&regs)[ROWS / 32]) {
-  const int t = threadIdx.x;
-  if (fast) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i)
-      regs[i] = ld16(g + (int64_t)(row0 + (t >> 3) + 32 * i) * ld + k0 + 4 * (t & 7));
-  } else {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int r = row0 + (t >> 3) + 32 * i;
-      const int k = k0 + 4 * (t & 7);
-      const int64_t base = (int64_t)r * ld + k;
-      const bool rok = r < nrows;
-      regs[i].x = ld_guard(g, base, rok && k < kend);
-      regs[i].y = ld_guard(g, base + 1, rok && k + 1 < kend);
-      regs[i].z = ld_guard(g, base + 2, rok && k + 2 < kend);
-      regs[i].w = ld_guard(g, base + 3, rok && k + 3 < kend);
-    }
-  }
-}
-template <int ROWS>
-__device__ __forceinline__ void store_kc(float* __restrict__ lds, const float4 (&regs)[ROWS / 32]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
-    *reinterpret_cast<float4*>(lds + ((t >> 3) + 32 * i) * kPadK + 4 * (t & 7)) = regs[i];
-  }
-}
-// rows-contiguous operand ([K][rows]): tile 32 x ROWS, stored [k][ROWS].
-template <int ROWS>
-__device__ __forceinline__ void load_rc(const float* __restrict__ g, int ld, int row0, int nrows, int k0, int kend,
-                                        bool fast, float4 (&regs)[ROWS / 32]) {
-  const int t = threadIdx.x;
-  constexpr int F4_PER_K = ROWS / 4;           // float4 per k-row of the tile
-  constexpr int K_PER_PASS = 256 / F4_PER_K;   // k-rows covered by the 256 threads per pass
-  if (fast) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i)
-      regs[i] = ld16(g + (int64_t)(k0 + (t / F4_PER_K) + K_PER_PASS * i) * ld + row0 + 4 * (t % F4_PER_K));
-  } else {
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int k = k0 + (t / F4_PER_K) + K_PER_PASS * i;
-      const int r = row0 + 4 * (t % F4_PER_K);
-      const int64_t base = (int64_t)k * ld + r;
-      const bool kok = k < kend;
-      regs[i].x = ld_guard(g, base, kok && r < nrows);
-      regs[i].y = ld_guard(g, base + 1, kok && r + 1 < nrows);
-      regs[i].z = ld_guard(g, base + 2, kok && r + 2 < nrows);
-      regs[i].w = ld_guard(g, base + 3, kok && r + 3 < nrows);
-    }
-  }
-}
-template <int ROWS>
-__device__ __forceinline__ void store_rc(float* __restrict__ lds, const float4 (&regs)[ROWS / 32]) {
-  const int t = threadIdx.x;
-  constexpr int F4_PER_K = ROWS / 4;
-  constexpr int K_PER_PASS = 256 / F4_PER_K;
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
-    float* d = lds + ((t / F4_PER_K) + K_PER_PASS * i) * ROWS + 4 * (t % F4_PER_K);
-    *reinterpret_cast<float4*>(d) = regs[i];
-  }
-}
-
-template <int LA, int ROWS>
-__device__ __forceinline__ float frag(const float* __restrict__ lds, int row, int k) {
-  if (LA == LAYOUT_KC) return lds[row * kPadK + k];
-  return lds[k * ROWS + row];
-}
-
-// C[M][N] (+)= sum over pairs  A_pair (M x K) * B_pair (K x N), operands in layouts LA / LB.
-// grid = (ceil(N/TN), ceil(M/128), splits), block = 256: TN = 32 -> 4 waves of 32 x 32 stacked along M; TN = 64 -> 2 x 2 waves of 64 x 32.
-// FAST: every tile is interior (M % 128 == 0, N % TN == 0, K % 32 == 0, leading dimensions % 4 == 0; checked by
-// launch_gemm).  The instance then has NO edge path: with the ragged-tile branches in the loop hipcc puts an
-// `s_waitcnt vmcnt(0)` at the top of every step (the control-flow join), which serialises the two-stage
-// register prefetch — step s+1's loads had to land BEFORE step s's MFMAs instead of behind them.
-// gemm_body: one workgroup's tile; (bx, by, bz) = (N tile, M tile, split).  k_gemm maps them from blockIdx; the grouped
-// launch of the hoisted direction products (k_hoist) from a per-problem block table.  `smem`: (2 * A_ELEMS + 2 * B_ELEMS)
-// floats of LDS provided by the kernel.
-template <int LA, int LB, int TN>
-struct GemmLds {
-  static constexpr int A_ELEMS = (LA == LAYOUT_KC) ? kTM * kPadK : kTK * kTM;
-  static constexpr int B_ELEMS = (LB == LAYOUT_KC) ? TN * kPadK : kTK * TN;
-  static constexpr int FLOATS = 2 * A_ELEMS + 2 * B_ELEMS;
-};
-template <int LA, int LB, int TN, bool FAST, bool BF, bool AS = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* __restrict__ smem) {
-  static_assert(TN == 64 || TN == 32, "tile width");
-  constexpr int NACC = TN / 32;  // 32x32 accumulator tiles per wave: waves are 2x2 (64x32 each) or 4x1 (32x32 each)
-  constexpr int A_ELEMS = GemmLds<LA, LB, TN>::A_ELEMS;
-  constexpr int B_ELEMS = GemmLds<LA, LB, TN>::B_ELEMS;
-  float (*sA)[A_ELEMS] = reinterpret_cast<float (*)[A_ELEMS]>(smem);
-  float (*sB)[B_ELEMS] = reinterpret_cast<float (*)[B_ELEMS]>(smem + 2 * A_ELEMS);
-
-  const int n0 = bx * TN;
-  const int m0 = by * kTM;
-  int split = bz, nsplit = a.splits, npairs = a.pairs, first = 0;
-  if (a.pair_split > 0) {   // this workgroup's K range belongs to ONE of the two operand pairs (workgroup-uniform)
-    first = split >= a.pair_split ? 1 : 0;
-    nsplit = first ? a.splits - a.pair_split : a.pair_split;
-    split = first ? split - a.pair_split : split;
-    npairs = 1;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = TN == 64 ? (wave >> 1) * 64 : wave * 32;  // wave's row offset inside the tile
-  const int wn = TN == 64 ? (wave & 1) * 32 : 0;           // wave's col offset
-  const int li = lane & 31, lk = lane >> 5;
-
-  // K range of this split (multiples of kTK except possibly the end)
-  const int ksteps_total = (a.K + kTK - 1) / kTK;
-  const int per = (ksteps_total + nsplit - 1) / nsplit;
-  const int kbeg = split * per * kTK;
-  const int kend = min(a.K, (split + 1) * per * kTK);
-  const int nsteps_pair = kbeg < kend ? (kend - kbeg + kTK - 1) / kTK : 0;
-  const int nsteps = nsteps_pair * npairs;
-
-  // Two K-interleaved accumulators per 32x32 output tile: consecutive MFMAs never depend on each other, so
-  // the instructions hipcc schedules between them (LDS reads, waits) do not stretch a dependent chain.
-  constexpr int KI = 2;
-  f32x16 acc[NACC * KI];
-#pragma unroll
-  for (int i = 0; i < NACC * KI; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  // (Measured, not kept: THREE register stages — loads issued three steps ahead, two steps to land; 142 VGPRs, still three
-  //  workgroups per CU: 296 vs 300 steps/s CG, 624 vs 631 Neumann.  Load latency is not what the K loop waits for.)
-  // Two register stages: the global loads of step s+2 are issued before the MFMAs of step s, so every
-  // load has two compute phases (plus the other resident workgroups) to land.  The loop body is kept free
-  // of control flow (a step index past the end re-loads the last tile, which is never used): with branches
-  // in the body hipcc shuttles all 32 accumulator registers AGPR -> VGPR -> AGPR around every step and
-  // drains the load queue at each join.
-  float4 ra0[kTM / 32], rb0[TN / 32], ra1[kTM / 32], rb1[TN / 32];
-  float4 rq0[TN / 32], rq1[TN / 32];   // BF: the second N-side operand of the stage (previous direction)
-  float bs0 = 0.f, bs1 = 0.f;          // BF: its weight for the stage's pair (beta or 0), workgroup-uniform
-  const float beta = BF ? (float)a.scal[S_BETA] : 0.f;
-  // (selects, not indices: a descriptor built inside a kernel — k_hoist — must not be pushed to scratch memory)
-  const GemmPair pr0 = first ? a.pr[1] : a.pr[0];
-  const GemmPair pr1 = (npairs > 1 || first) ? a.pr[1] : a.pr[0];   // operand bases live in SGPRs, not re-fetched per step
-  auto gload = [&](int step, float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32], float4 (&rq)[TN / 32], float& bs) {
-    step = min(step, nsteps - 1);
-    const bool second = step >= nsteps_pair;          // workgroup-uniform
-    const int k0 = kbeg + (step - (second ? nsteps_pair : 0)) * kTK;
-    const float* gA = second ? pr1.A : pr0.A;
-    const float* gB = second ? pr1.B : pr0.B;
-    const int lda = second ? pr1.lda : pr0.lda, ldb = second ? pr1.ldb : pr0.ldb;
-    const bool kfull = FAST || k0 + kTK <= kend;
-    const bool fa = FAST || (kfull && m0 + kTM <= a.M && (lda & 3) == 0);
-    const bool fb = FAST || (kfull && n0 + TN <= a.N && (ldb & 3) == 0);
-    if (LA == LAYOUT_KC) load_kc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
-    else load_rc<kTM>(gA, lda, m0, a.M, k0, kend, fa, ra);
-    if (AS) {   // K-split slabs of the M-side operand, summed in slab order (workgroup-uniform count)
-      const int ns = second ? pr1.a_slabs : pr0.a_slabs, stride = second ? pr1.a_slab_stride : pr0.a_slab_stride;
-      for (int sl = 1; sl < ns; ++sl) {
-        float4 rs[kTM / 32];
-        if (LA == LAYOUT_KC) load_kc<kTM>(gA + (int64_t)sl * stride, lda, m0, a.M, k0, kend, fa, rs);
-        else load_rc<kTM>(gA + (int64_t)sl * stride, lda, m0, a.M, k0, kend, fa, rs);
-#pragma unroll
-        for (int i = 0; i < kTM / 32; ++i) { ra[i].x += rs[i].x; ra[i].y += rs[i].y; ra[i].z += rs[i].z; ra[i].w += rs[i].w; }
-      }
-    }
-    if (LB == LAYOUT_KC) load_kc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
-    else load_rc<TN>(gB, ldb, n0, a.N, k0, kend, fb, rb);
-    if (BF) {
-      const float* gQ = second ? pr1.B2 : pr0.B2;
-      bs = (second ? pr1.mix : pr0.mix) ? beta : 0.f;
-      if (LB == LAYOUT_KC) load_kc<TN>(gQ, ldb, n0, a.N, k0, kend, fb, rq);
-      else load_rc<TN>(gQ, ldb, n0, a.N, k0, kend, fb, rq);
-    }
-  };
-  auto lstore = [&](int buf, const float4 (&ra)[kTM / 32], float4 (&rb)[TN / 32], const float4 (&rq)[TN / 32], float bs) {
-    if (BF) {   // same two roundings as k_cg_pdir: p = r' + (beta * p_old); a pair without mix has bs = 0 and B2 = B
-#pragma unroll
-      for (int i = 0; i < TN / 32; ++i) {
-        rb[i].x = __fadd_rn(rb[i].x, __fmul_rn(bs, rq[i].x)); rb[i].y = __fadd_rn(rb[i].y, __fmul_rn(bs, rq[i].y));
-        rb[i].z = __fadd_rn(rb[i].z, __fmul_rn(bs, rq[i].z)); rb[i].w = __fadd_rn(rb[i].w, __fmul_rn(bs, rq[i].w));
-      }
-    }
-    if (LA == LAYOUT_KC) store_kc<kTM>(sA[buf], ra); else store_rc<kTM>(sA[buf], ra);
-    if (LB == LAYOUT_KC) store_kc<TN>(sB[buf], rb); else store_rc<TN>(sB[buf], rb);
-  };
-  auto compute = [&](int buf) {
-    const float* A = sA[buf];
-    const float* B = sB[buf];
-    // Lane l works on k = 8*k8 + 4*(l>>5) + t, t = 0..3, in the t-th MFMA of each group of four: any
-    // assignment is valid as long as the A and the B fragment of a lane refer to the same k.  K-contiguous
-    // tiles therefore deliver four k per lane with ONE ds_read_b128.  (The tail of a K range is zero-filled
-    // in LDS, so running all 32 k of a partial tile only adds zeros.)
-#pragma unroll
-    for (int k8 = 0; k8 < kTK / 8; ++k8) {
-      const int kb = 8 * k8 + 4 * lk;
-      float av[NACC][4], bv[4];
-      if (LA == LAYOUT_KC) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(A + (wm + 32 * i + li) * kPadK + kb);
-          av[i][0] = v.x; av[i][1] = v.y; av[i][2] = v.z; av[i][3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) av[i][t] = A[(kb + t) * kTM + wm + 32 * i + li];
-      }
-      if (LB == LAYOUT_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(B + (wn + li) * kPadK + kb);
-        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv[t] = B[(kb + t) * TN + wn + li];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-          acc[i * KI + (t & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i * KI + (t & 1)], 0, 0, 0);
-    }
-  };
-
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-  if (nsteps > 0) {
-    gload(0, ra0, rb0, rq0, bs0);
-    gload(1, ra1, rb1, rq1, bs1);
-    lstore(0, ra0, rb0, rq0, bs0);
-    __syncthreads();
-    int step = 0;
-    for (; step + 1 < nsteps; step += 2) {
-      // Per step: issue the loads of tile s+2, hand tile s+1 (loaded a step ago) to the OTHER LDS buffer, then
-      // run this tile's MFMAs — the LDS stores complete in the shadow of the MFMAs, so the barrier at the end
-      // of the step finds them done.  (The buffer being written was last read before the previous barrier.)
-      gload(step + 2, ra0, rb0, rq0, bs0);   // even step: tile in buffer 0, next tile parked in stage 1
-      lstore(1, ra1, rb1, rq1, bs1);
-      SCHED_FENCE();
-      compute(0);
-      __syncthreads();
-      gload(step + 3, ra1, rb1, rq1, bs1);   // odd step: tile in buffer 1, next tile parked in stage 0
-      lstore(0, ra0, rb0, rq0, bs0);
-      SCHED_FENCE();
-      compute(1);
-      __syncthreads();
-    }
-    if (step < nsteps) compute(0);  // odd count: the last tile was stored to buffer 0 by the loop's second half
-  }
-#undef SCHED_FENCE
-
-  // epilogue: C/D fragment layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float* out = a.out + (a.splits > 1 || a.out_rows > 0 ? (int64_t)bz * a.out_rows * a.ldo : 0);
-  if (FAST && TN == 32 && LA == LAYOUT_KC && !a.addend && a.xpose_out) {
-    // all-interior 128 x 32 tile: transpose through LDS (the A buffer, free now) so the slab leaves as four 16-B stores
-    // per lane (8 lanes cover one 128-B row segment) instead of sixteen 4-B stores
-    __syncthreads();                       // every wave is done reading the operand tiles
-    float* sC = sA[0];                     // [128][kPadK]
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int row = wm + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
-      sC[row * kPadK + li] = acc[0][rg] + acc[1][rg];
-    }
-    __syncthreads();
-    double dacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int row = idx >> 3, c4 = 4 * (idx & 7);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * kPadK + c4);
-      f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)(m0 + row) * a.ldo + n0 + c4);
-      if (a.nt_out) __builtin_nontemporal_store(v, dst);
-      else *dst = v;
-      if (a.dotX) {   // workgroup-uniform
-        const float4 xv = ld16(a.dotX + (int64_t)(m0 + row) * a.ldo + n0 + c4);
-        dacc += (double)xv.x * v.x + (double)xv.y * v.y + (double)xv.z * v.z + (double)xv.w * v.w;
-      }
-    }
-    if (a.dotX) {
-      const double tot = block_sum(dacc, reinterpret_cast<double*>(sB[0]));   // (the B buffers are free; sC is the A buffer)
-      if (threadIdx.x == 0) *a.dot_out = tot;
-    }
-    return;
-  }
-  const int col = n0 + wn + li;
-  if (col < a.N) {
-#pragma unroll
-    for (int t = 0; t < NACC; ++t) {
-#pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int row = m0 + wm + 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
-        if (row < a.M) {
-          float v = acc[t * KI][rg] + acc[t * KI + 1][rg];
-          if (a.addend) v += a.addend_scale * a.addend[(int64_t)row * a.ldo + col];
-          if (a.nt_out) __builtin_nontemporal_store(v, &out[(int64_t)row * a.ldo + col]);
-          else out[(int64_t)row * a.ldo + col] = v;
-        }
-      }
-    }
-  }
-}
-
-template <int LA, int LB, int TN, bool FAST, bool BF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 32 ? 3 : 2, TN == 32 ? 3 : 2))) void k_gemm(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[GemmLds<LA, LB, TN>::FLOATS];
-  gemm_body<LA, LB, TN, FAST, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// ---- fused recurrence epilogues ("one pass": the weight-shaped HVP output never round-trips through HBM) ------
-// Instead of storing H*direction, the kernels that produce it (k_outer, k_head_outer, k_bias_hvp) apply the
-// CG / Neumann recurrence to the matching slices of the flat state vectors while the tile is still on chip:
-//   FUSE_CG       Hp = raw + shift*p ; r <- r - alpha*Hp ; x <- x + alpha*p [x <- out_scale*x] ; partial r'.r'
-//                 (cg.py:47-51; alpha = rr / (cg_alpha * p.Hp) was computed BEFORE these kernels from the batch-sized
-//                 factors of the R-chain — see k_cg_alpha — so there is no N-sized H*p vector at all)
-//   FUSE_NEUMANN  Hv = raw + shift*v ; v' <- v - alpha*Hv (written to the OTHER direction buffer: the R-backward
-//                 GEMMs of this HVP still read v) ; p <- p + v' [p <- out_scale*p]          (neumann.py:62-64,66)
-// Same rounding sequence as bhg_vector.hip's recurrence kernels (products rounded before add/sub, never contracted).
-enum : int { FUSE_NONE = 0, FUSE_CG = 1, FUSE_NEUMANN = 2 };
-struct FuseArgs {
-  float* a;          // CG: r (in/out)          Neumann: v_out (out)
-  float* b;          // CG: x (in/out)          Neumann: p (in/out)
-  float* d;          // the direction slice:    CG: p (in; in/out when lazy)    Neumann: v_in (in)
-  const double* scal;  // CG: device scalars, alpha = scal[S_ALPHA], beta = scal[S_BETA]
-  double* part;        // CG: per-workgroup partials -> part[q * part_stride + part_base + linear block id],
-  int part_base;       //     q = 0: r'.r'   q = 1: r'.p   q = 2: p.p   (p = this iteration's direction)
-  int part_stride;
-  float alpha;       // Neumann: step length (host constant); CG with alpha_ready: computed by the calling kernel itself
-  int alpha_ready;
-  int kpar;          // CG: iteration parity (alpha of iteration k lives in scal[S_ALPHA_RING + (k & 1)])
-  float shift;       // operator = raw HVP + shift * I
-  float out_scale;   // applied to x (CG) / p (Neumann) when apply_out != 0: the final scaling + negation of the solve
-  int apply_out;
-  int x_mode;        // CG, lazy slices only: 0 = x += alpha*p | 1 = leave x alone this iteration | 2 = catch up:
-                     // x = (x + alpha_prev*p_old) + alpha*p — the very two roundings of two separate updates, with x read
-                     // and written every OTHER iteration only (p_old, last iteration's direction, is loaded anyway)
-  int lazy;          // CG: the slice at d still holds the PREVIOUS direction; this iteration's is r + beta * d — formed
-                     // here (same roundings as k_cg_pdir) and written back, so no kernel of its own updates it (cg.py:53)
-};
-struct FuseAcc { double rr, rp, pp; };
-__device__ __forceinline__ float fz_mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float fz_add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float fz_sub(float a, float b) { return __fsub_rn(a, b); }
-// one element: hv = raw HVP value, dv = direction (CG lazy: previous direction), av / bv = the two state values;
-// results back in av / bv, the direction actually used back in dv.
-template <int MODE>
-__device__ __forceinline__ void fuse_elem(const FuseArgs& f, float alpha, float beta, float hv, float& dv, float& av,
-                                          float& bv, FuseAcc& acc, float alpha_prev = 0.f) {
-  const float d_old = dv;
-  if (MODE == FUSE_CG && f.lazy) dv = fz_add(av, fz_mul(beta, dv));
-  if (f.shift != 0.f) hv = fz_add(hv, fz_mul(f.shift, dv));
-  if (MODE == FUSE_CG) {
-    const float nr = fz_sub(av, fz_mul(alpha, hv));
-    float nx = bv;
-    if (f.x_mode == 2) nx = fz_add(nx, fz_mul(alpha_prev, d_old));
-    if (f.x_mode != 1) nx = fz_add(nx, fz_mul(alpha, dv));
-    if (f.apply_out) nx = fz_mul(f.out_scale, nx);
-    acc.rr += (double)nr * nr;
-    acc.rp += (double)nr * dv;
-    acc.pp += (double)dv * dv;
-    av = nr; bv = nx;
-  } else {
-    const float nv = fz_sub(dv, fz_mul(alpha, hv));
-    // x_mode for Neumann: 1 = leave the accumulator p alone this iteration, 2 = catch up: p = (p + v_in) + v' — v_in is
-    // last iteration's v' (the direction just read), so these are the very roundings of two separate p += v' updates
-    float np = bv;
-    if (f.x_mode == 2) np = fz_add(np, dv);
-    if (f.x_mode != 1) np = fz_add(np, nv);
-    if (f.apply_out) np = fz_mul(f.out_scale, np);
-    av = nv; bv = np;
-  }
-}
-template <int MODE>
-__device__ __forceinline__ float fuse_alpha(const FuseArgs& f) {
-  return (MODE == FUSE_CG && !f.alpha_ready) ? (float)f.scal[S_ALPHA] : f.alpha;
-}
-template <int MODE>
-__device__ __forceinline__ float fuse_beta(const FuseArgs& f) {
-  return MODE == FUSE_CG && f.lazy ? (float)f.scal[S_BETA] : 0.f;
-}
-// block-wide sums of the three partials -> part[q][part_base + idx]   (all threads of the 256-thread block call it)
-__device__ __forceinline__ void fuse_store_partials(const FuseArgs& f, const FuseAcc& acc, int idx, double* red) {
-  const double s0 = block_sum(acc.rr, red);
-  const double s1 = block_sum(acc.rp, red);
-  const double s2 = block_sum(acc.pp, red);
-  if (threadIdx.x == 0) {
-    double* p0 = f.part + f.part_base + idx;
-    p0[0] = s0;
-    p0[f.part_stride] = s1;
-    p0[2 * (int64_t)f.part_stride] = s2;
-  }
-}
-
-// ---- weight-shaped outputs: C[M][N] = sum_pairs A_pair^T B_pair (+ addend), K = batch (<= 128) -----------
-// The accumulators are transposed through LDS so C (and the addend) move as coalesced 16-B accesses.
-constexpr int kOK = 128;                      // max K of the outer-product kernel
-constexpr int kOH = kOK / 2;                  // K rows per pipeline stage (half of a pair)
-constexpr int kOA = kOH * kTM / (256 * 4);    // float4 per thread for one [64][128] A stage = 8
-constexpr int kOB = kOH * kTN / (256 * 4);    // = 4
-constexpr int kCPad = kTN + 4;                // LDS row stride of the C staging tile (16-B aligned rows)
-
-// Each operand pair is cut in two K halves => up to 4 pipeline stages; a stage is ONE round of global
-// loads (all in flight together) parked in registers while the previous stage's MFMAs run from the
-// single 40-KiB LDS tile, so 3-4 workgroups share a CU and cover each other's load/epilogue phases.
-// FAST: all tiles interior and 16-B aligned (checked by the launcher): no ragged path, loads unconditional with
-// clamped row index and a 0/1 multiplier (same reasons as k_gemm's FAST instance).
-// PRE (fused, FAST only): the last stage re-loads nothing; the first half tile's state slices are requested instead, so
-// they travel under that stage's MFMAs, and the second half's are requested before the first half is processed.
-template <bool FAST, int MODE, bool PRE = false>
-__device__ __forceinline__ void outer_body(const GemmArgs& a, const FuseArgs& fz, const int bx, const int by, const int gx) {
-  static_assert(!PRE || (FAST && MODE != FUSE_NONE), "PRE is the fused all-interior epilogue");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ double red_rr[kWaves];
-  const int K = a.K;
-  const int nsp = a.kstages;                          // stages per pair
-  const int Kh = (((K + nsp - 1) / nsp) + 1) & ~1;    // rows per stage, even, <= kOH
-  float* sA = smem;                       // [Kh][128]
-  float* sB = smem + Kh * kTM;            // [Kh][64]
-  const int n0 = bx * kTN;
-  const int m0 = by * kTM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
-  const int li = lane & 31, lk = lane >> 5;
-  const int t = threadIdx.x;
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  float4 ra[kOA], rb[kOB];
-  // stage s: pair s / nsp, K rows [ (s % nsp)*Kh, min(K, (s % nsp)*Kh + Kh) )
-  const GemmPair pr0 = a.pr[0];
-  const GemmPair pr1 = a.pr[a.pairs > 1 ? 1 : 0];
-  auto gload = [&](int stage) {
-    const bool second = stage >= nsp;             // workgroup-uniform
-    const GemmPair pr = {second ? pr1.A : pr0.A, second ? pr1.B : pr0.B, second ? pr1.lda : pr0.lda,
-                         second ? pr1.ldb : pr0.ldb};
-    const int kb = (stage - (second ? nsp : 0)) * Kh;
-    const bool fa = FAST || (m0 + kTM <= a.M && (pr.lda & 3) == 0);  // workgroup-uniform
-    const bool fb = FAST || (n0 + kTN <= a.N && (pr.ldb & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < kOA; ++i) {   // A stage: 32 float4 per k-row, 8 k-rows per pass
-      const int kl = (t >> 5) + 8 * i;
-      const int k = kb + kl;
-      const int r = m0 + 4 * (t & 31);
-      const bool kok = kl < Kh && k < K;
-      const int64_t base = (int64_t)(kok ? k : 0) * pr.lda + r;
-      if (fa) {
-        const float4 v = ld16(pr.A + base);
-        const float mz = kok ? 1.f : 0.f;   // multiplier, not a select: hipcc turns the select into a branch around the load
-        ra[i] = make_float4(v.x * mz, v.y * mz, v.z * mz, v.w * mz);
-      } else {
-        ra[i].x = ld_guard(pr.A, base, kok && r < a.M);
-        ra[i].y = ld_guard(pr.A, base + 1, kok && r + 1 < a.M);
-        ra[i].z = ld_guard(pr.A, base + 2, kok && r + 2 < a.M);
-        ra[i].w = ld_guard(pr.A, base + 3, kok && r + 3 < a.M);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kOB; ++i) {   // B stage: 16 float4 per k-row, 16 k-rows per pass
-      const int kl = (t >> 4) + 16 * i;
-      const int k = kb + kl;
-      const int r = n0 + 4 * (t & 15);
-      const bool kok = kl < Kh && k < K;
-      const int64_t base = (int64_t)(kok ? k : 0) * pr.ldb + r;
-      if (fb) {
-        const float4 v = ld16(pr.B + base);
-        const float mz = kok ? 1.f : 0.f;
-        rb[i] = make_float4(v.x * mz, v.y * mz, v.z * mz, v.w * mz);
-      } else {
-        rb[i].x = ld_guard(pr.B, base, kok && r < a.N);
-        rb[i].y = ld_guard(pr.B, base + 1, kok && r + 1 < a.N);
-        rb[i].z = ld_guard(pr.B, base + 2, kok && r + 2 < a.N);
-        rb[i].w = ld_guard(pr.B, base + 3, kok && r + 3 < a.N);
-      }
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < kOA; ++i) {
-      const int k = (t >> 5) + 8 * i;
-      if (k < Kh) *reinterpret_cast<float4*>(sA + k * kTM + 4 * (t & 31)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < kOB; ++i) {
-      const int k = (t >> 4) + 16 * i;
-      if (k < Kh) *reinterpret_cast<float4*>(sB + k * kTN + 4 * (t & 15)) = rb[i];
-    }
-  };
-  auto compute = [&](int stage) {
-    const int kb = (stage >= nsp ? stage - nsp : stage) * Kh;
-    const int kvalid = min(Kh, K - kb);           // rows of this stage that carry data (rest is zero)
-    const int nkp = kvalid > 0 ? (kvalid + 1) / 2 : 0;
-    int kp = 0;
-    for (; kp + 4 <= nkp; kp += 4) {  // 12 LDS reads in flight, then 8 MFMAs
-      float b[4], a0[4], a1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = 2 * (kp + u) + lk;
-        b[u] = sB[k * kTN + wn + li];
-        a0[u] = sA[k * kTM + wm + li];
-        a1[u] = sA[k * kTM + wm + 32 + li];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], acc[1], 0, 0, 0);
-      }
-    }
-    for (; kp < nkp; ++kp) {
-      const int k = 2 * kp + lk;
-      const float b = sB[k * kTN + wn + li];
-      const float a0 = sA[k * kTM + wm + li];
-      const float a1 = sA[k * kTM + wm + 32 + li];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
-    }
-  };
-
-  const int nstages = nsp * a.pairs;
-  const bool use_x = fz.x_mode != 1 || MODE == FUSE_NONE;   // workgroup-uniform
-  float4 pdv[4], pav[4], pbv[4];                // PRE: state slices of half tile 0
-  auto hload = [&](int hb, float4* dv, float4* av, float4* bv) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (t >> 4) + 16 * (4 * hb + i);
-      const int64_t off = (int64_t)(m0 + row) * a.ldo + n0 + 4 * (t & 15);
-      dv[i] = ld16(fz.d + off);
-      if (MODE == FUSE_CG) av[i] = ld16(fz.a + off);
-      bv[i] = use_x ? ld16(fz.b + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  gload(0);
-  lstore();
-  if (PRE) {
-    for (int stage = 0; stage + 1 < nstages; ++stage) {
-      gload(stage + 1);                         // in flight during this stage's MFMAs
-      __syncthreads();                          // this stage's tile is complete in LDS
-      compute(stage);
-      __syncthreads();                          // everyone is done reading it
-      lstore();
-    }
-    hload(0, pdv, pav, pbv);
-    __syncthreads();
-    compute(nstages - 1);
-  } else {
-    for (int stage = 0; stage < nstages; ++stage) {
-      gload(min(stage + 1, nstages - 1));       // in flight during this stage's MFMAs (the last one re-loads itself: unused)
-      __syncthreads();                          // this stage's tile is complete in LDS
-      compute(stage);
-      __syncthreads();                          // everyone is done reading it
-      lstore();                                 // (after the last stage: a dead store, overwritten by the C staging below)
-    }
-  }
-  __syncthreads();  // LDS is reused as the C staging tile below
-
-  // ---- epilogue: acc -> LDS [128][kCPad] -> coalesced float4 rows (+ addend) -> global
-  float* sC = smem;
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int row = wm + 32 * tt + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
-      sC[row * kCPad + wn + li] = acc[tt][rg];
-    }
-  __syncthreads();
-  const bool vec_ok = ((a.ldo & 3) == 0);
-  if (MODE != FUSE_NONE) {
-    // fused recurrence: the tile's slices of the state vectors are read/written at the SAME element offsets as C
-    // (the weight tensor W_l occupies flat[start_l + row*ldo + col]); two half-tiles of 4 float4 per thread so the
-    // 8-12 state loads of a half are all in flight before the first use.
-    const float alpha = fuse_alpha<MODE>(fz);
-    const float beta = fuse_beta<MODE>(fz);
-    const bool wr_d = MODE == FUSE_CG && fz.lazy;
-    const float alpha_prev = (MODE == FUSE_CG && fz.x_mode == 2) ? (float)fz.scal[S_ALPHA_RING + (fz.kpar ^ 1)] : 0.f;
-    FuseAcc racc{0.0, 0.0, 0.0};
-    if constexpr (PRE) {
-      float4 dv1[4], av1[4], bv1[4];
-      if (MODE != FUSE_CG) hload(1, dv1, av1, bv1);   // (CG: three state vectors — both halves at once do not fit 128 registers)
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        if (MODE == FUSE_CG && hb == 1) hload(1, dv1, av1, bv1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = (t >> 4) + 16 * (4 * hb + i);
-          const int c4 = 4 * (t & 15);
-          const float4 hv = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
-          const int64_t off = (int64_t)(m0 + row) * a.ldo + n0 + c4;
-          float4 na = MODE == FUSE_CG ? (hb ? av1[i] : pav[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          float4 nb = hb ? bv1[i] : pbv[i], nd = hb ? dv1[i] : pdv[i];
-          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc, alpha_prev);
-          *reinterpret_cast<float4*>(fz.a + off) = na;
-          if (use_x) *reinterpret_cast<float4*>(fz.b + off) = nb;
-          if (wr_d) *reinterpret_cast<float4*>(fz.d + off) = nd;
-        }
-      }
-      if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
-      return;
-    }
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      float4 dv[4], av[4], bv[4];
-      bool ok[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (t >> 4) + 16 * (4 * hb + i);
-        const int c4 = 4 * (t & 15);
-        const int grow = m0 + row, gcol = n0 + c4;
-        ok[i] = FAST || (grow < a.M && vec_ok && gcol + 4 <= a.N);
-        const int64_t off = ok[i] ? (int64_t)grow * a.ldo + gcol : 0;
-        dv[i] = ld16(fz.d + off);
-        if (MODE == FUSE_CG) av[i] = ld16(fz.a + off);
-        bv[i] = use_x ? ld16(fz.b + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (t >> 4) + 16 * (4 * hb + i);
-        const int c4 = 4 * (t & 15);
-        const int grow = m0 + row, gcol = n0 + c4;
-        const float4 hv = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
-        const int64_t off = (int64_t)grow * a.ldo + gcol;
-        if (ok[i]) {
-          float4 na = MODE == FUSE_CG ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), nb = bv[i], nd = dv[i];
-          fuse_elem<MODE>(fz, alpha, beta, hv.x, nd.x, na.x, nb.x, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.y, nd.y, na.y, nb.y, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.z, nd.z, na.z, nb.z, racc, alpha_prev);
-          fuse_elem<MODE>(fz, alpha, beta, hv.w, nd.w, na.w, nb.w, racc, alpha_prev);
-          *reinterpret_cast<float4*>(fz.a + off) = na;
-          if (use_x) *reinterpret_cast<float4*>(fz.b + off) = nb;
-          if (wr_d) *reinterpret_cast<float4*>(fz.d + off) = nd;
-        } else if (!FAST && grow < a.M) {   // ragged right edge / odd leading dimension: element by element
-          const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
-          for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
-            float na = MODE == FUSE_CG ? fz.a[off + j] : 0.f, nb = use_x ? fz.b[off + j] : 0.f, nd = fz.d[off + j];
-            fuse_elem<MODE>(fz, alpha, beta, hh[j], nd, na, nb, racc, alpha_prev);
-            fz.a[off + j] = na;
-            if (use_x) fz.b[off + j] = nb;
-            if (wr_d) fz.d[off + j] = nd;
-          }
-        }
-      }
-    }
-    if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < kTM * kTN / (256 * 4); ++i) {  // 8 float4 per thread
-    const int row = (t >> 4) + 16 * i;
-    const int c4 = 4 * (t & 15);
-    const int grow = m0 + row, gcol = n0 + c4;
-    if (!FAST && (grow >= a.M || gcol >= a.N)) continue;
-    float4 v = *reinterpret_cast<const float4*>(sC + row * kCPad + c4);
-    float* dst = a.out + (int64_t)grow * a.ldo + gcol;
-    if (FAST || (vec_ok && gcol + 4 <= a.N)) {
-      if (a.addend) {
-        const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)grow * a.ldo + gcol);
-        v.x += a.addend_scale * ad.x; v.y += a.addend_scale * ad.y;
-        v.z += a.addend_scale * ad.z; v.w += a.addend_scale * ad.w;
-      }
-      *reinterpret_cast<float4*>(dst) = v;
-    } else {
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      for (int j = 0; j < 4 && gcol + j < a.N; ++j) {
-        float o = vv[j];
-        if (a.addend) o += a.addend_scale * a.addend[(int64_t)grow * a.ldo + gcol + j];
-        dst[j] = o;
-      }
-    }
-  }
-}
-
-template <bool FAST, int MODE>
-__global__ __launch_bounds__(256) void k_outer(GemmArgs a, FuseArgs fz) {
-  outer_body<FAST, MODE>(a, fz, blockIdx.x, blockIdx.y, gridDim.x);
-}
-
-// ---- split-K epilogues ---------------------------------------------------------------------------------
-// out[m][n] = mask[m][n] * (sum_s part[s][m][n] + bias[n]);  rows >= B are written as zero.
-// One float4 per thread when N % 4 == 0 (all split loads independent => in flight together);
-// fixed summation order over splits => deterministic.
-template <int VEC>
-__global__ __launch_bounds__(256) void k_reduce_mask(const float* __restrict__ part, int splits, int slab,
-                                                     const float* __restrict__ bias, const float* __restrict__ mask,
-                                                     float* __restrict__ out, int rows, int N, int B,
-                                                     float* __restrict__ relu_mask_out) {
-  // relu_mask_out != NULL: forward-pass mode — out = relu(sum + bias), relu_mask_out = (sum + bias > 0)
-  const int64_t total = (int64_t)rows * N / VEC;
-  const int nv = N / VEC;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int m = (int)(i / nv), n = (int)(i - (int64_t)m * nv) * VEC;
-    float v[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
-    if (m < B) {
-      if constexpr (VEC == 4) {
-        // Batches of 8 slabs: all 8 loads (plus bias and mask) are issued before the first add, so a
-        // reduce costs one or two L2 round trips instead of `splits` dependent ones.  Lanes past the
-        // last slab re-read it (an L1 hit) and are not added; the summation order stays s = 0, 1, ...
-        constexpr int NB = 8;    // (measured: 16 in flight — one round trip for the benchmark's 12-16 slabs — is SLOWER, 5.5-6.1 vs 4.9 us)
-        const float* p0 = part + i * VEC;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
-        if (mask) mv = *reinterpret_cast<const float4*>(mask + i * VEC);
-        for (int s0 = 0; s0 < splits; s0 += NB) {
-          float4 t[NB];
-#pragma unroll
-          for (int u = 0; u < NB; ++u) {
-            const int s = s0 + u < splits ? s0 + u : splits - 1;
-            t[u] = *reinterpret_cast<const float4*>(p0 + (int64_t)s * slab);
-          }
-#pragma unroll
-          for (int u = 0; u < NB; ++u) {
-            if (s0 + u < splits) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
-          }
-        }
-        v[0] = (v[0] + bv.x) * mv.x; v[1] = (v[1] + bv.y) * mv.y;
-        v[2] = (v[2] + bv.z) * mv.z; v[3] = (v[3] + bv.w) * mv.w;
-      } else {
-        for (int s = 0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
-        if (bias) v[0] += bias[n];
-        if (mask) v[0] *= mask[i];
-      }
-    }
-    if (relu_mask_out) {
-      float mk[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        mk[j] = v[j] > 0.f ? 1.f : 0.f;
-        v[j] = v[j] > 0.f ? v[j] : 0.f;
-      }
-      if constexpr (VEC == 4) *reinterpret_cast<float4*>(relu_mask_out + i * VEC) = make_float4(mk[0], mk[1], mk[2], mk[3]);
-      else relu_mask_out[i] = mk[0];
-    }
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
-    else out[i] = v[0];
-  }
-}
-
-// ---- fused CG solver: step length BEFORE the weight-shaped outputs, direction update after them -------------------
-// p.(H p) from batch-sized factors of the R-chain (no N-sized H p exists in the fused solver):
-//   p.Hp = sum_b Rz_b . Rd_L,b  +  2 sum_{l>=1} <delta_l V_l, Rh_{l-1}>  +  shift * p.p
-// (second directional derivative of the loss: the Gauss-Newton term through the softmax-CE Hessian plus the
-//  layer-bilinear terms; the identity is checked in fp64 by tests/test_host_logic.py against p . autograd-HVP).
-// den = cg_alpha * p.Hp, alpha = rr / den with fp32 division of the fp32-rounded dots, as the reference does
-// (cg.py:42-47).  One workgroup; every partial array is summed in a fixed order.
-struct AlphaArgs {
-  const double* partT1; const double* partT2h; int B;
-  const double* partT2; int nT2;
-  const double* partPP; int nPP;   // nPP = 0: p.p = scal[S_PP] (written by k_cg_beta for the lazy direction)
-  const double* partRR; int nRR;   // iteration 0: r.r partials of bhg_cg_init; later nRR = 0 and r.r = scal[S_RR_NEW]
-  float cg_alpha, shift;
-  double* scal;
-  // Rz(x) = sum_k alpha_k Rz(p_k): x is a linear combination of the directions and the head kernel computes Rz of
-  // every direction anyway, so the mixed second derivative (cg.py:58-68 for this structure) needs no R-forward of its own
-  const float* rz; double* rzx; int nrz; int first;
-  int kpar;   // iteration parity (S_ALPHA_RING slot)
-  // global-batch CG (bhg_mlp_cg_global_phase): the data part of p.Hp is the SUM over the ranks of what k_php_local left on
-  // each of them (all-reduced by the caller), times inv_world — the T partials of this rank alone are not read
-  const double* php_ext; double inv_world;
-};
-// (Measured, not kept: letting the LAST-arriving workgroup of the chain's final reduce compute alpha — 8-byte agent-scope
-//  atomics + ticket — makes that reduce 10.9 us instead of 4.7 us + a 5.5 us launch: the dependent tail costs what the
-//  launch cost, 264.7 vs 265.3 steps/s in a same-box A/B.)
-// (Callable from blocks of more than kThreads threads — k_wsk_group's alpha block: the threads past kThreads only take part in
-//  the barriers, so the partial sums are split and combined exactly as in k_cg_alpha.)
-__device__ __forceinline__ float alpha_compute(const AlphaArgs& a, const bool writer) {
-  const bool act = threadIdx.x < kThreads;
-  const int tid = act ? (int)threadIdx.x : (1 << 30);
-  __shared__ double red[5][kWaves];
-  __shared__ float s_alpha;
-  // five fixed-order sums at once: every thread takes a strided share of each array (all loads independent), then
-  // one wave reduction per quantity and a fixed-order combine of the wave results
-  // the Rz(x) accumulation's operands do not depend on alpha: their loads go out first
-  constexpr int kRzPer = 8;
-  float rzv[kRzPer];
-  double rzxv[kRzPer];
-#pragma unroll
-  for (int u = 0; u < kRzPer; ++u) {
-    const int i = tid + u * kThreads;
-    rzv[u] = (writer && i < a.nrz) ? a.rz[i] : 0.f;
-    rzxv[u] = (writer && i < a.nrz && !a.first) ? a.rzx[i] : 0.0;
-  }
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < a.B; i += kThreads) acc[0] += a.partT1[i];
-  if (a.partT2h) for (int i = tid; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
-  for (int i = tid; i < a.nT2; i += kThreads)
-    acc[2] += a.partT2[i];
-  if (a.shift != 0.f) for (int i = tid; i < a.nPP; i += kThreads) acc[3] += a.partPP[i];
-  for (int i = tid; i < a.nRR; i += kThreads) acc[4] += a.partRR[i];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const double v = wave_sum(acc[q]);
-    if (act && lane == 0) red[q][w] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWaves; ++i) t += red[q][i];
-      tot[q] = t;
-    }
-    const double rr = a.nRR > 0 ? tot[4] : a.scal[S_RR_NEW];
-    const double pp = a.nPP > 0 ? tot[3] : a.scal[S_PP];
-    const double php_data = a.php_ext ? a.php_ext[0] * a.inv_world : (tot[0] + tot[1] + tot[2]);
-    const double php = php_data + (double)a.shift * pp;
-    const double den = (double)a.cg_alpha * php;
-    const float alpha = (float)rr / (float)den;
-    if (writer) {
-      a.scal[S_RR_OLD] = rr;
-      a.scal[S_PHP] = den;
-      a.scal[S_ALPHA] = (double)alpha;
-      a.scal[S_ALPHA_RING + a.kpar] = (double)alpha;
-    }
-    s_alpha = alpha;
-  }
-  __syncthreads();
-  if (!writer) return s_alpha;
-  const double al = (double)s_alpha;
-#pragma unroll
-  for (int u = 0; u < kRzPer; ++u) {
-    const int i = tid + u * kThreads;
-    if (i < a.nrz) a.rzx[i] = rzxv[u] + al * (double)rzv[u];
-  }
-  for (int i = tid + kRzPer * kThreads; i < a.nrz; i += kThreads) {   // more than 2048 (batch x classes) entries
-    const double v = al * (double)a.rz[i];
-    a.rzx[i] = a.first ? v : a.rzx[i] + v;
-  }
-  return s_alpha;
-}
-__global__ __launch_bounds__(kThreads) void k_cg_alpha(AlphaArgs a) { (void)alpha_compute(a, true); }
-
-// Global-batch CG: this rank's share of p.H_data p — the three partial arrays of the R-chain summed exactly as alpha_compute
-// sums them (same strides, same combine order), left as ONE double for the caller's all-reduce.
-__global__ __launch_bounds__(kThreads) void k_php_local(AlphaArgs a, double* __restrict__ out) {
-  __shared__ double red[3][kWaves];
-  const int tid = threadIdx.x;
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = tid; i < a.B; i += kThreads) acc[0] += a.partT1[i];
-  if (a.partT2h) for (int i = tid; i < a.B; i += kThreads) acc[1] += a.partT2h[i];
-  for (int i = tid; i < a.nT2; i += kThreads) acc[2] += a.partT2[i];
-  const int lane = tid & 63, w = tid >> 6;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const double v = wave_sum(acc[q]);
-    if (lane == 0) red[q][w] = v;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double tot[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWaves; ++i) t += red[q][i];
-      tot[q] = t;
-    }
-    out[0] = (tot[0] + tot[1]) + tot[2];
-  }
-}
-
-// Global-batch CG, after the residual's all-reduce: r'.r', r'.p, p.p over the whole flat vectors (p = the direction of the
-// iteration just finished) in the slot layout k_cg_beta reads — what the fused epilogues' partials are in the one-rank
-// solver, where every tile sees the final r' (here it only exists after the exchange).  8*N bytes; fixed order per block.
-__global__ __launch_bounds__(kThreads) void k_cg_global_dots(const bhg_chunk* __restrict__ chunks, int n_chunks,
-                                                             const float* __restrict__ r, const float* __restrict__ p,
-                                                             double* __restrict__ part, int stride, int nslots) {
-  __shared__ double red[kWaves];
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const bhg_chunk ck = chunks[c];
-    float4 a[kVecPerThread], q[kVecPerThread];
-#pragma unroll
-    for (int i = 0; i < kVecPerThread; ++i) {
-      const int e = 4 * (threadIdx.x + kThreads * i);
-      a[i] = ld4(r + ck.flat_off, e, ck.len);
-      q[i] = ld4(p + ck.flat_off, e, ck.len);
-    }
-#pragma unroll
-    for (int i = 0; i < kVecPerThread; ++i) {
-      a0 += (double)a[i].x * a[i].x + (double)a[i].y * a[i].y + (double)a[i].z * a[i].z + (double)a[i].w * a[i].w;
-      a1 += (double)a[i].x * q[i].x + (double)a[i].y * q[i].y + (double)a[i].z * q[i].z + (double)a[i].w * q[i].w;
-      a2 += (double)q[i].x * q[i].x + (double)q[i].y * q[i].y + (double)q[i].z * q[i].z + (double)q[i].w * q[i].w;
-    }
-  }
-  const double s0 = block_sum(a0, red);
-  const double s1 = block_sum(a1, red);
-  const double s2 = block_sum(a2, red);
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = s0;
-    part[stride + blockIdx.x] = s1;
-    part[2 * (int64_t)stride + blockIdx.x] = s2;
-    for (int i = gridDim.x + blockIdx.x; i < nslots; i += gridDim.x) {   // the slots no block of this launch owns
-      part[i] = 0.0; part[stride + i] = 0.0; part[2 * (int64_t)stride + i] = 0.0;
-    }
-  }
-}
-
-// R-backward reduce of the fused CG solver.  The split-K GEMM ran with pair_split = s0: slabs [0, s0) hold
-// G = delta_l V_l (chain-independent), slabs [s0, splits) hold Rd_l W_l.  Besides
-//   out[m][n] = mask[m][n] * (G + Rd_l W_l)[m][n]            (rows >= B written as zero)
-// every block emits its partial of T2_l = 2 <G, Rh_{l-1}>, the layer-bilinear part of p.Hp (see k_cg_alpha).
-// One float4 per thread and trip when VEC == 4; slabs are summed in fixed order s = 0, 1, ... => deterministic.
-template <int VEC>
-__global__ __launch_bounds__(256) void k_reduce_mask_t2(const float* __restrict__ part, int s0, int splits, int slab,
-                                                        const float* __restrict__ mask, const float* __restrict__ rh,
-                                                        float* __restrict__ out, int rows, int N, int B,
-                                                        double* __restrict__ partT2) {
-  __shared__ double red[kWaves];
-  const int64_t total = (int64_t)rows * N / VEC;
-  const int nv = N / VEC;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int m = (int)(i / nv);
-    float v[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
-    if (m < B) {
-      if constexpr (VEC == 4) {
-        constexpr int NB = 8;
-        const float* p0 = part + i * VEC;
-        const float4 mv = *reinterpret_cast<const float4*>(mask + i * VEC);
-        const float4 rv = *reinterpret_cast<const float4*>(rh + i * VEC);
-        for (int half = 0; half < 2; ++half) {
-          const int sb = half ? s0 : 0, se = half ? splits : s0;
-          for (int sA = sb; sA < se; sA += NB) {
-            float4 t[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) t[u] = *reinterpret_cast<const float4*>(p0 + (int64_t)(sA + u < se ? sA + u : se - 1) * slab);
-#pragma unroll
-            for (int u = 0; u < NB; ++u)
-              if (sA + u < se) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
-          }
-          if (!half) acc += (double)v[0] * rv.x + (double)v[1] * rv.y + (double)v[2] * rv.z + (double)v[3] * rv.w;
-        }
-        v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
-      } else {
-        for (int s = 0; s < s0; ++s) v[0] += part[(int64_t)s * slab + i];
-        acc += (double)v[0] * rh[i];
-        for (int s = s0; s < splits; ++s) v[0] += part[(int64_t)s * slab + i];
-        v[0] *= mask[i];
-      }
-    }
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + i * VEC) = make_float4(v[0], v[1], v[2], v[3]);
-    else out[i] = v[0];
-  }
-  const double sblk = block_sum(acc, red);
-  if (threadIdx.x == 0) partT2[blockIdx.x] = 2.0 * sblk;
-}
-
-// Top of the network: Rz = sum_s part + c ; Rd_L = sd * (p*Rz - p (p.Rz)).
-// 16 lanes per sample row (C <= 16 handled by one lane each; larger C strides), 16 rows per block.
-__global__ __launch_bounds__(256) void k_reduce_softmax_jvp(const float* __restrict__ part, int splits, int slab,
-                                                            const float* __restrict__ bias,
-                                                            const float* __restrict__ prob,
-                                                            const float* __restrict__ sd, float* __restrict__ rd,
-                                                            int rows, int C, int B) {
-  const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15;
-  const bool live = m < rows && m < B;
-  float dot = 0.f;
-  for (int c = sub; c < C; c += 16) {
-    float rz = 0.f;
-    if (live) {
-      for (int s = 0; s < splits; ++s) rz += part[(int64_t)s * slab + (int64_t)m * C + c];
-      if (bias) rz += bias[c];
-      dot += prob[(int64_t)m * C + c] * rz;
-    }
-  }
-  // sum `dot` over the 16 lanes of this row (xor butterfly stays inside the 16-lane group)
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-  if (m < rows) {
-    const float w = live ? sd[m] : 0.f;
-    for (int c = sub; c < C; c += 16) {
-      float v = 0.f;
-      if (live) {
-        float rz = 0.f;
-        for (int s = 0; s < splits; ++s) rz += part[(int64_t)s * slab + (int64_t)m * C + c];
-        if (bias) rz += bias[c];
-        const float p = prob[(int64_t)m * C + c];
-        v = w * (p * rz - p * dot);
-      }
-      rd[(int64_t)m * C + c] = v;
-    }
-  }
-}
-
-// H(b_l) = colsum_b Rd_l[b][:] + 2 rho c_l for ALL layers in one launch.
-// Block = 64 columns x 4 row groups; each thread sums rows rg, rg+4, ... in order, the 4 groups are
-// combined in fixed order through LDS => deterministic.
-struct BiasArgs {
-  const float* rd[BHG_MLP_MAX_LAYERS];
-  const float* c[BHG_MLP_MAX_LAYERS];
-  float* out[BHG_MLP_MAX_LAYERS];
-  int n[BHG_MLP_MAX_LAYERS];
-  int blk0[BHG_MLP_MAX_LAYERS + 1];  // first block of each layer
-  int L, B;
-  float rho2;
-  int64_t foff[BHG_MLP_MAX_LAYERS];  // fused modes: element offset of b_l inside the flat state vectors
-  const float* d0;                   // != NULL: the first bias's slice of the direction lives HERE, not at fz.d + foff[0] (k_proj_step)
-};
-template <int MODE, class BA = BiasArgs>
-__device__ __forceinline__ void bias_body(const BA& a, const FuseArgs& fz, const int bx, float* red_base) {
-  float (*red)[64] = reinterpret_cast<float (*)[64]>(red_base);   // 4 x 64 floats of LDS provided by the caller
-  __shared__ double red_rr[kWaves];
-  int l = 0;
-  while (l + 1 < a.L && bx >= a.blk0[l + 1]) ++l;
-  const int N = a.n[l];
-  const int col = (bx - a.blk0[l]) * 64 + (threadIdx.x & 63);
-  const int rg = threadIdx.x >> 6;
-  const float* __restrict__ rd = a.rd[l];
-  const int colc = col < N ? col : N - 1;   // clamped, not guarded: all loads of a batch are in flight together
-  float s0 = 0.f, s1 = 0.f;
-  for (int b0 = rg; b0 < a.B; b0 += 32) {   // 8 batch rows per trip: b0, b0+4, ..., b0+28
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int bb = b0 + 4 * u;
-      v[u] = rd[(int64_t)(bb < a.B ? bb : a.B - 1) * N + colc];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      if (b0 + 4 * u < a.B) s0 += v[u];
-      if (b0 + 4 * (u + 1) < a.B) s1 += v[u + 1];
-    }
-  }
-  red[rg][threadIdx.x & 63] = s0 + s1;
-  __syncthreads();
-  FuseAcc racc{0.0, 0.0, 0.0};
-  if (rg == 0 && col < N) {
-    const int t = threadIdx.x;
-    if (MODE == FUSE_NONE) {
-      a.out[l][col] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.rho2 * a.c[l][col];
-    } else {
-      const float hv = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-      const int64_t off = a.foff[l] + col;
-      const float* dsrc = (l == 0 && a.d0) ? a.d0 + col : fz.d + off;
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = *dsrc;
-      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), hv, nd, na, nb, racc);
-      fz.a[off] = na;
-      if (fz.b) fz.b[off] = nb;
-      if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
-    }
-  }
-  if (MODE == FUSE_CG) fuse_store_partials(fz, racc, bx, red_rr);
-}
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bias_hvp(BiasArgs a, FuseArgs fz) {
-  __shared__ float red[4 * 64];
-  bias_body<MODE>(a, fz, blockIdx.x, red);
-}
-
-// ---- narrow output layer (C = dims[L] <= 32 classes): dedicated latency-optimised kernels ----------------
-// A 128x64-tile MFMA kernel is the wrong tool for the classifier head (10 x 384 at the benchmark): three
-// small kernels replace two split-K GEMM+reduce pairs and one outer-product launch.
-constexpr int kSmallC = 32;
-enum : int { HEAD_JVP = 0, HEAD_COEFF = 1, HEAD_LOGITS = 2 };
-
-// Rz[b][c] = Rh[b].W[c] + h[b].V[c] + cb[c], then Rd_L[b] = sd[b] * (p*Rz - p (p.Rz)).
-// One workgroup per sample row; wave w handles classes w, w+4, ... (JMAX slots); lanes stride K (coalesced rows).
-// Every load address is clamped instead of guarded and HAS_RH / JMAX are compile-time, so a trip's
-// 2 + 2*JMAX 16-B loads are all in flight together (a runtime `if (c < C)` / `if (Rh)` around a load makes
-// hipcc wait vmcnt(0) after each one: 30 dependent L2 round trips on the critical path of every HVP).
-// FUSED: the split-K combine of the PREVIOUS layer's R-forward GEMM (sum of slabs + bias, times ReLU mask) is done
-// here, by the workgroup that owns the sample row, instead of by a k_reduce_mask launch in front of this kernel:
-// the row lands in LDS for the dot products and is written out once (the outer products need it).
-struct HeadFuse {
-  const float* part;   // [splits][rows][K] partial slabs of Ra_{L-2}
-  int splits, slab;
-  const float* bias;   // c_{L-2}[K]
-  const float* mask;   // m_{L-2}[rows][K]
-  float* rh_out;       // Rh_{L-2}[rows][K]
-  const float* addend; // [rows][K] or NULL: hoisted chain — the direction's share h_{L-2} V_{L-2}^T, already reduced
-};
-// PF (solver iterations: HEAD_JVP with the fused R-backward, K <= 512, C <= 12): the kernel is a chain of dependent
-// L2 round trips (slab batches -> dot-product operands -> softmax inputs -> three class batches of the R-backward);
-// every load that does not depend on the kernel's own results is requested up front instead: the dot-product operands
-// together with the first slab batch, the R-backward operands while the dot products run.  Same arithmetic, same order.
-template <bool HAS_RH, int JMAX, bool FUSED, bool PF = false>
-__global__ __launch_bounds__(256) void k_head_forward(const float* __restrict__ Rh, const float* __restrict__ h,
-                                                      const float* __restrict__ W, const float* __restrict__ V,
-                                                      const float* __restrict__ cb, const float* __restrict__ prob,
-                                                      const float* __restrict__ sd, float* __restrict__ rd, int K,
-                                                      int C, int B, int mode, const int64_t* __restrict__ labels,
-                                                      float* __restrict__ aux, const float* __restrict__ delta_top,
-                                                      const float* __restrict__ mask_prev,
-                                                      float* __restrict__ rd_prev, HeadFuse fz,
-                                                      double* __restrict__ partT1, double* __restrict__ partT2h,
-                                                      float* __restrict__ rz_out, double* __restrict__ rzx_acc,
-                                                      int rzx_first) {
-  extern __shared__ __attribute__((aligned(16))) float srow[];   // FUSED: the row of Rh_{L-2}, K floats
-  // partT1 / partT2h != NULL (HEAD_JVP, fused CG solver): this sample row's share of p.Hp (see k_cg_alpha):
-  //   partT1[b]  = sum_c Rz[b][c] * Rd_L[b][c]                          (the Gauss-Newton part)
-  //   partT2h[b] = 2 * sum_k (delta_L V_L)[b][k] * Rh_{L-2}[b][k]       (the head layer's second-order part)
-  __shared__ float t1s[kSmallC];
-  __shared__ double red_t[kWaves];
-  // HEAD_JVP with rd_prev != NULL also performs the R-backward step through the head for this sample row
-  // (it only needs the row's own Rd_L):  rd_prev[b][k] = mask_prev[b][k] * sum_c (delta_top[b][c] V[c][k] + Rd_L[b][c] W[c][k])
-  // mode HEAD_JVP:    rd[b][:] = sd[b] * (p*Rz - p (p.Rz))                     (one HVP's top of the network)
-  // mode HEAD_COEFF:  aux[b]   = (p - onehot(y)).Rz / B                         (mixed-derivative coefficient)
-  // mode HEAD_LOGITS: rd[b][:] = softmax(z), aux[b] = -log softmax(z)[y]        (forward pass; V = W, cb = bias)
-  __shared__ float rz[kSmallC], rdl[kSmallC], dtl[kSmallC], pz[kSmallC];
-  const int b = blockIdx.x;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  if (b >= B) {
-    if (mode != HEAD_COEFF && t < C) rd[(int64_t)b * C + t] = 0.f;
-    if (mode != HEAD_JVP && t == 0) aux[b] = 0.f;
-    if (mode == HEAD_JVP && rd_prev)
-      for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (FUSED)
-      for (int k = 4 * t; k < K; k += 1024) *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
-  const float* hb = h + (int64_t)b * K;
-  float acc[JMAX], cbv[JMAX];
-  const float* vrow[JMAX];
-  const float* wrow[JMAX];
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    const int cc = min(wave + 4 * j, C - 1);
-    acc[j] = 0.f;
-    vrow[j] = V + (int64_t)cc * K;
-    wrow[j] = W + (int64_t)cc * K;
-    cbv[j] = cb[cc];
-  }
-  // PF: operands of the dot products (k = 4 lane and 4 lane + 256; clamped, not guarded) and the softmax inputs
-  float4 pf_h[2], pf_v[2][JMAX], pf_w[2][JMAX];
-  float pf_p = 0.f, pf_sd = 0.f, pf_dt = 0.f;
-  if (PF) {
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-      const int k = 4 * lane + 256 * tr;
-      const int kc = k < K ? k : 0;
-      pf_h[tr] = ld16(hb + kc);
-#pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        pf_v[tr][j] = ld16(vrow[j] + kc);
-        pf_w[tr][j] = ld16(wrow[j] + kc);
-      }
-    }
-    const int tc = t < C ? t : C - 1;
-    pf_p = prob[(int64_t)b * C + tc];
-    pf_sd = sd[b];
-    pf_dt = delta_top[(int64_t)b * C + tc];
-  }
-  if (FUSED) {
-    for (int k = 4 * t; k < K; k += 1024) {
-      const float* p0 = fz.part + (int64_t)b * K + k;
-      const float4 bv = ld16(fz.bias + k);
-      const float4 mv = ld16(fz.mask + (int64_t)b * K + k);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      constexpr int NB = PF ? 16 : 8;                 // slabs in flight together; the summation order is s = 0, 1, ... either way
-      for (int s0 = 0; s0 < fz.splits; s0 += NB) {    // (as k_reduce_mask)
-        float4 tt[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) tt[u] = ld16(p0 + (int64_t)(s0 + u < fz.splits ? s0 + u : fz.splits - 1) * fz.slab);
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
-          if (s0 + u < fz.splits) { v.x += tt[u].x; v.y += tt[u].y; v.z += tt[u].z; v.w += tt[u].w; }
-      }
-      if (fz.addend) {
-        const float4 ad = ld16(fz.addend + (int64_t)b * K + k);
-        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
-      }
-      v.x = (v.x + bv.x) * mv.x; v.y = (v.y + bv.y) * mv.y; v.z = (v.z + bv.z) * mv.z; v.w = (v.w + bv.w) * mv.w;
-      *reinterpret_cast<float4*>(srow + k) = v;
-      *reinterpret_cast<float4*>(fz.rh_out + (int64_t)b * K + k) = v;
-    }
-    __syncthreads();
-  }
-  const float* rhb = HAS_RH ? (FUSED ? srow : Rh + (int64_t)b * K) : nullptr;
-  // PF: operands of the fused R-backward (k = 4 t, all C <= 12 classes), requested while the dot products run
-  float4 pf_mk, pf_W[12], pf_V[12];
-  if (PF) {
-    const int kd = 4 * t < K ? 4 * t : 0;
-    pf_mk = ld16(mask_prev + (int64_t)b * K + kd);
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const int cc = min(c, C - 1);
-      pf_W[c] = ld16(W + (int64_t)cc * K + kd);
-      pf_V[c] = ld16(V + (int64_t)cc * K + kd);
-    }
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-      const int k = 4 * lane + 256 * tr;
-      if (k < K) {
-        const float4 hv = pf_h[tr];
-        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (HAS_RH) rv = *reinterpret_cast<const float4*>(rhb + k);
-#pragma unroll
-        for (int j = 0; j < JMAX; ++j) {
-          float a = acc[j];
-          const float4 vv = pf_v[tr][j], ww = pf_w[tr][j];
-          a = fmaf(hv.x, vv.x, a); a = fmaf(hv.y, vv.y, a); a = fmaf(hv.z, vv.z, a); a = fmaf(hv.w, vv.w, a);
-          if (HAS_RH) {
-            a = fmaf(rv.x, ww.x, a); a = fmaf(rv.y, ww.y, a); a = fmaf(rv.z, ww.z, a); a = fmaf(rv.w, ww.w, a);
-          }
-          acc[j] = a;
-        }
-      }
-    }
-  }
-  for (int k = 4 * lane; k < (PF ? 0 : K); k += 256) {
-    const float4 hv = *reinterpret_cast<const float4*>(hb + k);
-    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (HAS_RH) rv = *reinterpret_cast<const float4*>(rhb + k);
-    float4 vv[JMAX], ww[JMAX];
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      vv[j] = *reinterpret_cast<const float4*>(vrow[j] + k);
-      if (HAS_RH) ww[j] = *reinterpret_cast<const float4*>(wrow[j] + k);
-    }
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      float a = acc[j];
-      a = fmaf(hv.x, vv[j].x, a); a = fmaf(hv.y, vv[j].y, a); a = fmaf(hv.z, vv[j].z, a); a = fmaf(hv.w, vv[j].w, a);
-      if (HAS_RH) {
-        a = fmaf(rv.x, ww[j].x, a); a = fmaf(rv.y, ww[j].y, a); a = fmaf(rv.z, ww[j].z, a); a = fmaf(rv.w, ww[j].w, a);
-      }
-      acc[j] = a;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    const int c = wave + 4 * j;
-    float a = acc[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    if (lane == 0 && c < C) rz[c] = a + cbv[j];
-  }
-  __syncthreads();
-  if (mode == HEAD_JVP) {
-    float p = 0.f, sdv = 0.f, dt = 0.f;
-    if (rz_out && t < C) rz_out[(int64_t)b * C + t] = rz[t];   // Rz_b(direction): accumulated into Rz(x) by k_cg_alpha
-    // fused Neumann solver without an accumulator vector: sum_k Rz_b(v_k), one owner per sample row (deterministic)
-    if (rzx_acc && t < C) rzx_acc[(int64_t)b * C + t] = (rzx_first ? 0.0 : rzx_acc[(int64_t)b * C + t]) + (double)rz[t];
-    if (t < C) {
-      if (PF) { p = pf_p; sdv = pf_sd; dt = pf_dt; }
-      else {
-        p = prob[(int64_t)b * C + t];
-        sdv = sd[b];
-        if (rd_prev) dt = delta_top[(int64_t)b * C + t];
-      }
-      pz[t] = p * rz[t];
-    }
-    __syncthreads();
-    if (t < C) {
-      float dot = 0.f;
-      for (int c = 0; c < C; ++c) dot += pz[c];
-      const float v = sdv * (p * rz[t] - p * dot);
-      rd[(int64_t)b * C + t] = v;
-      rdl[t] = v;
-      dtl[t] = dt;
-      t1s[t] = rz[t] * v;
-    }
-    if (rd_prev || partT1) __syncthreads();
-    if (partT1 && t == 0) {
-      double s1 = 0.0;
-      for (int c = 0; c < C; ++c) s1 += (double)t1s[c];
-      partT1[b] = s1;
-    }
-    double dacc = 0.0;
-    if (PF) {       // (rd_prev != NULL by construction)
-      const int k = 4 * t;
-      if (k < K) {
-        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 12; ++c) {
-          if (c < C) {
-            const float r = rdl[c], d = dtl[c];
-            const float4 v = pf_V[c], w = pf_W[c];
-            acc2.x += d * v.x + r * w.x; acc2.y += d * v.y + r * w.y;
-            acc2.z += d * v.z + r * w.z; acc2.w += d * v.w + r * w.w;
-            accd.x += d * v.x; accd.y += d * v.y; accd.z += d * v.z; accd.w += d * v.w;
-          }
-        }
-        acc2.x *= pf_mk.x; acc2.y *= pf_mk.y; acc2.z *= pf_mk.z; acc2.w *= pf_mk.w;
-        *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
-        if (HAS_RH && partT2h) {
-          const float4 rh4 = *reinterpret_cast<const float4*>(rhb + k);
-          dacc += (double)accd.x * rh4.x + (double)accd.y * rh4.y + (double)accd.z * rh4.z + (double)accd.w * rh4.w;
-        }
-      }
-    } else if (rd_prev) {  // fused R-backward through the head (K = feature width, K % 4 == 0)
-      for (int k = 4 * t; k < K; k += 1024) {
-        const float4 mk = *reinterpret_cast<const float4*>(mask_prev + (int64_t)b * K + k);
-        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f);   // (delta_L V_L)[b][k..k+3] alone, for partT2h
-        for (int c0 = 0; c0 < C; c0 += 4) {  // 8 independent 16-B loads per batch of 4 classes
-          float4 w[4], v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int cc = min(c0 + u, C - 1);
-            w[u] = *reinterpret_cast<const float4*>(W + (int64_t)cc * K + k);
-            v[u] = *reinterpret_cast<const float4*>(V + (int64_t)cc * K + k);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (c0 + u < C) {
-              const float r = rdl[c0 + u], d = dtl[c0 + u];
-              acc2.x += d * v[u].x + r * w[u].x; acc2.y += d * v[u].y + r * w[u].y;
-              acc2.z += d * v[u].z + r * w[u].z; acc2.w += d * v[u].w + r * w[u].w;
-              accd.x += d * v[u].x; accd.y += d * v[u].y; accd.z += d * v[u].z; accd.w += d * v[u].w;
-            }
-          }
-        }
-        acc2.x *= mk.x; acc2.y *= mk.y; acc2.z *= mk.z; acc2.w *= mk.w;
-        *reinterpret_cast<float4*>(rd_prev + (int64_t)b * K + k) = acc2;
-        if (HAS_RH && partT2h) {
-          const float4 rh4 = *reinterpret_cast<const float4*>(rhb + k);
-          dacc += (double)accd.x * rh4.x + (double)accd.y * rh4.y + (double)accd.z * rh4.z + (double)accd.w * rh4.w;
-        }
-      }
-    }
-    if (partT2h) {
-      const double s2 = block_sum(dacc, red_t);
-      if (t == 0) partT2h[b] = 2.0 * s2;
-    }
-  } else if (mode == HEAD_COEFF) {
-    if (t < C) pz[t] = (prob[(int64_t)b * C + t] - (t == (int)labels[b] ? 1.f : 0.f)) * rz[t];
-    __syncthreads();
-    if (t == 0) {
-      float acc2 = 0.f;
-      for (int c = 0; c < C; ++c) acc2 += pz[c];
-      aux[b] = acc2 / (float)B;
-    }
-  } else {  // HEAD_LOGITS: numerically stable log-softmax, one thread per row (C <= 32)
-    if (t == 0) {
-      float mx = rz[0];
-      for (int c = 1; c < C; ++c) mx = fmaxf(mx, rz[c]);
-      float sum = 0.f;
-      for (int c = 0; c < C; ++c) sum += expf(rz[c] - mx);
-      const float lse = mx + logf(sum);
-      for (int c = 0; c < C; ++c) rd[(int64_t)b * C + c] = expf(rz[c] - lse);
-      aux[b] = lse - rz[(int)labels[b]];
-    }
-  }
-}
-
-void launch_head_forward(hipStream_t st, int rows, const float* Rh, const float* h, const float* W, const float* V,
-                         const float* cb, const float* prob, const float* sd, float* rd, int K, int C, int B, int mode,
-                         const int64_t* labels, float* aux, const float* delta_top, const float* mask_prev,
-                         float* rd_prev, const HeadFuse* fuse = nullptr, double* partT1 = nullptr,
-                         double* partT2h = nullptr, float* rz_out = nullptr, double* rzx_acc = nullptr, int rzx_first = 0) {
-  // classes per wave: (C + 3) / 4 <= 3 for C <= 12 (the usual 10-way head), else up to 8
-  HeadFuse fz{};
-  if (fuse) fz = *fuse;
-  const size_t lds = fuse ? (size_t)K * sizeof(float) : 0;
-#define BHG_HEAD(RH, J, F)                                                                                              \
-  hipLaunchKernelGGL((k_head_forward<RH, J, F>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C, B, \
-                     mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out, rzx_acc, rzx_first)
-  static const bool no_pf = getenv("BHG_HEAD_NO_PREFETCH") != nullptr;   // A/B switch
-  const bool pf = !no_pf && fuse && C <= 12 && K <= 512 && mode == HEAD_JVP && rd_prev && delta_top && mask_prev;
-  if (pf) {
-    hipLaunchKernelGGL((k_head_forward<true, 3, true, true>), dim3(rows), dim3(256), lds, st, Rh, h, W, V, cb, prob, sd, rd, K, C,
-                       B, mode, labels, aux, delta_top, mask_prev, rd_prev, fz, partT1, partT2h, rz_out, rzx_acc, rzx_first);
-  } else if (fuse) { if (C <= 12) BHG_HEAD(true, 3, true); else BHG_HEAD(true, 8, true); }
-  else if (Rh) { if (C <= 12) BHG_HEAD(true, 3, false); else BHG_HEAD(true, 8, false); }
-  else    { if (C <= 12) BHG_HEAD(false, 3, false); else BHG_HEAD(false, 8, false); }
-#undef BHG_HEAD
-}
-
-// Rd_prev[b][n] = mask[b][n] * sum_c (delta[b][c] V[c][n] + Rd[b][c] W[c][n]);  thread per (b, 4 n).
-__global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__ delta, const float* __restrict__ rd,
-                                                       const float* __restrict__ W, const float* __restrict__ V,
-                                                       const float* __restrict__ mask, float* __restrict__ out,
-                                                       int N, int C, int B, int rows) {
-  const int nv = N / 4;
-  const int64_t total = (int64_t)rows * nv;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int b = (int)(i / nv), n = (int)(i - (int64_t)b * nv) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < B) {
-      for (int c = 0; c < C; ++c) {
-        const float r = rd[(int64_t)b * C + c];
-        const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)c * N + n);
-        acc.x += r * w.x; acc.y += r * w.y; acc.z += r * w.z; acc.w += r * w.w;
-        if (V) {  // second operand pair (absent in the plain backward pass of bhg_mlp_backward)
-          const float d = delta[(int64_t)b * C + c];
-          const float4 v = *reinterpret_cast<const float4*>(V + (int64_t)c * N + n);
-          acc.x += d * v.x; acc.y += d * v.y; acc.z += d * v.z; acc.w += d * v.w;
-        }
-      }
-      const float4 m = *reinterpret_cast<const float4*>(mask + (int64_t)b * N + n);
-      acc.x *= m.x; acc.y *= m.y; acc.z *= m.z; acc.w *= m.w;
-    }
-    *reinterpret_cast<float4*>(out + (int64_t)b * N + n) = acc;
-  }
-}
-
-// G[c][n] = sum_b (Rd[b][c] h[b][n] + delta[b][c] Rh[b][n]) + rho2 V[c][n];  block = 64 n x 4 batch groups,
-// fixed-order combine through LDS (deterministic).
-struct HeadOuterArgs {
-  const float* rd; const float* h; const float* delta; const float* Rh; const float* V;
-  float rho2; float* out; int N, C, B;
-};
-template <bool HAS_RH, int MODE>
-__device__ __forceinline__ void head_outer_body(const HeadOuterArgs& ha, const FuseArgs& fz, const int bx, const int by,
-                                                const int gx, float* red_base) {
-  // fused modes: fz.a / fz.b / fz.d already point at the head weight's slice of the flat state vectors
-  float (*red)[64] = reinterpret_cast<float (*)[64]>(red_base);   // 4 x 64 floats of LDS provided by the caller
-  __shared__ double red_rr[kWaves];
-  const float* __restrict__ rd = ha.rd; const float* __restrict__ h = ha.h; const float* __restrict__ delta = ha.delta;
-  const float* __restrict__ Rh = ha.Rh; const float* __restrict__ V = ha.V; float* __restrict__ out = ha.out;
-  const float rho2 = ha.rho2;
-  const int N = ha.N, C = ha.C, B = ha.B;
-  const int c = by;
-  const int n = bx * 64 + (threadIdx.x & 63);
-  const int nc = n < N ? n : N - 1;   // clamped, not guarded (see k_head_forward)
-  const int g = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int b = g; b < B; b += 32) {  // 8 batch rows per trip: 16 / 32 independent loads before the fma chain
-    float r[8], hh[8], d[8], rr[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int bb = b + 4 * u < B ? b + 4 * u : B - 1;
-      r[u] = rd[(int64_t)bb * C + c];
-      hh[u] = h[(int64_t)bb * N + nc];
-      if (HAS_RH) {
-        d[u] = delta[(int64_t)bb * C + c];
-        rr[u] = Rh[(int64_t)bb * N + nc];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (b + 4 * u < B) {
-        acc = fmaf(r[u], hh[u], acc);
-        if (HAS_RH) acc = fmaf(d[u], rr[u], acc);
-      }
-    }
-  }
-  red[g][threadIdx.x & 63] = acc;
-  __syncthreads();
-  FuseAcc racc{0.0, 0.0, 0.0};
-  if (g == 0 && n < N) {
-    const int t = threadIdx.x;
-    float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    const int64_t off = (int64_t)c * N + n;
-    if (MODE == FUSE_NONE) {
-      if (rho2 != 0.f) v += rho2 * V[off];
-      out[off] = v;
-    } else {
-      float na = MODE == FUSE_CG ? fz.a[off] : 0.f, nb = fz.b ? fz.b[off] : 0.f, nd = fz.d[off];
-      fuse_elem<MODE>(fz, fuse_alpha<MODE>(fz), fuse_beta<MODE>(fz), v, nd, na, nb, racc);
-      fz.a[off] = na;
-      if (fz.b) fz.b[off] = nb;
-      if (MODE == FUSE_CG && fz.lazy) fz.d[off] = nd;
-    }
-  }
-  if (MODE == FUSE_CG) fuse_store_partials(fz, racc, by * gx + bx, red_rr);
-}
-template <bool HAS_RH, int MODE>
-__global__ __launch_bounds__(256) void k_head_outer(HeadOuterArgs ha, FuseArgs fz) {
-  __shared__ float red[4 * 64];
-  head_outer_body<HAS_RH, MODE>(ha, fz, blockIdx.x, blockIdx.y, gridDim.x, red);
-}
-
-// ---- all weight-shaped outputs of one HVP in ONE launch (fused CG: they all need the step length, which is known
-// only at the end of the R-chain; one grid fills the chip without any stream/event choreography) -----------------------
-// Blocks [blk0[i], blk0[i+1]) are the 128 x 64 tiles of MFMA layer i (largest layers first), then the narrow head's
-// blocks, then the bias blocks.  All MFMA layers must be all-interior (FAST); the launcher falls back to one launch
-// per layer otherwise.
-constexpr int kOuterAllMax = 8;
-struct OuterAllArgs {
-  GemmArgs g[kOuterAllMax];
-  FuseArgs f[kOuterAllMax];
-  int gx[kOuterAllMax];
-  int blk0[kOuterAllMax + 1];
-  int n;
-  HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
-  FuseArgs bf;
-  int stagger;   // wave priority by dispatch round (see stagger_prio)
-};
-static_assert(sizeof(OuterAllArgs) + sizeof(BiasArgs) <= 4000, "kernel arguments of k_outer_all must fit the 4 KiB kernarg segment");
-// (Measured, not kept: every workgroup of this kernel deriving the step length itself from the batch-sized partials
-//  instead of reading the scalar k_cg_alpha leaves: the kernel grows by 10 us for the 5.7 us launch it saves.  Nor an
-//  "alpha block": block 0 of this launch doing k_cg_alpha's work while all other workgroups run their MFMA phase, the
-//  epilogues picking the result up from 64 replicated 8-byte {tag : alpha} granules with relaxed agent-scope loads — no
-//  fence, no hot word, correct, and 301.7 vs 300.5 steps/s: the step length's dependent loads take ~4 us under the
-//  launch's own operand burst, the first tiles' epilogues wait for them, and the launch grows by what it saved.
-//  Nor a tile QUEUE: 768 / 1024 resident workgroups popping tile numbers from one agent-scope counter (self-rewinding:
-//  the workgroup that draws number total + grid - 1 knows nobody pops again), largest-layer-first or two-pair-tiles-
-//  first: 264 / 260 / 256 vs 301 steps/s (CG), 575-582 vs 626 (Neumann) — the loop around the tile bodies alone costs
-//  8 % (the compiler no longer keeps the per-tile descriptors in SGPRs), and a popped second tile starts cold where a
-//  freshly dispatched workgroup's first loads are already in flight when its predecessor drains.)
-// Where its time goes (CG 56 us / Neumann 41 us at the benchmark, state traffic 200 MB / 120 MB): the two fit
-// T = 18 us + bytes / 5.3 TB/s, i.e. the MFMA phase (17.5 us is the fp32 matrix-pipe floor of the 4 GFLOP) and the
-// streaming of the state slices ADD UP — the four workgroups of a CU start together, so they all sit in the MFMA phase
-// together and then all in the epilogue.  PRE (first half tile's state requested under the last stage's MFMAs, no
-// redundant re-load of the last stage) buys 2 us.  A five-workgroups-per-CU instance (34-row stages, C staged 64 rows
-// at a time, quarter-tile pipelining: 1224 tiles = one resident wave) was built and measured SLOWER (63 us; 79 us with
-// the register spills of the pipelined form), so four it stays.  So was a whole-tile prefetch (r and the previous
-// direction of all 128 rows requested behind the last operand load, x behind the last LDS store; 168 VGPRs, three
-// workgroups per CU): CG 277 vs 294 steps/s, Neumann 616 vs 619 — the reads were never what the matrix phase delayed;
-// the tile's WRITES cannot start before its MFMAs end, and with 1.3 rounds of workgroups there is no steady state in
-// which one workgroup's stores run under another's matrix phase.
-template <int MODE, bool PRE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_all(OuterAllArgs oa, BiasArgs ba) {
-  // the small blocks borrow their 1 KiB of reduction scratch from the dynamic LDS of the MFMA tiles, and the register
-  // budget is held to 128 (amdgpu_waves_per_eu(4,4): 124 VGPRs, accumulators in VGPR form, no scratch): FOUR workgroups
-  // fit a CU (4 x 38.4 KiB at batch <= 100) instead of three — the kernel is bound by the recurrence traffic it carries,
-  // more tiles in flight = more memory parallelism: 281.5 vs 275.8 steps/s (CG), 605 vs 584 (Neumann), same-box A/B x 2
-  extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
-  const int b = blockIdx.x;
-  const int nw = oa.blk0[oa.n];
-  stagger_prio(oa.stagger, b, 4);
-  if (b < nw) {
-    int i = 0;
-    while (i + 1 < oa.n && b >= oa.blk0[i + 1]) ++i;
-    const int t = b - oa.blk0[i];
-    outer_body<true, MODE, PRE>(oa.g[i], oa.f[i], t % oa.gx[i], t / oa.gx[i], oa.gx[i]);
-  } else if (b < nw + oa.head_blocks) {
-    const int t = b - nw;
-    if (oa.head_has_rh) head_outer_body<true, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx, dyn_smem);
-    else head_outer_body<false, MODE>(oa.head, oa.hf, t % oa.head_gx, t / oa.head_gx, oa.head_gx, dyn_smem);
-  } else {
-    bias_body<MODE>(ba, oa.bf, b - nw - oa.head_blocks, dyn_smem);
-  }
-}
-
-// delta_L[b][c] = sd[b] * (prob[b][c] - onehot(y_b)[c]); rows >= B zero.
-__global__ __launch_bounds__(256) void k_delta_top(const float* __restrict__ prob, const float* __restrict__ sd,
-                                                   const int64_t* __restrict__ labels, float* __restrict__ delta,
-                                                   int rows, int C, int B) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * C) return;
-  const int b = i / C, c = i - b * C;
-  delta[i] = b < B ? sd[b] * (prob[i] - ((int)labels[b] == c ? 1.f : 0.f)) : 0.f;
-}
-
-// ---- skinny GEMM with the split along K INSIDE the workgroup ("wsk") ------------------------------------------------
-// The split-K launches above leave [splits][Bp][N] partial slabs that a reduce launch sums, biases and masks (12.6 MB
-// written and re-read, one more launch on the dependent chain per layer).  Here ONE workgroup owns a final 32 x 32
-// output tile: its 8 waves take disjoint K ranges (with two operand pairs: waves 0-3 the first pair, 4-7 the second),
-// the eight partial tiles meet in LDS and are summed in fixed order (deterministic), and the same epilogue
-//   out[m][n] = mask[m][n] * (sum + bias[n])        (rows >= B written as zero)
-// [+ the block's partial of T2 = 2 <first pair's product, Rh> for the fused CG step length] runs before anything
-// leaves the chip.  No slabs, no reduce launch.  Operands go from global memory straight into the MFMA register layout
-// (v_mfma_f32_16x16x4_f32: lane l holds A[l & 15][l >> 4]); any k <-> lane assignment is valid as long as the A and the
-// B fragment of a lane agree, so a lane's 16-B load along K feeds four MFMAs:
-//   K-contiguous operand: lane (li, lk) loads [row li][k0 + 16 h + 4 lk .. + 3]       -> 64 B contiguous per row
-//   N-contiguous operand: lane (li, lk) loads [k0 + 16 h + 4 lk + c][n0 + 2 li .. + 1] -> 128 B contiguous per k;
-//                         component t of the 8-B load belongs to column n0 + 2 li + t (interleaved column blocks).
-// A D-deep ring of register stages keeps D chunks of 32 k in flight per wave; there is no barrier in the K loop.
-// The price is operand reuse: a 32 x 32 tile moves 8 KiB (12 KiB with the lazy direction) per 32 MFMAs through the
-// vector cache against 5-6 KiB for a 128 x 32 tile — the reason this form is an A/B arm (BHG_MLP_WSK), not a given.
-struct WskArgs {
-  GemmPair pr[2];
-  int pairs;
-  int M, N, K;          // K per pair; M, N multiples of 32, K a multiple of 32 * (8 / pairs)
-  int B;                // valid rows
-  const float* bias;    // [N] or NULL
-  const float* mask;    // [M][N] or NULL
-  const float* rh;      // [M][N]: T2 partner (needs pairs == 2 and partT2) or NULL
-  float* out;           // [M][N]
-  double* partT2;       // one partial per workgroup or NULL
-  const double* scal;   // BF instances: beta
-  int ntm, ntn;         // output tiles
-  const float* addend;  // [M][N] or NULL: a fully reduced product added before bias / mask (hoisted chain: the direction's
-                        // share G_l, see k_hoist); with partT2 it — not the first operand pair — is T2's left factor
-};
-constexpr int kWskWaves = 8;
-constexpr int kWskPad = 33;
-
-template <int LB, bool MIX, int D>
-__device__ __forceinline__ void wsk_loop(const GemmPair& pr, const int m0, const int n0, const int kbeg, const int nch,
-                                         const float bs, f32x4 (&acc)[2][2]) {
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const float* gA = pr.A + (int64_t)(m0 + li) * pr.lda + kbeg + 4 * lk;
-  const float* gB;
-  const float* gQ;
-  if (LB == LAYOUT_KC) {
-    gB = pr.B + (int64_t)(n0 + li) * pr.ldb + kbeg + 4 * lk;
-    gQ = pr.B2 + (int64_t)(n0 + li) * pr.ldb + kbeg + 4 * lk;
-  } else {
-    gB = pr.B + (int64_t)(kbeg + 4 * lk) * pr.ldb + n0 + 2 * li;
-    gQ = pr.B2 + (int64_t)(kbeg + 4 * lk) * pr.ldb + n0 + 2 * li;
-  }
-  const int64_t a16 = (int64_t)16 * pr.lda, b16 = (int64_t)16 * pr.ldb;
-  f32x4 sa[D][2][2];        // [stage][row block][k half]
-  f32x4 sb[D][2][2];        // K-contiguous B: [stage][col block][k half]
-  f32x4 sq[D][2][2];
-  f32x2 tb[D][2][4];        // N-contiguous B: [stage][k half][k component] (x, y = the two interleaved column blocks)
-  f32x2 tq[D][2][4];
-  auto load = [&](const int d, int ch) {
-    ch = min(ch, nch - 1);   // past the end: re-load the last chunk (never used), keeps the loop free of control flow
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) sa[d][rb][h] = *reinterpret_cast<const f32x4*>(gA + rb * a16 + ch * 32 + 16 * h);
-      if (LB == LAYOUT_KC) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          sb[d][cb][h] = *reinterpret_cast<const f32x4*>(gB + cb * b16 + ch * 32 + 16 * h);
-          if (MIX) sq[d][cb][h] = *reinterpret_cast<const f32x4*>(gQ + cb * b16 + ch * 32 + 16 * h);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int64_t o = (int64_t)(ch * 32 + 16 * h + c) * pr.ldb;
-          tb[d][h][c] = *reinterpret_cast<const f32x2*>(gB + o);
-          if (MIX) tq[d][h][c] = *reinterpret_cast<const f32x2*>(gQ + o);
-        }
-      }
-    }
-  };
-  auto compute = [&](const int d) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float b0, b1;
-        if (LB == LAYOUT_KC) {
-          b0 = sb[d][0][h][c]; b1 = sb[d][1][h][c];
-          if (MIX) {   // p = r' + (beta * p_old): the two roundings of k_cg_pdir
-            b0 = __fadd_rn(b0, __fmul_rn(bs, sq[d][0][h][c]));
-            b1 = __fadd_rn(b1, __fmul_rn(bs, sq[d][1][h][c]));
-          }
-        } else {
-          b0 = tb[d][h][c].x; b1 = tb[d][h][c].y;
-          if (MIX) {
-            b0 = __fadd_rn(b0, __fmul_rn(bs, tq[d][h][c].x));
-            b1 = __fadd_rn(b1, __fmul_rn(bs, tq[d][h][c].y));
-          }
-        }
-        const float a0 = sa[d][0][h][c], a1 = sa[d][1][h][c];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
-    }
-  };
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    load(d, d);
-    __builtin_amdgcn_sched_barrier(0);   // stage order = issue order (the waits count loads issued AFTER the needed ones)
-  }
-  int s = 0;
-  // steady state: every load is a chunk that will be used
-  for (; s + 2 * D <= nch; s += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      // fences: without them hipcc gathers the MFMAs of all D stages behind ONE s_waitcnt vmcnt(0) and issues the
-      // loads of all D stages at the end of the body — the ring would then hide nothing inside a wave
-      compute(d);
-      __builtin_amdgcn_sched_barrier(0);
-      load(d, s + D + d);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // last refills (fewer than D chunks left to fetch), then the drain
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    if (s + d < nch) compute(d);
-    if (s + D + d < nch) load(d, s + D + d);
-  }
-  s += D;
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (s + d < nch) compute(d);
-}
-
-// The same K loop with COALESCED global loads (8 lanes per 128-B row segment: 8 full cache lines per instruction instead of
-// 16 half lines) staged through a wave-private LDS tile (written and read back by the same wave, in order: no barrier)
-// into the MFMA layout — the transposition the direct form asks of the vector cache's address path is done by LDS.
-// Long reductions: 27.8 / 31.1 / 24.8 us against the direct form's 37.3 / 40.4 / 30.2 us (cfg-2 shapes); only the
-// R-backward into layer 0 beats split-K + reduce (26.9 us).  Two register stages.
-constexpr int kWslPad = 36;                              // LDS row stride (floats): 16-B aligned rows, conflict-free 16-lane groups
-constexpr int kWslWaveFloats = 2 * 32 * kWslPad;         // A tile + B tile of one wave
-template <int LB, bool MIX, int D>
-__device__ __forceinline__ void wsl_loop(const GemmPair& pr, const int m0, const int n0, const int kbeg, const int nch,
-                                         const float bs, f32x4 (&acc)[2][2], float* __restrict__ lds) {
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const int lr = lane >> 3, lq = lane & 7;               // loader: row (of 8 per instruction), 16-B piece of the row
-  float* sA = lds;
-  float* sB = lds + 32 * kWslPad;
-  const float* gA = pr.A + (int64_t)(m0 + lr) * pr.lda + kbeg + 4 * lq;
-  const float* gB;
-  const float* gQ;
-  if (LB == LAYOUT_KC) {
-    gB = pr.B + (int64_t)(n0 + lr) * pr.ldb + kbeg + 4 * lq;
-    gQ = pr.B2 + (int64_t)(n0 + lr) * pr.ldb + kbeg + 4 * lq;
-  } else {
-    gB = pr.B + (int64_t)(kbeg + lr) * pr.ldb + n0 + 4 * lq;
-    gQ = pr.B2 + (int64_t)(kbeg + lr) * pr.ldb + n0 + 4 * lq;
-  }
-  const int64_t a8 = (int64_t)8 * pr.lda, b8 = (int64_t)8 * pr.ldb;
-  f32x4 ra[D][4], rb[D][4], rq[D][4];
-  auto load = [&](const int d, int ch) {
-    ch = min(ch, nch - 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[d][i] = *reinterpret_cast<const f32x4*>(gA + i * a8 + ch * 32);
-      const int64_t ob = LB == LAYOUT_KC ? i * b8 + ch * 32 : (int64_t)(ch * 32 + 8 * i) * pr.ldb;
-      rb[d][i] = *reinterpret_cast<const f32x4*>(gB + ob);
-      if (MIX) rq[d][i] = *reinterpret_cast<const f32x4*>(gQ + ob);
-    }
-  };
-  auto compute = [&](const int d) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 b = rb[d][i];
-      if (MIX) {   // p = r' + (beta * p_old): the two roundings of k_cg_pdir
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[c] = __fadd_rn(b[c], __fmul_rn(bs, rq[d][i][c]));
-      }
-      *reinterpret_cast<f32x4*>(sA + (8 * i + lr) * kWslPad + 4 * lq) = ra[d][i];
-      *reinterpret_cast<f32x4*>(sB + (8 * i + lr) * kWslPad + 4 * lq) = b;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sA + li * kWslPad + 16 * h + 4 * lk);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(sA + (16 + li) * kWslPad + 16 * h + 4 * lk);
-      float b0[4], b1[4];
-      if (LB == LAYOUT_KC) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sB + li * kWslPad + 16 * h + 4 * lk);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sB + (16 + li) * kWslPad + 16 * h + 4 * lk);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { b0[c] = v0[c]; b1[c] = v1[c]; }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          b0[c] = sB[(16 * h + 4 * lk + c) * kWslPad + li];
-          b1[c] = sB[(16 * h + 4 * lk + c) * kWslPad + 16 + li];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
-      }
-    }
-  };
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    load(d, d);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  int s = 0;
-  for (; s + 2 * D <= nch; s += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      compute(d);
-      __builtin_amdgcn_sched_barrier(0);
-      load(d, s + D + d);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    if (s + d < nch) compute(d);
-    if (s + D + d < nch) load(d, s + D + d);
-  }
-  s += D;
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (s + d < nch) compute(d);
-}
-
-template <int LB, bool BF, int D, bool LDSV = false>
-__device__ __forceinline__ void wsk_body(const WskArgs& a, const int blk) {
-  // LDSV: dynamic LDS = 8 wave-private staging tiles (73.7 KB); the partial-tile exchange aliases them after the loop
-  extern __shared__ __attribute__((aligned(16))) float wsl_smem[];
-  __shared__ float sP_static[LDSV ? 1 : kWskWaves * 32 * kWskPad];
-  float (*sP)[32][kWskPad] = reinterpret_cast<float (*)[32][kWskPad]>(LDSV ? wsl_smem : sP_static);
-  __shared__ double red[kWskWaves];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  // tile of this workgroup.  Workgroup ids go round-robin over the 8 XCDs: all row tiles of a column tile sit on ONE
-  // XCD (the streamed weight-side operand is fetched into one L2), consecutive column tiles on different XCDs.
-  int tm, tn;
-  {
-    const int b = blk;
-    if ((a.ntn & 7) == 0) {
-      const int xcd = b & 7, j = b >> 3;
-      tm = j % a.ntm;
-      tn = (j / a.ntm) * 8 + xcd;
-    } else {
-      tm = b % a.ntm;
-      tn = b / a.ntm;
-    }
-  }
-  const int m0 = tm * 32, n0 = tn * 32;
-  const int nwp = kWskWaves / a.pairs;   // waves per operand pair
-  const int pi = wave / nwp;             // wave-uniform
-  const int wq = wave - pi * nwp;
-  // this wave's share of the pair's K range, in 32-k chunks: [c0, c1) — even when nwp divides the chunk count, else the
-  // first waves take one chunk more; a wave without a chunk contributes a zero tile
-  const int nct = a.K / 32;
-  const int c0 = (int)(((int64_t)wq * nct) / nwp), c1 = (int)(((int64_t)(wq + 1) * nct) / nwp);
-  const int kbeg_w = c0 * 32, nch_w = c1 - c0;
-  const GemmPair pr = pi ? a.pr[1] : a.pr[0];   // (a select, not an index: a locally built descriptor must not go to scratch)
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-  // epilogue operands of this thread's two outputs: requested before the K loop, they land under it
-  // (the three-stage staged form has no registers to spare: it fetches them behind the loop)
-  constexpr bool kLateE = LDSV && D >= 3;
-  float e_mask[2], e_rh[2], e_bias[2], e_add[2];
-  auto load_e = [&]() {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = threadIdx.x + 64 * kWskWaves * u;
-      const int64_t idx = (int64_t)(m0 + (e >> 5)) * a.N + n0 + (e & 31);
-      e_mask[u] = a.mask ? a.mask[idx] : 1.f;
-      e_rh[u] = a.partT2 ? a.rh[idx] : 0.f;
-      e_bias[u] = a.bias ? a.bias[n0 + (e & 31)] : 0.f;
-      e_add[u] = a.addend ? a.addend[idx] : 0.f;
-    }
-  };
-  if (!kLateE) load_e();
-  if (nch_w > 0) {   // (wave-uniform)
-    if (LDSV) {
-      float* my = wsl_smem + wave * kWslWaveFloats;
-      if (BF && pr.mix) wsl_loop<LB, true, D>(pr, m0, n0, kbeg_w, nch_w, (float)a.scal[S_BETA], acc, my);
-      else wsl_loop<LB, false, D>(pr, m0, n0, kbeg_w, nch_w, 0.f, acc, my);
-    } else if (BF && pr.mix) wsk_loop<LB, true, D>(pr, m0, n0, kbeg_w, nch_w, (float)a.scal[S_BETA], acc);
-    else wsk_loop<LB, false, D>(pr, m0, n0, kbeg_w, nch_w, 0.f, acc);
-  }
-  if (kLateE) load_e();
-  if (LDSV) __syncthreads();   // every wave is done with its staging tile before the partial tiles overwrite them
-
-  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = (LB == LAYOUT_KC || LDSV) ? 16 * cb + li : 2 * li + cb;
-        sP[wave][16 * rb + 4 * lk + r][col] = acc[rb][cb][r];
-      }
-  __syncthreads();
-  double t2 = 0.0;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = threadIdx.x + 64 * kWskWaves * u;
-    const int row = e >> 5, col = e & 31;
-    const int m = m0 + row, n = n0 + col;
-    const int64_t idx = (int64_t)m * a.N + n;
-    float v = 0.f;
-    if (a.addend) {   // hoisted chain: the direction's share arrives reduced; every wave of this launch carries the chain product
-      v = e_add[u];
-      if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
-      for (int w = 0; w < kWskWaves; ++w) v += sP[w][row][col];
-    } else {
-      for (int w = 0; w < nwp; ++w) v += sP[w][row][col];
-      if (a.partT2 && m < a.B) t2 += (double)v * (double)e_rh[u];
-      for (int w = nwp; w < kWskWaves; ++w) v += sP[w][row][col];
-    }
-    if (a.bias) v += e_bias[u];
-    if (a.mask) v *= e_mask[u];
-    a.out[idx] = m < a.B ? v : 0.f;
-  }
-  if (a.partT2) {
-    t2 = wave_sum(t2);
-    if (lane == 0) red[wave] = t2;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWskWaves; ++i) s += red[i];
-      a.partT2[blk] = 2.0 * s;
-    }
-  }
-}
-template <int LB, bool BF, int D, bool LDSV = false>
-__global__ __launch_bounds__(64 * kWskWaves) void k_gemm_wsk(WskArgs a) { wsk_body<LB, BF, D, LDSV>(a, blockIdx.x); }
-
-// Several small K-contiguous x K-contiguous products in ONE launch of the LDS-staged form (projected CG: the B x B Gram
-// products T_l = h_l Rh_{l-1}^T, E_l = delta_l Rd_l^T of an iteration, or S_l = h_l h_l^T, D_l = delta_l delta_l^T once per
-// solve): blocks [blk0[i], blk0[i+1]) are the 32 x 32 tiles of problem i.
-constexpr int kWskGroupMax = 26;   // first iteration of the deepest hoistable net (8 layers): 12 (T, E) + 13 (S, D) problems
-// K split over `nsplit` WORKGROUPS per tile (per-iteration Gram products: a few tiles with a long K would otherwise leave most of
-// the chip idle while each runs its whole K loop): split s takes K chunks [s, s+1) * nct / nsplit and leaves its tile in slab s
-// of `out` ([nsplit][M][N]); the CONSUMER sums the slabs in the order 0, 1, ... as it loads them (gemm_body<..., AS>: the A-side
-// loader of the G(raw) products).  (Measured, not kept: summing inside this launch by the last-arriving workgroup of a tile —
-// agent-scope fence + ticket: the fences write back and invalidate the L2s, 109.6 vs 88.4 us per iteration.)
-struct WskGroupProb { const float* A; const float* Bm; float* out; int M, N, K, B; int nsplit; };
-struct WskGroupArgs {
-  WskGroupProb p[kWskGroupMax];
-  int blk0[kWskGroupMax + 1];
-  int n;
-  int do_alpha; AlphaArgs alpha;   // block blk0[n]: k_cg_alpha's work (the step length needs the same inputs as this iteration's
-                                   // Gram products — the end of the R-chain — and nothing of them)
-};
-template <int D>
-__global__ __launch_bounds__(64 * kWskWaves) void k_wsk_group(WskGroupArgs g) {
-  const int b = blockIdx.x;
-  if (b >= g.blk0[g.n]) {
-    if (g.do_alpha) (void)alpha_compute(g.alpha, true);
-    return;
-  }
-  int i = 0;
-  while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
-  const WskGroupProb q = g.p[i];
-  const int tiles = (q.M / 32) * (q.N / 32);
-  const int t = b - g.blk0[i];
-  const int tile = q.nsplit > 1 ? t % tiles : t, sp = q.nsplit > 1 ? t / tiles : 0;
-  const int nct = q.K / 32;
-  const int cb = q.nsplit > 1 ? (int)(((int64_t)sp * nct) / q.nsplit) : 0, ce = q.nsplit > 1 ? (int)(((int64_t)(sp + 1) * nct) / q.nsplit) : nct;
-  WskArgs a{};
-  a.pr[0].A = q.A + 32 * cb; a.pr[0].B = q.Bm + 32 * cb; a.pr[0].lda = q.K; a.pr[0].ldb = q.K;
-  a.pairs = 1; a.M = q.M; a.N = q.N; a.K = 32 * (ce - cb); a.B = q.B;
-  a.out = q.out + (size_t)sp * q.M * q.N; a.ntm = a.M / 32; a.ntn = a.N / 32;
-  wsk_body<LAYOUT_KC, false, D, true>(a, tile);
-}
+#include "mlp/wsk.inc"   // skinny GEMMs with the K split inside the workgroup (register and LDS-staged forms), k_wsk_group
 
 // BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
 // for short reductions (pairs * K <= BHG_MLP_WSK_MAXK, default 1024), where the launch and the slab round trip weigh more
@@ -2197,527 +209,9 @@ int pick_splits(int tiles, int K, int pairs) {
   return s;
 }
 
-// coeff[b] = scale * (prob_b - onehot(y_b)) . RzX_b / B   (mixed-derivative coefficient from the accumulated Rz(x))
-//   add_scale != 0: coeff[b] = that + add_scale * coeff[b]  (the accumulator-free Neumann solve: the last direction's share
-//   is already in coeff);  rzx == NULL counts as zero.
-__global__ __launch_bounds__(kThreads) void k_coeff_from_rzx(const double* __restrict__ rzx, const float* __restrict__ prob,
-                                                             const int64_t* __restrict__ labels, float* __restrict__ coeff,
-                                                             int rows, int C, int B, float scale, float add_scale) {
-  const int b = blockIdx.x * kThreads + threadIdx.x;
-  if (b >= rows) return;
-  float out = 0.f;
-  if (b < B) {
-    const int y = (int)labels[b];
-    double acc = 0.0;
-    if (rzx)
-      for (int c = 0; c < C; ++c) acc += ((double)prob[(int64_t)b * C + c] - (c == y ? 1.0 : 0.0)) * rzx[(int64_t)b * C + c];
-    double o = (double)scale * acc / (double)B;
-    if (add_scale != 0.f) o += (double)add_scale * (double)coeff[b];
-    out = (float)o;
-  }
-  coeff[b] = out;
-}
+#include "mlp/recurrence.inc"   // mixed coefficient from Rz(x), direction update kernels (k_cg_pdir, k_cg_beta)
 
-// cg.py:52-53 after the fused outputs: beta = r'.r' / r.r ; p <- r' + beta * p ; partial p'.p' (next iteration's
-// shift term).  12*N bytes (read r', p; write p).  x and r were already updated by the fused epilogues.
-__global__ __launch_bounds__(kThreads) void k_cg_pdir(const bhg_chunk* __restrict__ chunks, int n_chunks,
-                                                      const float* __restrict__ r, float* __restrict__ p,
-                                                      const double* __restrict__ partRR_new, int nRR,
-                                                      double* __restrict__ partPP, double* __restrict__ scal) {
-  __shared__ double red[kWaves];
-  const double rr_new = sum_partials(partRR_new, nRR, red);
-  const double rr_old = scal[S_RR_OLD];
-  const float beta = (float)rr_new / (float)rr_old;
-  double acc = 0.0;
-  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const bhg_chunk ck = chunks[c];
-    float4 a[kVecPerThread], q[kVecPerThread];
-#pragma unroll
-    for (int i = 0; i < kVecPerThread; ++i) {
-      const int e = 4 * (threadIdx.x + kThreads * i);
-      a[i] = ld4(r + ck.flat_off, e, ck.len);
-      q[i] = ld4(p + ck.flat_off, e, ck.len);
-    }
-#pragma unroll
-    for (int i = 0; i < kVecPerThread; ++i) {
-      const int e = 4 * (threadIdx.x + kThreads * i);
-      float4 np;
-      np.x = fz_add(a[i].x, fz_mul(beta, q[i].x)); np.y = fz_add(a[i].y, fz_mul(beta, q[i].y));
-      np.z = fz_add(a[i].z, fz_mul(beta, q[i].z)); np.w = fz_add(a[i].w, fz_mul(beta, q[i].w));
-      st4(p + ck.flat_off, e, ck.len, np);
-      acc += (double)np.x * np.x + (double)np.y * np.y + (double)np.z * np.z + (double)np.w * np.w;
-    }
-  }
-  const double s = block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    partPP[blockIdx.x] = s;
-    if (blockIdx.x == 0) {
-      scal[S_RR_NEW] = rr_new;
-      scal[S_BETA] = (double)beta;
-    }
-  }
-}
-
-// Lazy direction (default of the fused CG solver): instead of k_cg_pdir's 12*N-byte pass, the coming iteration forms
-// p = r' + beta * p_old wherever it reads the direction (k_gemm<BF> loaders, the fused output epilogue, which also
-// writes it back).  This kernel is what remains of cg.py:51-53 between two iterations:
-//   rr' = sum partials, beta = rr' / rr (fp32 division of fp32-rounded dots, as the reference), and
-//   p.p of the coming direction = rr' + 2 beta r'.p_old + beta^2 p_old.p_old  (only used for the shift * p.p term of
-//   the step length; in exact CG r'.p_old = 0, so this is a sum of positives),
-// plus the direction update of the SMALL slices (biases, narrow head weights), which the head / reduce kernels read
-// directly.  A few blocks; every block recomputes the same scalars from the same partials in the same order.
-struct BetaArgs {
-  const double* part; int n, stride;     // [3][stride] partials of the previous iteration's epilogues (rr', r'.p, p.p)
-  double* scal;
-  const float* r; float* p;
-  int64_t off[BHG_MLP_MAX_LAYERS + 1]; int len[BHG_MLP_MAX_LAYERS + 1]; int nt;   // small slices (flat element offsets)
-};
-__device__ __forceinline__ void beta_body(const BetaArgs& a, const int bx) {
-  __shared__ double red[3][kWaves];
-  __shared__ float s_beta;
-  // this thread's element of the small slices: its loads are issued BEFORE the partial sums are reduced (independent)
-  const int gi = bx * kThreads + threadIdx.x;
-  int64_t eoff = -1;
-  {
-    int base = 0;
-    for (int t = 0; t < a.nt; ++t) {
-      if (eoff < 0 && gi < base + a.len[t]) eoff = a.off[t] + (gi - base);
-      base += a.len[t];
-    }
-  }
-  float rv = 0.f, pv = 0.f;
-  if (eoff >= 0) { rv = a.r[eoff]; pv = a.p[eoff]; }
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < a.n; i += kThreads) {
-    acc[0] += a.part[i];
-    acc[1] += a.part[a.stride + i];
-    acc[2] += a.part[2 * (int64_t)a.stride + i];
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const double v = wave_sum(acc[q]);
-    if (lane == 0) red[q][w] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWaves; ++i) t += red[q][i];
-      tot[q] = t;
-    }
-    const double rr_old = a.scal[S_RR_OLD];
-    const float beta = (float)tot[0] / (float)rr_old;
-    s_beta = beta;
-    if (bx == 0) {
-      a.scal[S_RR_NEW] = tot[0];
-      a.scal[S_BETA] = (double)beta;
-      a.scal[S_PP] = tot[0] + 2.0 * (double)beta * tot[1] + (double)beta * (double)beta * tot[2];
-    }
-  }
-  __syncthreads();
-  if (eoff >= 0) a.p[eoff] = fz_add(rv, fz_mul(s_beta, pv));
-}
-__global__ __launch_bounds__(kThreads) void k_cg_beta(BetaArgs a) { beta_body(a, blockIdx.x); }
-
-// ---- hoisted direction products (fused CG solver, BHG_MLP_HOIST) ----------------------------------------------------------
-// Half of the R-chain's matrix work does not depend on the chain at all, only on the direction: the forward products
-// Gf_l = h_l V_l^T (every MFMA layer) and the backward products Gb_l = delta_l V_l (every layer behind the first).  And
-// they are LINEAR in the direction, which the lazy CG direction is a two-term sum of:  p_k = r_k + beta p_{k-1}  =>
-//     G(p_k) = G(r_k) + beta * G(p_{k-1})          (batch-sized arrays, kept from iteration to iteration)
-// So ONE grouped launch at the top of the iteration (k_hoist) forms every G(r_k) — reading the residual alone: no
-// second operand, no mixing in the loaders, and no step of the chain in front of it, not even beta: the blocks behind the
-// GEMM tiles of the same launch do k_cg_beta's work — and k_hoist_reduce turns the split-K slabs into G(p_k).  What stays on
-// the dependent chain are the products with the constant weights, Rh_{l-1} W_l^T and Rd_l W_l: one operand pair, half the K
-// loop, run in the in-workgroup split-K form whose epilogue adds G (no slabs, no reduce launch).  One fill / drain for
-// half of the chain's flops instead of five; 9 dependent launches per iteration instead of 12.
-struct HoistProb {
-  const float* A;      // [Bp][K] batch-sized and iteration-invariant: h_l (forward) / delta_l (backward)
-  const float* Bm;     // residual slice of the W_l-shaped state: [N][K] (forward, K-contiguous) / [K][N] (backward)
-  float* slabs;        // [splits][Bp][N]  (splits == 1: the product itself)
-  int K, N, splits, rc, lda, ldb;
-  const float* A2;     // optional second operand pair with the same layouts and leading dimensions (projected CG:
-  const float* B2m;    // G(raw) = S Rd + T delta, two B x B Gram matrices times two batch-sized arrays); NULL = one pair
-  const float* X;      // fully projected CG: the tiles also emit <X, G(raw)> — raw.raw's share of this product (GemmArgs.dotX)
-  int a_slabs, a2_slabs, a_slab_stride;   // > 1: A / A2 arrive as K-split slabs (GemmPair.a_slabs)
-};
-constexpr int kHoistMax = 14;
-// Fully projected CG: partials of  r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>  and  p.raw (the same with G(p)) over the
-// MFMA layers' weight slices — the inner products of the N-sized residual / direction with the N-sized outer products, from
-// batch-sized arrays (see k_proj_scalars).  One float4 per thread, one (r.raw, p.raw) pair of fp64 partials per block.
-// (raw.raw has the same form with G(raw) in place of G(r): <raw_l, raw_l> = <Rd_l, Gf_l(raw)> + <Rh_{l-1}, Gb_l(raw)> — the tiles that
-//  form G(raw) emit it themselves, GemmArgs.dotX.  Round 3's first form took it from Gram matrices, <S_l, Rd_l Rd_l^T> +
-//  2 <E_l^T, T_l> + <D_l, Rh Rh^T>: five more B x B x K products per iteration.)
-struct ProjDotProb { const float* Gr; const float* Gp; const float* X; int N; };
-// One dot block takes kDotUnroll x 256 float4 of its problem: a quarter of the partials k_proj_step's blocks each sum again.
-constexpr int kDotUnroll = 4;
-constexpr int dot_blocks_of(int float4s) { return ((float4s + 255) / 256 + kDotUnroll - 1) / kDotUnroll; }
-constexpr int kProjDotMax = kHoistMax;
-// The small slices' outputs (head weight, biases) with their fused CG epilogue, as block classes of k_hoist (fully projected CG:
-// they are all that is left of k_outer_all).  Compact twin of BiasArgs (the hoisted forms take at most 8 layers).
-constexpr int kSmallL = kHoistMax / 2 + 1;
-struct BiasArgsC {
-  const float* rd[kSmallL]; const float* c[kSmallL]; float* out[kSmallL];
-  int n[kSmallL]; int blk0[kSmallL + 1]; int L, B; float rho2; int64_t foff[kSmallL];
-  const float* d0;   // see BiasArgs
-};
-struct SmallOutArgs {
-  HeadOuterArgs head; FuseArgs hf; int head_gx, head_blocks, head_has_rh;
-  BiasArgsC ba; FuseArgs bf; int bias_blocks;
-};
-struct HoistArgs {
-  HoistProb p[kHoistMax];
-  int blk0[kHoistMax + 1];
-  int n, Bp, gemm_blocks, do_beta;
-  BetaArgs beta;
-  int beta_blocks;               // blocks [gemm_blocks, gemm_blocks + beta_blocks): k_cg_beta's work (do_beta)
-  int dot_blocks, nd, B;         // then dot_blocks blocks of the projected inner products (fully projected CG)
-  ProjDotProb dp[kProjDotMax];
-  int dblk0[kProjDotMax + 1];
-  double* part_dot;              // [2][dot_blocks]: r.raw, p.raw
-  double* part_raw;              // [gemm_blocks]: raw.raw, one partial per G(raw) tile (HoistProb.X)
-  int small_blocks;              // then the small slices' output blocks (head_blocks + bias_blocks)
-  SmallOutArgs so;
-};
-
-static_assert(sizeof(HoistArgs) <= 3800, "kernel arguments of k_hoist must fit the kernarg segment");
-constexpr int kHoistLds = GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS > GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS
-                              ? GemmLds<LAYOUT_KC, LAYOUT_KC, 32>::FLOATS : GemmLds<LAYOUT_KC, LAYOUT_RC, 32>::FLOATS;
-template <int SMODE>   // epilogue of the small slices' output blocks: FUSE_CG / FUSE_NEUMANN
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hoist(HoistArgs ha) {
-  __shared__ __attribute__((aligned(16))) float smem[kHoistLds];
-  const int b = blockIdx.x;
-  if (b >= ha.gemm_blocks) {
-    const int e = b - ha.gemm_blocks;
-    if (e < ha.beta_blocks) {   // the scalar work between two iterations rides behind the tiles (cg.py:51-53, see k_cg_beta)
-      if (ha.do_beta) beta_body(ha.beta, e);
-      return;
-    }
-    // projected inner products: block d of product i
-    const int d = e - ha.beta_blocks;
-    if (d >= ha.dot_blocks) {   // small slices' outputs, CG epilogue (r' = r - alpha Hp on their slices + partials)
-      const int sb = d - ha.dot_blocks;
-      if (sb < ha.so.head_blocks) {
-        if (ha.so.head_has_rh) head_outer_body<true, SMODE>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
-        else head_outer_body<false, SMODE>(ha.so.head, ha.so.hf, sb % ha.so.head_gx, sb / ha.so.head_gx, ha.so.head_gx, smem);
-      } else {
-        bias_body<SMODE>(ha.so.ba, ha.so.bf, sb - ha.so.head_blocks, smem);
-      }
-      return;
-    }
-    int i = 0;
-    while (i + 1 < ha.nd && d >= ha.dblk0[i + 1]) ++i;
-    const ProjDotProb q = ha.dp[i];
-    const int nv = q.N / 4;
-    double ar = 0.0, ap = 0.0;
-#pragma unroll
-    for (int u = 0; u < kDotUnroll; ++u) {
-    const int64_t idx = ((int64_t)(d - ha.dblk0[i]) * kDotUnroll + u) * 256 + threadIdx.x;
-    if (idx < (int64_t)ha.Bp * nv && (int)(idx / nv) < ha.B) {
-      const float4 gr = ld16(q.Gr + idx * 4);
-      const float4 xv = ld16(q.X + idx * 4), gp = ld16(q.Gp + idx * 4);
-      ar += (double)xv.x * gr.x + (double)xv.y * gr.y + (double)xv.z * gr.z + (double)xv.w * gr.w;
-      ap += (double)xv.x * gp.x + (double)xv.y * gp.y + (double)xv.z * gp.z + (double)xv.w * gp.w;
-    }
-    }
-    double* red = reinterpret_cast<double*>(smem);
-    const double sr = block_sum(ar, red);
-    const double sp = block_sum(ap, red);
-    if (threadIdx.x == 0) { ha.part_dot[d] = sr; ha.part_dot[ha.dot_blocks + d] = sp; }
-    return;
-  }
-  int i = 0;
-  while (i + 1 < ha.n && b >= ha.blk0[i + 1]) ++i;
-  const int t = b - ha.blk0[i];
-  GemmArgs a{};
-  a.pr[0].A = ha.p[i].A; a.pr[0].B = ha.p[i].Bm; a.pr[0].lda = ha.p[i].lda; a.pr[0].ldb = ha.p[i].ldb;
-  a.pairs = 1;
-  if (ha.p[i].A2) {
-    a.pr[1].A = ha.p[i].A2; a.pr[1].B = ha.p[i].B2m; a.pr[1].lda = ha.p[i].lda; a.pr[1].ldb = ha.p[i].ldb; a.pairs = 2;
-    if (ha.p[i].splits == 2) a.pair_split = 1;   // one workgroup per operand pair: two slabs, half the K loop each
-  }
-  a.M = ha.Bp; a.N = ha.p[i].N; a.K = ha.p[i].K; a.splits = ha.p[i].splits;
-  a.out = ha.p[i].slabs; a.ldo = a.N; a.out_rows = ha.Bp; a.nt_out = 1; a.xpose_out = 1;
-  if (ha.p[i].X && ha.part_raw) { a.dotX = ha.p[i].X; a.dot_out = ha.part_raw + b; }
-  const int ntn = a.N / 32, ntm = ha.Bp / kTM;
-  const int bx = t % ntn, by = (t / ntn) % ntm, bz = t / (ntn * ntm);
-  a.pr[0].a_slabs = ha.p[i].a_slabs; a.pr[1].a_slabs = ha.p[i].a2_slabs;
-  a.pr[0].a_slab_stride = a.pr[1].a_slab_stride = ha.p[i].a_slab_stride;
-  if (ha.p[i].rc) {
-    if (ha.p[i].a_slabs > 1 || ha.p[i].a2_slabs > 1) gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false, true>(a, bx, by, bz, smem);
-    else gemm_body<LAYOUT_KC, LAYOUT_RC, 32, true, false>(a, bx, by, bz, smem);
-  } else gemm_body<LAYOUT_KC, LAYOUT_KC, 32, true, false>(a, bx, by, bz, smem);
-}
-
-// G(p_k)[m][n] = sum_s slabs[s][m][n] + beta * G(p_{k-1})[m][n]   (rows >= B zero; first iteration: no second term), and for
-// the first layer's forward product also Rh_0 = mask_0 * (G + c_0).  One float4 per thread; fixed summation order.
-struct HoistRedProb {
-  const float* slabs; float* G; int N, splits;
-  const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (G + bias)
-  float* G2;                                          // projected CG, first iteration: G(r_0) = G(p_0), kept separately
-};
-struct HoistRedArgs {
-  HoistRedProb p[kHoistMax];
-  int blk0[kHoistMax + 1];
-  int n, Bp, B, first;
-  const double* scal;
-};
-__global__ __launch_bounds__(256) void k_hoist_reduce(HoistRedArgs ra) {
-  const int b = blockIdx.x;
-  int i = 0;
-  while (i + 1 < ra.n && b >= ra.blk0[i + 1]) ++i;
-  const HoistRedProb pr = ra.p[i];
-  const int nv = pr.N / 4;
-  const int64_t total = (int64_t)ra.Bp * nv;
-  const int64_t idx = (int64_t)(b - ra.blk0[i]) * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
-  const int64_t slab = (int64_t)ra.Bp * pr.N;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (m < ra.B) {
-    constexpr int NB = 8;
-    const float* p0 = pr.slabs + idx * 4;
-    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), bv = gp, mv = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (!ra.first) gp = ld16(pr.G + idx * 4);
-    if (pr.out) { if (pr.bias) bv = ld16(pr.bias + n); if (pr.mask) mv = ld16(pr.mask + idx * 4); }
-    for (int s0 = 0; s0 < pr.splits; s0 += NB) {
-      float4 t[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) t[u] = ld16(p0 + (int64_t)(s0 + u < pr.splits ? s0 + u : pr.splits - 1) * slab);
-#pragma unroll
-      for (int u = 0; u < NB; ++u)
-        if (s0 + u < pr.splits) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
-    }
-    if (!ra.first) {   // the two roundings of p = r + (beta * p_old), applied to the products instead of the operands
-      const float beta = (float)ra.scal[S_BETA];
-      v.x = fz_add(v.x, fz_mul(beta, gp.x)); v.y = fz_add(v.y, fz_mul(beta, gp.y));
-      v.z = fz_add(v.z, fz_mul(beta, gp.z)); v.w = fz_add(v.w, fz_mul(beta, gp.w));
-    }
-    *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
-    if (pr.G2) *reinterpret_cast<float4*>(pr.G2 + idx * 4) = v;
-    if (pr.out) {
-      float4 o;
-      o.x = (v.x + bv.x) * mv.x; o.y = (v.y + bv.y) * mv.y; o.z = (v.z + bv.z) * mv.z; o.w = (v.w + bv.w) * mv.w;
-      *reinterpret_cast<float4*>(pr.out + idx * 4) = o;
-    }
-  } else {
-    *reinterpret_cast<float4*>(pr.G + idx * 4) = v;
-    if (pr.G2) *reinterpret_cast<float4*>(pr.G2 + idx * 4) = v;
-    if (pr.out) *reinterpret_cast<float4*>(pr.out + idx * 4) = v;
-  }
-}
-
-// ---- fully projected CG: the scalars of an iteration without an N-sized residual ------------------------------------------
-// With G(r), G(p) projected, the solve needs the N-sized residual and direction for ONE thing only: the dots r'.r' (-> beta,
-// next alpha) and p.p (-> the shift's share of p.Hp).  They follow from the recurrences as well — on the MFMA layers' slices
-//     r'.r' = r.r - 2 a r.Hp + a^2 Hp.Hp,   Hp = raw + shift p
-//     r.Hp  = r.raw + shift r.p          p.Hp = p.raw + shift p.p          Hp.Hp = raw.raw + 2 shift p.raw + shift^2 p.p
-//     r.raw = sum_l <Rd_l, Gf_l(r)> + <Rh_{l-1}, Gb_l(r)>     (p.raw alike: the dot blocks of k_hoist)
-//     raw.raw = sum_l <Rd_l Rd_l^T, S_l> + 2 <E_l^T, T_l> + <D_l, Rh_{l-1} Rh_{l-1}^T>     (B x B Gram matrices, k_wsk_group)
-//     r'.p = r.p - a p.Hp ;  next:  r.p <- r'.r' + b r'.p ,  p.p <- r'.r' + 2 b r'.p + b^2 p.p
-// in fp64, while the small slices (biases, head weight) stay explicit: their epilogues (k_outer_all's head / bias blocks) emit
-// their share of r'.r', r'.p, p.p as before.  So after iteration 0 NO kernel reads or writes an N-sized state vector: what
-// is left of an iteration is the R-chain through the constant weights and batch-sized work.  (CPU emulation in fp32 against
-// the reference's fp64 run at full size: 1e-7 ... 2e-6 on the well-conditioned variant, r.r falling smoothly through
-// twenty orders of magnitude; GPU: tests/test_cfg2_goldens.py.)  One workgroup.
-struct ProjScalArgs {
-  const double* part_dot; int dot_blocks;                        // [2][dot_blocks]: r.raw, p.raw (k_hoist's dot blocks)
-  const double* part_raw; int raw_blocks;                        // raw.raw: one partial per tile of the G(raw) launch
-  const double* part; int part_stride; int off0, n0, off1, n1;   // the small slices' epilogue partials [3][stride]
-  const float* r_small; float* p_small;                          // flat r / p (small slices only)
-  int64_t soff[BHG_MLP_MAX_LAYERS + 1]; int slen[BHG_MLP_MAX_LAYERS + 1]; int snt;
-  double* scal; double* pscal;   // pscal: {rr_big, rp_big, pp_big} x 2, ping-pong by iteration parity
-  float shift; int first, kpar;
-};
-// A few blocks (one thread per element of the small slices); every block recomputes the same scalars from the same partials in
-// the same order, block 0 publishes them (like k_cg_beta).  The previous iteration's {rr, rp, pp} are read from the OTHER
-// parity slot of pscal, so no block can see block 0's new values.
-// (bias 0 of the direction may be read at p0_rd and written at p0_wr instead of in place: k_proj_step)
-__device__ __forceinline__ float proj_scalars_body(const ProjScalArgs& a, const int bx, const bool publish, const bool small,
-                                                   const float* __restrict__ p0_rd, float* __restrict__ p0_wr) {
-  __shared__ double red[6][kWaves];
-  __shared__ float s_beta;
-  const int t = threadIdx.x;
-  // this thread's element of the small slices: loads first (independent of the sums)
-  const int gi = bx * kThreads + t;
-  int64_t eoff = -1;
-  int etensor = -1, eidx = 0;
-  if (small) {
-    int base = 0;
-    for (int tt = 0; tt < a.snt; ++tt) {
-      if (eoff < 0 && gi < base + a.slen[tt]) { eoff = a.soff[tt] + (gi - base); etensor = tt; eidx = gi - base; }
-      base += a.slen[tt];
-    }
-  }
-  const bool alt0 = etensor == 0 && p0_rd != nullptr;
-  float rv = 0.f, pv = 0.f;
-  if (eoff >= 0) { rv = a.r_small[eoff]; pv = alt0 ? p0_rd[eidx] : a.p_small[eoff]; }
-  double ar = 0.0, ap = 0.0, ag = 0.0;
-  for (int i = t; i < a.dot_blocks; i += kThreads) { ar += a.part_dot[i]; ap += a.part_dot[a.dot_blocks + i]; }
-  for (int i = t; i < a.raw_blocks; i += kThreads) ag += a.part_raw[i];
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int i = t; i < a.n0 + a.n1; i += kThreads) {
-    const int j = i < a.n0 ? a.off0 + i : a.off1 + (i - a.n0);
-    s0 += a.part[j]; s1 += a.part[a.part_stride + j]; s2 += a.part[2 * (int64_t)a.part_stride + j];
-  }
-  // six fixed-order sums with ONE barrier (wave sums, then the waves in order: block_sum's order, value for value)
-  {
-    const double v[6] = {ar, ap, ag, s0, s1, s2};
-    const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const double ws = wave_sum(v[q]);
-      if (lane == 0) red[q][wv] = ws;
-    }
-  }
-  __syncthreads();
-  if (t == 0) {
-    double tot[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      double acc = 0.0;
-#pragma unroll
-      for (int i = 0; i < kWaves; ++i) acc += red[q][i];
-      tot[q] = acc;
-    }
-    const double r_raw = tot[0], p_raw = tot[1], raw_raw = tot[2], rr_s = tot[3], rp_s = tot[4], pp_s = tot[5];
-    const double rr_old = a.scal[S_RR_OLD];          // r.r of this iteration (k_cg_alpha)
-    const double al = a.scal[S_ALPHA_RING + a.kpar], sh = (double)a.shift;
-    const double* pin = a.pscal + 4 * (a.kpar ^ 1);
-    double* pout = a.pscal + 4 * a.kpar;
-    double rr_b, rp_b, pp_b;
-    // first iteration: p = r (bhg_cg_init), so the small slices' share of r.r is their p.p partial of this very iteration
-    if (a.first) rr_b = rp_b = pp_b = rr_old - pp_s;
-    else { rr_b = pin[0]; rp_b = pin[1]; pp_b = pin[2]; }
-    const double rHp = r_raw + sh * rp_b, pHp = p_raw + sh * pp_b, HpHp = raw_raw + 2.0 * sh * p_raw + sh * sh * pp_b;
-    const double rr_b1 = rr_b - 2.0 * al * rHp + al * al * HpHp;
-    const double rp_b1 = rp_b - al * pHp;              // r'.p over the MFMA layers
-    const double rr1 = rr_b1 + rr_s, rp1 = rp_b1 + rp_s, pp = pp_b + pp_s;
-    const float beta = (float)rr1 / (float)rr_old;     // fp32 division of the fp32-rounded dots, as the reference (cg.py:51-52)
-    const double b = (double)beta;
-    if (publish) {
-      a.scal[S_RR_NEW] = rr1;
-      a.scal[S_BETA] = b;
-      a.scal[S_PP] = rr1 + 2.0 * b * rp1 + b * b * pp;
-      pout[0] = rr_b1;
-      pout[1] = rr_b1 + b * rp_b1;
-      pout[2] = rr_b1 + 2.0 * b * rp_b1 + b * b * pp_b;
-    }
-    s_beta = beta;
-  }
-  __syncthreads();
-  // cg.py:53 for the small slices (biases, head weight): p = r' + beta p
-  if (eoff >= 0) {
-    const float np = fz_add(rv, fz_mul(s_beta, pv));
-    if (alt0) p0_wr[eidx] = np; else a.p_small[eoff] = np;
-  }
-  return s_beta;
-}
-// The scalars as a launch of their own (BHG_PROJ_STEP_ALONE; the default merges them into the next iteration's k_proj_step): it
-// runs alone because the chain of the next iteration and k_proj_update (Rh_0 needs the first bias direction) read the slices.
-__global__ __launch_bounds__(kThreads) void k_proj_scalars(ProjScalArgs a) {
-  (void)proj_scalars_body(a, blockIdx.x, blockIdx.x == 0, true, nullptr, nullptr);
-}
-
-// ---- projected CG (BHG_MLP_PROJ, default on): the direction products WITHOUT the N-sized operand ---------------------------
-// The products G(.) are linear, and the residual itself obeys r' = r - alpha (raw + shift p) with raw = H p's weight-shaped
-// outputs — outer products of batch-sized factors:  raw(W_l) = Rd_l^T h_l + delta_l^T Rh_{l-1}.  So
-//     Gf_l(raw) = h_l raw(W_l)^T  = (h_l h_l^T) Rd_l       + (h_l Rh_{l-1}^T) delta_l   = S_l Rd_l + T_l delta_l
-//     Gb_l(raw) = delta_l raw(W_l) = (delta_l Rd_l^T) h_l  + (delta_l delta_l^T) Rh_{l-1} = E_l h_l + D_l Rh_{l-1}
-// with B x B Gram matrices (S_l, D_l once per solve; T_l, E_l per iteration: k_wsk_group) and batch-deep products
-// (k_hoist with two operand pairs, K = batch): ~0.2 GFLOP instead of the 2.75 GFLOP of k_hoist on the residual, and no pass
-// over the N-sized state at all.  The recurrences (k_proj_update, at the top of the next iteration):
-//     G(r_{k+1}) = G(r_k) - alpha_k (G(raw_k) + shift G(p_k))        G(p_{k+1}) = G(r_{k+1}) + beta_k G(p_k)
-// Only iteration 0 reads the N-sized residual (k_hoist on the initial vector).  Checked against the reference's CPU goldens
-// on the well-conditioned full-size variant like every other arm (tests/test_cfg2_goldens.py); fp32 emulation on the CPU
-// beforehand: 1e-6 from the fp64 truth, the same as the direct form and as the reference itself.
-struct ProjProb {
-  float* Gr; float* Gp; const float* Graw; const float* Graw2 /* second slab of G(raw) or NULL */; int N;
-  const float* bias; const float* mask; float* out;   // out != NULL: out = mask * (Gp + bias)   (first layer: Rh_0)
-};
-struct ProjArgs {
-  ProjProb p[kHoistMax];
-  int blk0[kHoistMax + 1];
-  int n, Bp, B, kpar_prev;
-  float shift;
-  const double* scal;   // CG: alpha_{k-1}, beta_{k-1}.  NULL: Neumann — G(v') = G(v) - alpha (G(raw) + shift G(v)) with the constant
-  float alpha;          // step `alpha` (Gr and Gp then name the same array)
-};
-// b0: bias 0 of the coming direction is formed here, r'_b0 + beta * p_b0_old (k_proj_step; the very roundings of the small slices'
-// update), instead of read from pr.bias
-__device__ __forceinline__ void proj_update_body(const ProjArgs& pa, const int b, const bool own_beta, const float beta_in,
-                                                 const float* __restrict__ r_b0, const float* __restrict__ p_b0_old) {
-  int i = 0;
-  while (i + 1 < pa.n && b >= pa.blk0[i + 1]) ++i;
-  const ProjProb pr = pa.p[i];
-  const int nv = pr.N / 4;
-  const int64_t total = (int64_t)pa.Bp * nv;
-  const int64_t idx = (int64_t)(b - pa.blk0[i]) * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
-  float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gp = gr;
-  if (m < pa.B) {
-    const float4 r0 = ld16(pr.Gr + idx * 4), p0 = ld16(pr.Gp + idx * 4);
-    float4 w0 = ld16(pr.Graw + idx * 4);
-    if (pr.Graw2) { const float4 w1 = ld16(pr.Graw2 + idx * 4); w0.x += w1.x; w0.y += w1.y; w0.z += w1.z; w0.w += w1.w; }
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mv = make_float4(1.f, 1.f, 1.f, 1.f);
-    const float alpha = pa.scal ? (float)pa.scal[S_ALPHA_RING + pa.kpar_prev] : pa.alpha;
-    const float beta = own_beta ? beta_in : (pa.scal ? (float)pa.scal[S_BETA] : 0.f);
-    if (pr.out) {
-      if (pr.bias && r_b0) {
-        const float4 rb = ld16(r_b0 + n), pb = ld16(p_b0_old + n);
-        bv.x = fz_add(rb.x, fz_mul(beta, pb.x)); bv.y = fz_add(rb.y, fz_mul(beta, pb.y));
-        bv.z = fz_add(rb.z, fz_mul(beta, pb.z)); bv.w = fz_add(rb.w, fz_mul(beta, pb.w));
-      } else if (pr.bias) {
-        bv = ld16(pr.bias + n);
-      }
-      if (pr.mask) mv = ld16(pr.mask + idx * 4);
-    }
-    // the rounding sequence of the N-sized recurrences (fuse_elem): Hp = raw + shift p; r' = r - alpha Hp; p' = r' + beta p
-#define BHG_PROJ1(c)                                                                  \
-    {                                                                                 \
-      float hv = w0.c;                                                                \
-      if (pa.shift != 0.f) hv = fz_add(hv, fz_mul(pa.shift, p0.c));                   \
-      gr.c = fz_sub(r0.c, fz_mul(alpha, hv));                                         \
-      gp.c = pa.scal ? fz_add(gr.c, fz_mul(beta, p0.c)) : gr.c;                       \
-    }
-    BHG_PROJ1(x) BHG_PROJ1(y) BHG_PROJ1(z) BHG_PROJ1(w)
-#undef BHG_PROJ1
-    *reinterpret_cast<float4*>(pr.Gr + idx * 4) = gr;
-    *reinterpret_cast<float4*>(pr.Gp + idx * 4) = gp;
-    if (pr.out) {
-      float4 o;
-      o.x = (gp.x + bv.x) * mv.x; o.y = (gp.y + bv.y) * mv.y; o.z = (gp.z + bv.z) * mv.z; o.w = (gp.w + bv.w) * mv.w;
-      *reinterpret_cast<float4*>(pr.out + idx * 4) = o;
-    }
-  } else if (pr.out) {
-    *reinterpret_cast<float4*>(pr.out + idx * 4) = gr;
-  }
-}
-__global__ __launch_bounds__(256) void k_proj_update(ProjArgs pa) { proj_update_body(pa, blockIdx.x, false, 0.f, nullptr, nullptr); }
-
-// Fully projected CG, default: the scalars of iteration k-1 and the recurrences of iteration k in ONE launch (one dependent
-// launch less per iteration).  Every block sums the same partials in the same order to the same beta (a few KB out of L2);
-// the blocks behind the update blocks own the small slices' direction update and the first of them publishes the scalars.
-// Nothing in this launch reads what another block of it writes: the update blocks of the first layer need the coming first
-// bias direction — they form it themselves from r'_b0 and the OLD p_b0, which the small blocks leave alone (the new one goes to
-// the other of two slots, p0_wr; every later reader of that slice is pointed at the slot of its iteration's parity).
-struct ProjStepArgs {
-  ProjArgs pa; ProjScalArgs sa;
-  int update_blocks;
-  const float* r_b0; const float* p0_rd; float* p0_wr;
-};
-static_assert(sizeof(ProjStepArgs) <= 3800, "kernel arguments of k_proj_step must fit the kernarg segment");
-__global__ __launch_bounds__(256) void k_proj_step(ProjStepArgs g) {
-  const int b = blockIdx.x;
-  const bool small = b >= g.update_blocks;
-  const int sb = small ? b - g.update_blocks : 0;
-  const float beta = proj_scalars_body(g.sa, sb, small && sb == 0, small, g.p0_rd, g.p0_wr);
-  if (!small) proj_update_body(g.pa, b, true, beta, g.r_b0, g.p0_rd);
-}
+#include "mlp/proj.inc"   // hoisted direction products (k_hoist, k_hoist_reduce) and the projected solvers' kernels (k_proj_scalars / _update / _step)
 
 // ---- per-device side stream + events -------------------------------------------------------------------------------
 struct SideState {
