@@ -12,7 +12,8 @@ import csv, glob, json, collections, hashlib, sys, os
 sys.path.insert(0, os.getcwd())
 from betty_amd import _native
 sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()
-base = json.load(open("profiles/r03_pmc_traffic.json"))
+src = "gpurun_out/pmc/r03_pmc_traffic.json" if os.path.exists("gpurun_out/pmc/r03_pmc_traffic.json") else "profiles/r03_pmc_traffic.json"
+base = json.load(open(src))   # (after gpu_pmc3.sh in the same call: the fresh file; on its own: the committed one)
 assert base["lib_sha256"] == sha, "the committed traffic file belongs to another library"
 def per_kernel(C):
     f = glob.glob(f"/tmp/pmc_neu_{C}/*counter_collection.csv")

@@ -43,3 +43,4 @@ run darts --algo darts
 run cg_global_ws1 --mode global
 BHG_MLP_HOIST=0 run cg_global_ws1_classic_chain --mode global
 bash scripts/gpu_pmc3.sh 2>&1 | tail -40
+bash scripts/gpu_pmc3_neumann.sh 2>&1 | tail -6
