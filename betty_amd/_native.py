@@ -101,6 +101,11 @@ SYMBOLS = {
         c_int,
         [_PP, _PP, _PP, _PP, c_int, _CH, c_int, c_void_p, c_double, c_double, c_double, c_double, c_void_p, c_void_p],
     ),
+    "bhg_debug_set": (c_int, [c_char_p, c_int]),
+    "bhg_debug_unset": (c_int, [c_char_p]),
+    "bhg_debug_reset": (None, []),
+    "bhg_debug_key_count": (c_int, []),
+    "bhg_debug_key_name": (c_char_p, [c_int]),
     "bhg_timing_enable": (c_int, [c_int]),
     "bhg_timing_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
     "bhg_logreg_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -169,6 +174,33 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().bhg_last_error()
         raise NativeLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def _debug_key(key: str) -> bytes:
+    """'BHG_MLP_PROJ' / 'MLP_PROJ' / 'mlp_proj' -> b'mlp_proj' (the names of round 1-3's environment switches still work)."""
+    k = key.strip()
+    if k.upper().startswith("BHG_"):
+        k = k[4:]
+    return k.lower().encode()
+
+
+def debug_set(key: str, value) -> None:
+    """Select a measurement / test arm of libbhg (include/bhg.h: bhg_debug_set).  value None = back to the shipped behaviour.
+    The library itself reads no environment variable."""
+    lib = load()
+    if value is None:
+        check(lib.bhg_debug_unset(_debug_key(key)), f"bhg_debug_unset({key})")
+    else:
+        check(lib.bhg_debug_set(_debug_key(key), int(value)), f"bhg_debug_set({key})")
+
+
+def debug_reset() -> None:
+    load().bhg_debug_reset()
+
+
+def debug_keys():
+    lib = load()
+    return [lib.bhg_debug_key_name(i).decode() for i in range(lib.bhg_debug_key_count())]
 
 
 def ptr_array(ptrs):

@@ -32,6 +32,28 @@ inline size_t ws_bytes(int T) {
 enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 /* fused solver: p.p of the coming direction */, S_ALPHA_RING = 10 /* and 11: fused solver, alpha of iteration k in slot 10 + (k & 1) */,
        S_NPART0 = 8 /* and 9 */ };
 
+// ---- debug / A-B switches ----------------------------------------------------------
+// The library reads NO environment variable.  Every measurement arm and every test-only behaviour is an int in this table,
+// unset by default, changed only through bhg_debug_set() (include/bhg.h) — so the product's behaviour cannot depend on a stray
+// variable in a user's shell.  dbg(key, dflt): the value, or `dflt` while the key is unset.  Read on every call.
+#define BHG_DBG_KEYS(X)                                                                                                      \
+  X(mlp_wsk) X(mlp_wsk_maxk) X(mlp_wsk_depth) X(mlp_wsk_lds) X(wsl_depth) X(no_nt_slabs) X(gemm_no_xpose) X(mlp_no_fast)      \
+  X(mlp_tn) X(split_target) X(split_cap) X(mlp_no_head) X(gram_ksplit) X(gram_kchunk) X(proj_graw_split) X(mlp_proj)         \
+  X(mlp_hoist) X(hoist_wgs) X(proj_step_alone) X(mlp_no_side) X(mlp_no_fuse) X(mlp_no_outer_all) X(neumann_side)             \
+  X(hoist_staged_mink) X(proj_alpha_alone) X(proj_small_alone) X(outer_order_by_work) X(outer_no_pre) X(outer_stagger)       \
+  X(mlp_no_fused_solve) X(cg_eager_p) X(cg_x_every_iter) X(neumann_p_every_iter) X(head_no_prefetch) X(cg_spin_limit)        \
+  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb)
+enum DbgKey : int {
+#define BHG_DBG_ENUM(n) DBG_##n,
+  BHG_DBG_KEYS(BHG_DBG_ENUM)
+#undef BHG_DBG_ENUM
+  DBG_COUNT
+};
+constexpr int kDbgUnset = INT32_MIN;
+extern int g_dbg[DBG_COUNT];
+inline bool dbg_is_set(DbgKey k) { return g_dbg[k] != kDbgUnset; }
+inline int dbg(DbgKey k, int dflt) { return g_dbg[k] == kDbgUnset ? dflt : g_dbg[k]; }
+
 // ---- error plumbing -------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define BHG_HIP_CHECK(expr)                                                        \

@@ -18,6 +18,23 @@ void set_error(const char* fmt, ...) {
 
 static inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+int g_dbg[DBG_COUNT] = {
+#define BHG_DBG_INIT(n) kDbgUnset,
+    BHG_DBG_KEYS(BHG_DBG_INIT)
+#undef BHG_DBG_INIT
+};
+static const char* const kDbgNames[DBG_COUNT] = {
+#define BHG_DBG_NAME(n) #n,
+    BHG_DBG_KEYS(BHG_DBG_NAME)
+#undef BHG_DBG_NAME
+};
+static int dbg_find(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < DBG_COUNT; ++i)
+    if (strcmp(kDbgNames[i], key) == 0) return i;
+  return -1;
+}
+
 }  // namespace bhg
 
 using namespace bhg;
@@ -29,6 +46,25 @@ int bhg_version(void) { return BHG_VERSION; }
 const char* bhg_last_error(void) { return g_err; }
 
 size_t bhg_workspace_bytes(int T) { return ws_bytes(T); }
+
+int bhg_debug_set(const char* key, int value) {
+  const int i = dbg_find(key);
+  BHG_REQUIRE(i >= 0, "unknown debug key");
+  BHG_REQUIRE(value != kDbgUnset, "INT32_MIN is the 'unset' marker");
+  g_dbg[i] = value;
+  return BHG_OK;
+}
+int bhg_debug_unset(const char* key) {
+  const int i = dbg_find(key);
+  BHG_REQUIRE(i >= 0, "unknown debug key");
+  g_dbg[i] = kDbgUnset;
+  return BHG_OK;
+}
+void bhg_debug_reset(void) {
+  for (int i = 0; i < DBG_COUNT; ++i) g_dbg[i] = kDbgUnset;
+}
+int bhg_debug_key_count(void) { return DBG_COUNT; }
+const char* bhg_debug_key_name(int i) { return (i >= 0 && i < DBG_COUNT) ? kDbgNames[i] : nullptr; }
 
 int64_t bhg_layout_flat_size(const int64_t* numel, int T) {
   if (T < 0 || (T > 0 && !numel)) return -1;

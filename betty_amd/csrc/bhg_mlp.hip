@@ -48,8 +48,7 @@ namespace {
 // address path retires about one line per 4 clocks — 8 waves x 12 loads x 16 lines x 4 clk per 32-k chunk is three times
 // the chunk's MFMA time.  Read on every call so a test can compare both arms in one process.
 inline int wsk_mode(int chain_mode, int unfused_hint) {
-  const char* e = getenv("BHG_MLP_WSK");
-  if (e) return atoi(e);   // an explicit value applies everywhere
+  if (dbg_is_set(DBG_mlp_wsk)) return dbg(DBG_mlp_wsk, 0);   // an explicit value applies everywhere
   // defaults: fused CG solver 2 (short reductions; the staged form of mode 3 is +0.75 % there but draws 2.3e-4 from the fp64
   // truth in the CG-20 noise lottery); the Neumann solver — no reduction, no chaos — 3 in BOTH of its arms
   // (the un-fused arm asks for it through bhg_mlp_hvp_mode, so fused and un-fused stay bitwise equal); everything else 0
@@ -60,12 +59,10 @@ inline int wsk_mode(int chain_mode, int unfused_hint) {
 inline bool wsk_wanted(int mode, int pairs, int K) {
   if (mode == 1) return true;
   if (mode != 2 && mode != 3) return false;
-  const char* e = getenv("BHG_MLP_WSK_MAXK");
-  return pairs * K <= (e ? atoi(e) : 1024);
+  return pairs * K <= dbg(DBG_mlp_wsk_maxk, 1024);
 }
 inline int wsk_depth() {
-  const char* e = getenv("BHG_MLP_WSK_DEPTH");
-  const int d = e ? atoi(e) : 3;
+  const int d = dbg(DBG_mlp_wsk_depth, 3);
   return d == 2 ? 2 : 3;
 }
 inline bool wsk_eligible(const WskArgs& a) {
@@ -89,7 +86,7 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   for (int i = 0; i < a.pairs; ++i) bf = bf || a.pr[i].mix != 0;
   const dim3 grid(a.ntm * a.ntn), block(64 * kWskWaves);
   const int d = wsk_depth();
-  static const bool force_staged = getenv("BHG_MLP_WSK_LDS") != nullptr && atoi(getenv("BHG_MLP_WSK_LDS")) != 0;
+  const bool force_staged = dbg(DBG_mlp_wsk_lds, 0) != 0;
   // LDS-staged form (two register stages).  Only WITHOUT the lazy direction: the mixing instance (a third staged operand)
   // does not fit the register file (256 VGPRs + 42-44 spilled, round-2 verdict) and is not built — callers with a lazy
   // direction get the direct form or split-K (run_chain never asks for the staged form then); scripts/check_spills.py
@@ -101,7 +98,7 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
-    static const int wsl_depth = getenv("BHG_WSL_DEPTH") ? atoi(getenv("BHG_WSL_DEPTH")) : 2;   // A/B: register stages of the staged form
+    const int wsl_depth = dbg(DBG_wsl_depth, 2);   // A/B: register stages of the staged form
     if (wsl_depth == 3) {
       static bool attr3 = false;
       if (!attr3) {
@@ -132,7 +129,7 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  static const int wsl_depth = getenv("BHG_WSL_DEPTH") ? atoi(getenv("BHG_WSL_DEPTH")) : 2;
+  const int wsl_depth = dbg(DBG_wsl_depth, 2);
   if (wsl_depth == 3) hipLaunchKernelGGL(k_wsk_group<3>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
   else hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
@@ -142,11 +139,11 @@ void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   GemmArgs a = a_in;
   // split-K slabs leave with non-temporal stores: they stream out while the kernel runs instead of sitting dirty in L2
   // until its end (same-box A/B: 3.707 vs 3.778 ms per step; BHG_NO_NT_SLABS restores plain stores)
-  static const bool nt_slabs = getenv("BHG_NO_NT_SLABS") == nullptr;
+  const bool nt_slabs = dbg(DBG_no_nt_slabs, 0) == 0;
   a.nt_out = (nt_slabs && (a.splits > 1 || a.out_rows > 0)) ? 1 : 0;
   // slab tiles of all-interior 128 x 32 instances leave through LDS as 16-B stores (11.7 vs 12.6 us for a 2-step
   // launch, 276.5 vs 270.5 steps/s, two same-box repetitions; BHG_GEMM_NO_XPOSE restores the direct 4-B stores)
-  static const bool xpose = getenv("BHG_GEMM_NO_XPOSE") == nullptr;
+  const bool xpose = dbg(DBG_gemm_no_xpose, 0) == 0;
   a.xpose_out = xpose ? 1 : 0;
   dim3 grid((a.N + tn - 1) / tn, (a.M + kTM - 1) / kTM, a.splits);
   bool fast = a.M % kTM == 0 && a.N % tn == 0 && a.K % kTK == 0;
@@ -158,7 +155,7 @@ void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   if (bf)   // a pair without mixing reads its own operand twice with weight 0 (B + 0 * B = B exactly; the loop stays branch-free)
     for (int i = 0; i < a.pairs; ++i)
       if (!a.pr[i].mix) a.pr[i].B2 = a.pr[i].B;
-  static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;   // A/B switch (debug)
+  const bool no_fast = dbg(DBG_mlp_no_fast, 0) != 0;   // A/B switch (debug)
   if (no_fast) fast = false;
 #define BHG_GEMM(TNV, F, BFV) hipLaunchKernelGGL((k_gemm<LA, LB, TNV, F, BFV>), grid, dim3(256), 0, st, a)
   if (tn == 64) {
@@ -171,7 +168,7 @@ void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
 #undef BHG_GEMM
 }
 inline int skinny_tile_n() {
-  static const int tn = getenv("BHG_MLP_TN") ? atoi(getenv("BHG_MLP_TN")) : 32;  // 32 measured +2 % over 64
+  const int tn = dbg(DBG_mlp_tn, 32);  // 32 measured +2 % over 64
   return tn == 64 ? 64 : 32;
 }
 
@@ -194,10 +191,10 @@ int pick_splits(int tiles, int K, int pairs) {
   // fill 3 workgroups per CU (measured on the cfg-2 shapes: 512 -> 171 us, 768 -> 165 us, 896 -> 169 us per HVP);
   // never split below one K step; prefer a split count that divides the K steps evenly (no short last slice)
   const int ksteps = (K + kTK - 1) / kTK;
-  static const int target = getenv("BHG_SPLIT_TARGET") ? atoi(getenv("BHG_SPLIT_TARGET")) : 768;
+  const int target = dbg(DBG_split_target, 768);
   int s = (target + tiles - 1) / tiles;
   if (s > ksteps) s = ksteps;
-  static const int cap = getenv("BHG_SPLIT_CAP") ? atoi(getenv("BHG_SPLIT_CAP")) : 16;
+  const int cap = dbg(DBG_split_cap, 16);
   if (s > cap) s = cap;
   if (s < 1) s = 1;
   if (ksteps % s != 0) {
@@ -248,7 +245,7 @@ int side_state(SideState** out) {
 }
 
 bool use_head(const bhg_mlp* m) {
-  static const bool no_head = getenv("BHG_MLP_NO_HEAD") != nullptr;    // A/B switch (debug)
+  const bool no_head = dbg(DBG_mlp_no_head, 0) != 0;    // A/B switch (debug)
   return !no_head && m->L >= 1 && m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0;
 }
 
@@ -275,10 +272,9 @@ int reduce_blocks(int slab, int N) {
 // (BHG_GRAM_KSPLIT=0: one workgroup per tile, the A/B arm)
 constexpr int kGramSplitMax = 8;
 inline int gram_ksplit(int K) {
-  const char* e = getenv("BHG_GRAM_KSPLIT");
-  if (e && atoi(e) == 0) return 1;
-  const char* c = getenv("BHG_GRAM_KCHUNK");   // k per workgroup (A/B)
-  const int per = c && atoi(c) >= 32 ? atoi(c) : 512;
+  if (dbg(DBG_gram_ksplit, 1) == 0) return 1;
+  const int c = dbg(DBG_gram_kchunk, 512);   // k per workgroup (A/B)
+  const int per = c >= 32 ? c : 512;
   const int s = K / per;
   return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
 }
@@ -296,16 +292,13 @@ struct HoistPlan {
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
 inline bool graw_split() {   // G(raw) products with two operand pairs: one workgroup per pair (A/B: BHG_PROJ_GRAW_SPLIT=0)
-  static const bool on = !(getenv("BHG_PROJ_GRAW_SPLIT") && atoi(getenv("BHG_PROJ_GRAW_SPLIT")) == 0);
-  return on;
+  return dbg(DBG_proj_graw_split, 1) != 0;
 }
 inline int proj_mode() {
-  const char* e = getenv("BHG_MLP_PROJ");   // read on every call (A/B in one process); default on
-  return e ? atoi(e) : 1;
+  return dbg(DBG_mlp_proj, 1);   // read on every call (A/B in one process); default on
 }
 inline int hoist_mode() {
-  const char* e = getenv("BHG_MLP_HOIST");   // read on every call so a test can compare both arms in one process
-  return e ? atoi(e) : 1;
+  return dbg(DBG_mlp_hoist, 1);   // read on every call so a test can compare both arms in one process
 }
 void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
   memset(hp, 0, sizeof(*hp));
@@ -321,7 +314,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
   for (int l = 0; l + 1 < L; ++l) { hp->layer[n] = l; hp->bwd[n] = 0; hp->K[n] = m->dims[l]; hp->N[n] = m->dims[l + 1]; hp->gf[l] = n; ++n; }
   for (int l = 1; l + 1 < L; ++l) { hp->layer[n] = l; hp->bwd[n] = 1; hp->K[n] = m->dims[l + 1]; hp->N[n] = m->dims[l]; hp->gb[l] = n; ++n; }
   hp->n = n;
-  static const int slots = getenv("BHG_HOIST_WGS") ? atoi(getenv("BHG_HOIST_WGS")) : 768;
+  const int slots = dbg(DBG_hoist_wgs, 768);
   const int ntm = Bp / kTM;
   int tgt = 8;
   for (; tgt < 4096; ++tgt) {
@@ -379,8 +372,7 @@ int graw_blocks(const HoistPlan* hp, int Bp) {
 // Fully projected CG: scalars of iteration k-1 + recurrences of iteration k in one launch (k_proj_step); BHG_PROJ_STEP_ALONE=1
 // keeps them as two launches (k_proj_scalars at the end of an iteration, k_proj_update at the top of the next): the A/B arm.
 bool proj_step_merged() {
-  const char* e = getenv("BHG_PROJ_STEP_ALONE");
-  return !(e && *e && *e != '0');
+  return dbg(DBG_proj_step_alone, 0) == 0;
 }
 
 // Fused-solver scratch (device), carved out of the caller's buffer by bhg_mlp_cg_solve.
@@ -469,10 +461,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   const int L = m->L, Bp = m->Bp, B = m->B;
   const float rho2 = cm.mode == FUSE_NONE ? m->ridge2 : 0.f;
   const bool cg = cm.mode == FUSE_CG;
-  static const bool no_side_env = getenv("BHG_MLP_NO_SIDE") != nullptr;    // A/B switches (debug)
-  static const bool no_fuse = getenv("BHG_MLP_NO_FUSE") != nullptr;
-  static const bool no_outer_all = getenv("BHG_MLP_NO_OUTER_ALL") != nullptr;
-  static const bool neumann_side = getenv("BHG_NEUMANN_SIDE") != nullptr;    // A/B: fused Neumann with side-stream outputs
+  const bool no_side_env = dbg(DBG_mlp_no_side, 0) != 0;    // A/B switches (debug)
+  const bool no_fuse = dbg(DBG_mlp_no_fuse, 0) != 0;
+  const bool no_outer_all = dbg(DBG_mlp_no_outer_all, 0) != 0;
+  const bool neumann_side = dbg(DBG_neumann_side, 0) != 0;    // A/B: fused Neumann with side-stream outputs
   // `single`: one stream, no events, all weight-shaped outputs in one launch after the chain
   const bool single = cg || (cm.mode == FUSE_NEUMANN && !neumann_side && !no_outer_all);
   const bool no_side = no_side_env || single;
@@ -587,7 +579,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       ++g_proj_iterations;
     }
-    static const int staged_mink = getenv("BHG_HOIST_STAGED_MINK") ? atoi(getenv("BHG_HOIST_STAGED_MINK")) : 256;
+    const int staged_mink = dbg(DBG_hoist_staged_mink, 256);
     // forward chain: Rh_l = mask_l * (Rh_{l-1} W_l^T + Gf_l + c_l)
     for (int l = 1; l + 1 < L; ++l) {
       const int K = m->dims[l], N = m->dims[l + 1];
@@ -694,7 +686,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     bool f = Mo % kTM == 0 && No % kTN == 0 && (a.ldo & 3) == 0;
     for (int i = 0; i < a.pairs; ++i) f = f && (a.pr[i].lda & 3) == 0 && (a.pr[i].ldb & 3) == 0;
     if (cm.mode != FUSE_NONE) f = f && (cm.starts[2 * l] & 3) == 0;   // 16-B aligned state slices
-    static const bool no_fast = getenv("BHG_MLP_NO_FAST") != nullptr;
+    const bool no_fast = dbg(DBG_mlp_no_fast, 0) != 0;
     *fast = f && !no_fast;
     *ga = a;
   };
@@ -840,14 +832,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
     // (projected Neumann: EVERY iteration — the closing pass needs G(raw) of the last one)
     const bool proj_iter = hp && cm.proj && (cg ? (!cm.apply_out && !cm.skip_outputs) : true);
-    static const bool alpha_alone = getenv("BHG_PROJ_ALPHA_ALONE") != nullptr;   // A/B
+    const bool alpha_alone = dbg(DBG_proj_alpha_alone, 0) != 0;   // A/B
     const bool alpha_in_gram = cg && proj_iter && !alpha_alone;
     if (cg && !alpha_in_gram) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
       BHG_HIP_CHECK(hipGetLastError());
       return BHG_OK;
     }
-    static const bool small_alone = getenv("BHG_PROJ_SMALL_ALONE") != nullptr;   // A/B
+    const bool small_alone = dbg(DBG_proj_small_alone, 0) != 0;   // A/B
     const bool small_in_graw = proj_iter && (cm.proj >= 2 || !cg) && !small_alone;
     if (proj_iter) {   // projected CG: G(raw) of this iteration for the next one's recurrences
       float* hbase = cm.ws->hoist;
@@ -936,7 +928,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     int order[BHG_MLP_MAX_LAYERS];
     // dispatch order = tile order: the layer with the most tiles first (measured 260 vs 256 steps/s against
     // "two-pair tiles first"; BHG_OUTER_ORDER_BY_WORK selects the latter)
-    static const bool work_first = getenv("BHG_OUTER_ORDER_BY_WORK") != nullptr;
+    const bool work_first = dbg(DBG_outer_order_by_work, 0) != 0;
     auto weight = [&](int l) { return !work_first ? (double)outer_blocks(m, l, head) : (l > 0 ? 2.0 : 1.0) * 1e9 + outer_blocks(m, l, head); };
     for (int i = 0; i < n_mfma; ++i) order[i] = i;
     for (int i = 1; i < n_mfma; ++i)   // insertion sort, descending
@@ -966,8 +958,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       oa.bf = bias_fz;
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
-      static const bool no_pre = getenv("BHG_OUTER_NO_PRE") != nullptr;   // A/B runs
-      static const int stagger = getenv("BHG_OUTER_STAGGER") ? atoi(getenv("BHG_OUTER_STAGGER")) : 1;
+      const bool no_pre = dbg(DBG_outer_no_pre, 0) != 0;   // A/B runs
+      const int stagger = dbg(DBG_outer_stagger, 1);
       oa.stagger = stagger;
       if (no_pre) {
         if (cg) hipLaunchKernelGGL((k_outer_all<FUSE_CG, false>), dim3(total), dim3(256), lds_max, st, oa, ba);
@@ -1094,7 +1086,7 @@ int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, con
 }
 
 int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
-  static const bool off = getenv("BHG_MLP_NO_FUSED_SOLVE") != nullptr;   // A/B switch: callers fall back to HVP + recurrence kernel
+  const bool off = dbg(DBG_mlp_no_fused_solve, 0) != 0;   // A/B switch: callers fall back to HVP + recurrence kernel
   return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m);
 }
 
@@ -1137,7 +1129,7 @@ static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p
   for (int i = 0; i < 2 * m->L; ++i) c->dir[i] = p + starts[i];
   c->pgrid = n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks;
   // Direction update between two iterations: lazy (default; see k_cg_beta) or the 12*N-byte k_cg_pdir pass (A/B switch)
-  static const bool eager = getenv("BHG_CG_EAGER_P") != nullptr;
+  const bool eager = dbg(DBG_cg_eager_p, 0) != 0;
   c->lazy = global || !eager;
   BetaArgs& ba = c->ba;
   ba = BetaArgs{};
@@ -1191,7 +1183,7 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
   // iteration 0: beta = 0 (bhg_cg_init zeroes the scalars) and p = r, so "r + beta * p" is the initial direction
   cm.lazy = lazy;
   // x is read and written every other iteration (FuseArgs.x_mode): even iterations defer, odd ones catch up
-  static const bool x_every = getenv("BHG_CG_X_EVERY_ITER") != nullptr;   // A/B switch
+  const bool x_every = dbg(DBG_cg_x_every_iter, 0) != 0;   // A/B switch
   cm.x_mode = (lazy && !x_every) ? ((k & 1) ? 2 : (k + 1 < K ? 1 : 0)) : 0;
   if (!c->x) cm.x_mode = 1;
   // Without a solution vector the LAST iteration ends with its step length: alpha_{K-1} completes Rz(x) (k_cg_alpha), and
@@ -1318,7 +1310,7 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     cm.alpha = alpha; cm.shift = hvp_shift;
     cm.apply_out = k == K - 1; cm.out_scale = -alpha;   // neumann.py:66 and the negation of neumann.py:45/54
     // the accumulator p is read and written every OTHER iteration (FuseArgs.x_mode): even iterations defer, odd catch up
-    static const bool p_every = getenv("BHG_NEUMANN_P_EVERY_ITER") != nullptr;   // A/B switch
+    const bool p_every = dbg(DBG_neumann_p_every_iter, 0) != 0;   // A/B switch
     cm.x_mode = p_every ? 0 : ((k & 1) ? 2 : (k + 1 < K ? 1 : 0));
     cm.first = k == 0;
     if (!p) { cm.x_mode = 1; cm.rzx_acc = w.rzx; }

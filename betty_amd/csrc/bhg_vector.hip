@@ -923,14 +923,8 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
   return BHG_OK;
 }
 
-// BHG_CG_SPIN_LIMIT overrides the barrier's polling bound (tests force a time-out with 0).
-static unsigned spin_limit() {
-  static const unsigned v = [] {
-    const char* e = getenv("BHG_CG_SPIN_LIMIT");
-    return e ? (unsigned)strtoul(e, nullptr, 10) : kSpinLimit;
-  }();
-  return v;
-}
+// bhg_debug_set("cg_spin_limit", n) overrides the barrier's polling bound (tests force a time-out with 0).
+static unsigned spin_limit() { return dbg_is_set(DBG_cg_spin_limit) ? (unsigned)dbg(DBG_cg_spin_limit, 0) : kSpinLimit; }
 
 // The LDS-assisted and hybrid resident instances park direction slices in 144 KiB of dynamic LDS per workgroup.  Probed
 // once per device (mutex-guarded: the first CG steps of two host threads may race): the attribute must be granted for

@@ -170,6 +170,18 @@ int bhg_sama_adam_precondition(const void* const* vec, const void* const* last_g
                                const bhg_chunk* chunks_dev, int n_chunks, float* out_flat,
                                double beta1, double beta2, double eps, double lr, void* ws, void* stream);
 
+/* ---- debug / A-B switches (measurement and tests only; not part of the drop-in surface) ----
+ * libbhg reads NO environment variable: its behaviour depends on its arguments alone.  The arms the
+ * test-suite compares against each other and the same-box A/B measurements of profiles/ are selected
+ * through a table of named ints, all UNSET by default (unset = the shipped behaviour).  Keys are the
+ * lower-case names listed in betty_amd/csrc/bhg_common.hpp (BHG_DBG_KEYS), e.g. "mlp_proj",
+ * "mlp_hoist", "packed_chain".  Process-global, not thread-safe against concurrent solves.        */
+int bhg_debug_set(const char* key, int value);   /* BHG_ERR_ARG for an unknown key */
+int bhg_debug_unset(const char* key);
+void bhg_debug_reset(void);                       /* every key back to unset        */
+int bhg_debug_key_count(void);
+const char* bhg_debug_key_name(int i);            /* NULL past the end              */
+
 /* ---- optional kernel timing (measurement only) ----------------------------------
  * When enabled, every bhg_cg_step / bhg_neumann_step launch group carries start/stop
  * HIP events attached to its first/last kernel on the launch stream (kernel begin ->

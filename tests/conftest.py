@@ -41,6 +41,30 @@ def _poison_the_gpu_allocator():
     yield
 
 
+class _DebugArms:
+    """Selects measurement / test arms of libbhg through bhg_debug_set (the library reads no environment variable).  The
+    method names mirror pytest's monkeypatch so the arm tables of rounds 1-3 ("BHG_MLP_PROJ": "0", ...) read as before."""
+
+    def setenv(self, key, value):
+        from betty_amd import _native
+
+        _native.debug_set(key, int(value))
+
+    def delenv(self, key, raising=False):
+        from betty_amd import _native
+
+        _native.debug_set(key, None)
+
+
+@pytest.fixture
+def bhg_debug():
+    from betty_amd import _native
+
+    _native.debug_reset()
+    yield _DebugArms()
+    _native.debug_reset()
+
+
 _GOLDEN_CACHE = {}
 
 

@@ -99,7 +99,7 @@ def _arms(algo):
     return arms
 
 
-def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
+def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
     from betty_amd import _native
     from betty_amd import hypergradient as hg
     from betty_amd.backend import get_backend
@@ -107,21 +107,21 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
     be = get_backend()
     assert be.name == "hip"
     if arm.get("wsk") is None:
-        monkeypatch.delenv("BHG_MLP_WSK", raising=False)
+        bhg_debug.delenv("BHG_MLP_WSK", raising=False)
     else:
-        monkeypatch.setenv("BHG_MLP_WSK", arm["wsk"])
+        bhg_debug.setenv("BHG_MLP_WSK", arm["wsk"])
     if arm.get("hoist") is None:
-        monkeypatch.delenv("BHG_MLP_HOIST", raising=False)
+        bhg_debug.delenv("BHG_MLP_HOIST", raising=False)
     else:
-        monkeypatch.setenv("BHG_MLP_HOIST", arm["hoist"])
+        bhg_debug.setenv("BHG_MLP_HOIST", arm["hoist"])
     if arm.get("proj") is None:
-        monkeypatch.delenv("BHG_MLP_PROJ", raising=False)
+        bhg_debug.delenv("BHG_MLP_PROJ", raising=False)
     else:
-        monkeypatch.setenv("BHG_MLP_PROJ", arm["proj"])
+        bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
     for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK"):
-        monkeypatch.delenv(key, raising=False)
+        bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
-        monkeypatch.setenv(key, val)
+        bhg_debug.setenv(key, val)
     saved = be.cg_variant
     be.cg_variant = {"stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}.get(arm.get("variant"), _native.BHG_CG_AUTO)
     try:
@@ -137,13 +137,13 @@ def _run_arm(algo, K, seed, ridge, arm, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("aname", list(mk.ALGOS))
 @pytest.mark.parametrize("seed", WELL_SEEDS)
-def test_every_arm_matches_the_reference_cpu_golden_on_the_well_conditioned_variant(seed, aname, monkeypatch):
+def test_every_arm_matches_the_reference_cpu_golden_on_the_well_conditioned_variant(seed, aname, bhg_debug):
     algo, K = mk.ALGOS[aname]
     want32, want64 = GOLD[f"well/{seed}/{aname}/fp32"], GOLD[f"well/{seed}/{aname}/fp64"]
     spread = float(GOLD[f"well/{seed}/{aname}/ref_spread"])
     worst = 0.0
     for name, arm in _arms(algo):
-        got = _run_arm(algo, K, seed, mk.RIDGE_WELL, arm, monkeypatch)
+        got = _run_arm(algo, K, seed, mk.RIDGE_WELL, arm, bhg_debug)
         e32, e64 = rel(got, want32), rel(got, want64)
         worst = max(worst, e32)
         print(f"cfg2 well seed={seed} {aname} {name:18s}: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e} "
@@ -154,7 +154,7 @@ def test_every_arm_matches_the_reference_cpu_golden_on_the_well_conditioned_vari
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", METRIC_SEEDS)
-def test_metric_configuration_against_the_reference_cpu_goldens(seed, monkeypatch):
+def test_metric_configuration_against_the_reference_cpu_goldens(seed, bhg_debug):
     """ridge 1e-2: CG-20's fp32 noise decides the 3rd-4th digit, whoever runs it (the reference's CPU run sits `ref_spread`
     from its own fp64 run).  Held: the product is no further from the fp64 truth than 3x the reference's own distance
     (floor rtol 1e-4); Neumann (no division, no chaos) to rtol 1e-4 — except where a ReLU kink separates the reference's
@@ -162,7 +162,7 @@ def test_metric_configuration_against_the_reference_cpu_goldens(seed, monkeypatc
     for aname, (algo, K) in mk.ALGOS.items():
         want32, want64 = GOLD[f"metric/{seed}/{aname}/fp32"], GOLD[f"metric/{seed}/{aname}/fp64"]
         spread = float(GOLD[f"metric/{seed}/{aname}/ref_spread"])
-        got = _run_arm(algo, K, seed, bench.RIDGE, dict(hvp="hip", fused=True, wsk=None), monkeypatch)
+        got = _run_arm(algo, K, seed, bench.RIDGE, dict(hvp="hip", fused=True, wsk=None), bhg_debug)
         e32, e64 = rel(got, want32), rel(got, want64)
         print(f"cfg2 metric seed={seed} {aname}: product vs reference-CPU fp32 {e32:.2e}, product vs fp64 truth {e64:.2e}, "
               f"reference fp32 vs fp64 {spread:.2e}")

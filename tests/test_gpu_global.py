@@ -147,14 +147,14 @@ def _emulate(parts, prev, vecs, K, alpha, keep):
 @pytest.mark.parametrize("keep", [True, False], ids=["x-materialised", "solution-free"])
 @pytest.mark.parametrize("dims,B,K,alpha", [([256, 384, 128, 10], 100, 6, 1.0), ([70, 130, 36, 10], 64, 4, 0.5),
                                             ([512, 256, 128, 64, 10], 128, 8, 1.0)], ids=lambda v: str(v))
-def test_two_emulated_ranks_match_the_one_rank_solver_on_the_concatenated_batch(dims, B, K, alpha, keep, hoist, monkeypatch):
+def test_two_emulated_ranks_match_the_one_rank_solver_on_the_concatenated_batch(dims, B, K, alpha, keep, hoist, bhg_debug):
     """mean_g (r - alpha H_g p) = r - alpha H p: two half batches, two states, the 8-byte and the N-sized exchange done by hand,
     against bhg_mlp_cg_solve on the whole batch (2B rows: other tile counts, other summation trees — fp32 noise, tolerance
     north_star's 1e-4 with ridge 0.05 keeping the K-step recurrence well inside it)."""
     if hoist is None:
-        monkeypatch.delenv("BHG_MLP_HOIST", raising=False)
+        bhg_debug.delenv("BHG_MLP_HOIST", raising=False)
     else:
-        monkeypatch.setenv("BHG_MLP_HOIST", hoist)
+        bhg_debug.setenv("BHG_MLP_HOIST", hoist)
     ridge = 0.05
     inner, prev, x, y, _ = _problem(dims, 2 * B, ridge, 7 * sum(dims) + B + K, K, keep)
     g = torch.Generator().manual_seed(99)

@@ -557,7 +557,7 @@ def test_fused_solver_matches_unfused(algo, dims, B, K):
 
 @pytest.mark.parametrize("dims,B,K", [([256, 384, 128, 10], 100, 5), ([70, 130, 36, 10], 100, 4), ([3072, 2048, 1536, 384, 10], 100, 20)],
                          ids=lambda v: str(v))
-def test_fused_cg_without_a_solution_vector(dims, B, K, be, monkeypatch):
+def test_fused_cg_without_a_solution_vector(dims, B, K, be, bhg_debug):
     """The product default: the fused CG solver is handed x = NULL (WeightedCEMLP.keep_solution=False) — the mixed
     second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), accumulated from batch-sized factors, so the N-sized
     solution is never zeroed, read or written, and the x buffer of the layout is provably untouched (filled with NaN before
@@ -566,7 +566,7 @@ def test_fused_cg_without_a_solution_vector(dims, B, K, be, monkeypatch):
     without x goes further (no N-sized state at all, tests/test_cfg2_goldens.py holds it to the reference)."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
-    monkeypatch.setenv("BHG_MLP_PROJ", "9")
+    bhg_debug.setenv("BHG_MLP_PROJ", "9")
     outs = {}
     for keep in (True, False):
         curr, prev, direction, _ = _mlp_problem(dims, B, ridge=0.05, seed=sum(dims) + B + K)
@@ -816,17 +816,17 @@ def test_fused_solver_full_size_cfg2(ridge):
      ([256, 256, 256, 256, 128, 10], 100), ([512, 256, 64, 10], 200)],
     ids=lambda v: str(v),
 )
-def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
+def test_wsk_gemm_arm_matches_split_k(dims, B, bhg_debug):
     """k_gemm_wsk (a final 32 x 32 tile per workgroup: K split over the workgroup's waves, sum + bias + mask [+ the T2
     partial of the fused CG step length] before anything leaves the chip) against the split-K launches + reduce
     kernels: the HVP's outputs (un-fused chain, K-contiguous and N-contiguous weight operands, one and two operand
     pairs) and a fused CG solve (lazy direction formed in the loaders, T2 from the tile epilogue).  The launch counter
     proves the arm under test really ran."""
     lib = _native.load()
-    monkeypatch.setenv("BHG_MLP_HOIST", "0")   # the classic chain: BHG_MLP_WSK picks the form of ITS skinny GEMMs
+    bhg_debug.setenv("BHG_MLP_HOIST", "0")   # the classic chain: BHG_MLP_WSK picks the form of ITS skinny GEMMs
     outs, sols = {}, {}
     for arm in ("0", "1"):
-        monkeypatch.setenv("BHG_MLP_WSK", arm)
+        bhg_debug.setenv("BHG_MLP_WSK", arm)
         n0 = lib.bhg_mlp_wsk_launches()
         curr, prev, direction, provider = _mlp_problem(dims, B, ridge=0.05, seed=sum(dims) + B)
         outs[arm] = [t.clone() for t in provider("hip").prepare()(direction)]
@@ -841,7 +841,7 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
     x1, x0 = sols["1"][1][0].astype(np.float64), sols["0"][1][0].astype(np.float64)
     assert np.linalg.norm(x1 - x0) <= 5e-5 * np.linalg.norm(x0)
     # bit-reproducible (fixed-order sums in LDS, no atomics)
-    monkeypatch.setenv("BHG_MLP_WSK", "1")
+    bhg_debug.setenv("BHG_MLP_WSK", "1")
     again = _run_solver("cg", dims, B, 0.05, 4, sum(dims) + B, True)
     assert all(np.array_equal(u, v) for u, v in zip(again[1], sols["1"][1]))
 
@@ -854,7 +854,7 @@ def test_wsk_gemm_arm_matches_split_k(dims, B, monkeypatch):
     ids=lambda v: str(v),
 )
 @pytest.mark.parametrize("algo", ["cg", "neumann"])
-def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, monkeypatch):
+def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_debug):
     """Fused solvers, three forms of the R-chain on the same inputs:
       classic    BHG_MLP_HOIST=0: direction products inside the chain, lazy direction mixed in the GEMM loaders;
       hoisted    BHG_MLP_HOIST=1 BHG_MLP_PROJ=0: every direction product h V^T / delta V in ONE grouped launch on the
@@ -881,10 +881,10 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, monke
     out = {}
     for name, env in arms.items():
         for k in ("BHG_MLP_HOIST", "BHG_MLP_PROJ"):
-            monkeypatch.delenv(k, raising=False)
+            bhg_debug.delenv(k, raising=False)
         for k, v in env.items():
             if k != "keep":
-                monkeypatch.setenv(k, v)
+                bhg_debug.setenv(k, v)
         keep = env.get("keep", "1") == "1"
         h0, p0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations()
         out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
@@ -905,7 +905,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, monke
 @pytest.mark.parametrize("algo", ["cg", "neumann"])
 @pytest.mark.parametrize("ridge,alpha,K", [(0.05, 0.5, 4), (0.0, None, 3), (0.05, None, 1), (0.05, None, 2), (0.3, 0.25, 7)],
                          ids=lambda v: str(v))
-def test_projected_solvers_edge_cases(algo, ridge, alpha, K, monkeypatch):
+def test_projected_solvers_edge_cases(algo, ridge, alpha, K, bhg_debug):
     """The default (fully projected CG / projected Neumann, no solution vector) against the classic chain where the recurrences
     could go wrong: cg_alpha != 1 (the reference's quirk: the step length uses cg_alpha * Hp, the residual update the
     un-scaled Hp, cg.py:42-50), no ridge (shift = 0), K = 1 (no recurrence at all), K = 2 (one), a batch that fills two
@@ -914,7 +914,7 @@ def test_projected_solvers_edge_cases(algo, ridge, alpha, K, monkeypatch):
     for dims, B in (([256, 384, 128, 10], 100), ([512, 256, 256, 64, 10], 200)):
         outs = {}
         for arm in ("0", "1"):
-            monkeypatch.setenv("BHG_MLP_HOIST", arm)
+            bhg_debug.setenv("BHG_MLP_HOIST", arm)
             p0 = lib.bhg_mlp_proj_iterations()
             outs[arm], _ = _run_solver(algo, dims, B, ridge, K, 5 + K, True, alpha=alpha, keep=False)
             projected = lib.bhg_mlp_proj_iterations() - p0
@@ -924,12 +924,12 @@ def test_projected_solvers_edge_cases(algo, ridge, alpha, K, monkeypatch):
         assert rel <= 5e-5, (algo, dims, B, ridge, alpha, K, rel)
 
 
-def test_wsk_defaults_per_solver(monkeypatch):
+def test_wsk_defaults_per_solver(bhg_debug):
     """Default (no BHG_MLP_WSK): the fused CG solver takes the in-workgroup form for reductions of <= 1024 k (mode 2); the
     un-fused CG chain never does; the Neumann solver uses mode 3 (short reductions direct, long R-backward LDS-staged)
     in BOTH arms — the un-fused loop asks for it through bhg_mlp_hvp_mode — so they stay bitwise equal."""
-    monkeypatch.delenv("BHG_MLP_WSK", raising=False)
-    monkeypatch.setenv("BHG_MLP_HOIST", "0")   # the classic chain (the hoisted form has its own test below)
+    bhg_debug.delenv("BHG_MLP_WSK", raising=False)
+    bhg_debug.setenv("BHG_MLP_HOIST", "0")   # the classic chain (the hoisted form has its own test below)
     lib = _native.load()
     dims, B = [256, 384, 128, 10], 100     # per iteration: R-forward of layer 0 (256 k) and R-backward into it (2 x 128 k)
     n0 = lib.bhg_mlp_wsk_launches()
@@ -1213,6 +1213,8 @@ sys.path.insert(0, {root!r})
 from betty_amd import _native
 from betty_amd.backend import get_backend
 be = get_backend()
+if {limit!r} is not None:
+    _native.debug_set("cg_spin_limit", int({limit!r}))
 dev = torch.device("cuda:0")
 vec = [torch.randn(600 * 4096, device=dev)]          # every one of the 256 workgroups owns chunks
 hv = [2.0 * vec[0]]
@@ -1229,15 +1231,13 @@ print("TIMED_OUT", int(be.cg_barrier_timed_out(lay)), "NAN", int(torch.isnan(x).
 @pytest.mark.parametrize("limit,expect", [("0", (1, 1)), (None, (0, 0))])
 def test_resident_barrier_timeout_poisons_the_result(limit, expect):
     """A grid barrier that gives up (GPU shared mid-run) must not return a plausible wrong answer:
-    the flag is raised AND the iterate is NaN.  BHG_CG_SPIN_LIMIT=0 forces the time-out."""
+    the flag is raised AND the iterate is NaN.  bhg_debug_set("cg_spin_limit", 0) forces the time-out (in a process of its
+    own: a timed-out barrier leaves the resident kernel's counters in an unusable state)."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.pop("BHG_CG_SPIN_LIMIT", None)
-    if limit is not None:
-        env["BHG_CG_SPIN_LIMIT"] = limit
-    out = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT.format(root=root)], env=env, capture_output=True,
+    out = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT.format(root=root, limit=limit)], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("TIMED_OUT")][-1].split()
