@@ -264,6 +264,9 @@ def main():
                          "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's)")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=INT",
+                    help="select a measurement arm of libbhg through bhg_debug_set (the library reads no environment variable); "
+                         "repeatable, e.g. --debug packed_chain=0 --debug mlp_proj=0.  Echoed in config.debug_arms")
     args = ap.parse_args()
 
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner on the C-level stdout when a process group
@@ -298,6 +301,9 @@ def main():
     from betty_amd.backend import get_backend
 
     be = get_backend()
+    for kv in args.debug:
+        key, _, val = kv.partition("=")
+        _native.debug_set(key, int(val))
     be.cg_variant = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}[args.variant]
     K = args.cg_iters
     if args.mode == "global":
@@ -557,6 +563,7 @@ def main():
                                 ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world))
                 if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,
+                "debug_arms": args.debug or None,
                 "lib_sha256": lib_sha256()[:16],
             },
             "roofline": roof,

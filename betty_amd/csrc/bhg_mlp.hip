@@ -40,6 +40,8 @@ namespace {
 
 #include "mlp/wsk.inc"   // skinny GEMMs with the K split inside the workgroup (register and LDS-staged forms), k_wsk_group
 
+#include "mlp/wskp.inc"   // round 4: the same products on PACKED operands (no LDS in the K loop), several problems per launch; k_pack
+
 // BHG_MLP_WSK: 0 = split-K launches + reduce everywhere | 1 = in-workgroup split wherever the shape allows | 2 = only
 // for short reductions (pairs * K <= BHG_MLP_WSK_MAXK, default 1024), where the launch and the slab round trip weigh more
 // than the operand re-reads.  Measured on the cfg-2 shapes (rocprofv3 timeline, MI355X): K = 2 x 384 -> 10.8 us against
@@ -133,6 +135,30 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
   if (wsl_depth == 3) hipLaunchKernelGGL(k_wsk_group<3>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
   else hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
+
+// Grouped launch on packed operands (wskp.inc).  Block tables are rounded up to multiples of 8 so that a problem's tile t keeps
+// t % 8 == blockIdx.x % 8 (the XCD it runs on).
+struct WskpBuilder {
+  WskpArgs g{};
+  int blk = 0;
+  bool add(const WskpProb& q) {
+    if (g.n >= kWskpMax) return false;
+    g.p[g.n] = q;
+    g.blk0[g.n++] = blk;
+    blk += (((q.RA / 32) * (q.RB / 32) * q.nsplit) + 7) & ~7;
+    return true;
+  }
+  void launch(hipStream_t st) {
+    if (!g.n) return;
+    g.blk0[g.n] = blk;
+    const int d = dbg(DBG_packed_depth, 3);   // register stages of the K loop (A/B)
+    if (d == 2) hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
+    else if (d == 4) hipLaunchKernelGGL(k_wskp<4>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
+    else hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
+    g = WskpArgs{};
+    blk = 0;
+  }
+};
 
 template <int LA, int LB>
 void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
@@ -385,6 +411,13 @@ struct FusedWs {
   double* part_dot; double* pscal;  // fully projected CG: [2][dot_blocks] partials of r.raw / p.raw; {rr, rp, pp} over the MFMA layers
   double* part_raw;                 // fully projected CG: [raw_blocks] partials of raw.raw (tiles of the G(raw) launch)
   float* pb0[2];                    // fully projected CG: the first bias's slice of the direction, two slots by iteration parity (k_proj_step)
+  // packed operands of the chain and of the Gram products (wskp.inc); NULL when the hoisted forms do not apply
+  float* Wf[BHG_MLP_MAX_LAYERS];    // W_l as the N-side operand of the forward chain   [d_l / 16][d_{l+1}][16],  l = 1 .. L-2
+  float* Wb[BHG_MLP_MAX_LAYERS];    // W_l^T as the N-side operand of the backward chain [d_{l+1} / 16][d_l][16]
+  float* hpk[BHG_MLP_MAX_LAYERS];   // h_l      [d_l / 16][Bp][16],      l = 0 .. L-2
+  float* dpk[BHG_MLP_MAX_LAYERS];   // delta_l  [d_{l+1} / 16][Bp][16],  l = 1 .. L-2
+  float* Rhp[BHG_MLP_MAX_LAYERS];   // Rh_l     [d_{l+1} / 16][Bp][16],  l = 0 .. L-3   (written by the producer of Rh_l)
+  float* Rdp[BHG_MLP_MAX_LAYERS];   // Rd_l     [d_{l+1} / 16][Bp][16],  l = 1 .. L-2   (written by the producer of Rd_l)
   size_t bytes;
 };
 void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
@@ -413,7 +446,52 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->part_raw = static_cast<double*>(take(sizeof(double) * (hp.ok ? hp.raw_blocks : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   for (int i = 0; i < 2; ++i) w->pb0[i] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[1]));
+  if (hp.ok) {
+    const int L = m->L;
+    const size_t Bp = (size_t)m->Bp;
+    for (int l = 0; l + 1 < L; ++l) {
+      w->hpk[l] = static_cast<float*>(take(sizeof(float) * Bp * m->dims[l]));
+      if (l + 2 < L) w->Rhp[l] = static_cast<float*>(take(sizeof(float) * Bp * m->dims[l + 1]));
+      if (l >= 1) {
+        w->Wf[l] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[l + 1] * m->dims[l]));
+        w->Wb[l] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[l + 1] * m->dims[l]));
+        w->dpk[l] = static_cast<float*>(take(sizeof(float) * Bp * m->dims[l + 1]));
+        w->Rdp[l] = static_cast<float*>(take(sizeof(float) * Bp * m->dims[l + 1]));
+      }
+    }
+  }
   w->bytes = off;
+}
+
+// Packed copies of the constants of a solve (wskp.inc): the chain's weights in both orientations, h_l and delta_l for the Gram
+// products.  One launch, once per solve: 3 x 15 M floats moved at cfg 2, ~1 % of a CG-20 solve.
+bool packed_chain_on(const FusedWs& w) { return w.Wf[1] != nullptr && dbg(DBG_packed_chain, 1) != 0; }
+int pack_operands(const bhg_mlp* m, const FusedWs& w, hipStream_t st) {
+  PackArgs g{};
+  int blk = 0;
+  auto add = [&](const float* X, float* Xp, int R, int K, int kind) {
+    if (g.n >= kPackMax) return false;
+    g.p[g.n] = {X, Xp, R, K, kind};
+    g.blk0[g.n] = blk;
+    blk += pack_blocks(g.p[g.n]);
+    ++g.n;
+    return true;
+  };
+  const int L = m->L, Bp = m->Bp;
+  bool ok = true;
+  for (int l = 0; l + 1 < L && ok; ++l) {
+    ok = ok && add(m->h[l], w.hpk[l], Bp, m->dims[l], 0);
+    if (l >= 1) {
+      ok = ok && add(m->delta[l], w.dpk[l], Bp, m->dims[l + 1], 0);
+      ok = ok && add(m->W[l], w.Wf[l], m->dims[l + 1], m->dims[l], 0);
+      ok = ok && add(m->W[l], w.Wb[l], m->dims[l], m->dims[l + 1], 1);
+    }
+  }
+  BHG_REQUIRE(ok, "too many layers for one packing launch");
+  g.blk0[g.n] = blk;
+  hipLaunchKernelGGL(k_pack, dim3(blk), dim3(256), 0, st, g);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
 }
 
 // What one pass of the HVP chain does with its weight-shaped outputs.
@@ -509,6 +587,13 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   HeadFuse head_fuse{};
   bool fuse_head = false;
   const bool do_chain = cm.gphase != 2;
+  // projected CG, not the last iteration (projected Neumann: EVERY iteration): the iteration ends with the G(raw) products
+  const bool proj_iter = hp && cm.proj && (cg ? (!cm.apply_out && !cm.skip_outputs) : true);
+  // round 4: the chain through the constant weights on PACKED operands (wskp.inc), the per-iteration Gram products T_l / E_l as
+  // extra workgroups of the chain launch that consumes the same packed activation (debug keys packed_chain / packed_gram: A/B)
+  const bool packed = hp && packed_chain_on(*cm.ws);
+  const bool gram_in_chain = packed && proj_iter && !cm.stop_after_head && dbg(DBG_packed_gram, 1) != 0;
+  bool sd_in_chain = false;   // first iteration: S_l, D_l rode in the first chain launch as well
   if (hp && do_chain) {
     float* hbase = cm.ws->hoist;
     HoistArgs ha{};
@@ -525,7 +610,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ha.blk0[i] = hp->blk0[i];
       HoistRedProb& rq = ra.p[i];
       rq.slabs = q.slabs; rq.G = hbase + hp->g_off[i]; rq.N = hp->N[i]; rq.splits = hp->splits[i];
-      if (!hp->bwd[i] && l == 0) { rq.bias = static_cast<const float*>(dir[1]); rq.mask = m->mask[0]; rq.out = m->Rh[0]; }
+      if (!hp->bwd[i] && l == 0) {
+        rq.bias = static_cast<const float*>(dir[1]); rq.mask = m->mask[0]; rq.out = m->Rh[0];
+        rq.outp = packed ? cm.ws->Rhp[0] : nullptr;
+      }
     }
     ha.blk0[hp->n] = hp->blk0[hp->n];
     ha.n = hp->n; ha.Bp = Bp; ha.gemm_blocks = hp->blk0[hp->n];
@@ -551,7 +639,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         q.Gr = hbase + (cg ? hp->gr_off[i] : hp->g_off[i]); q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
         // (products with two operand pairs leave one slab per pair, see the G(raw) launch)
         if (graw_split() && !(hp->bwd[i] == 0 && hp->layer[i] == 0)) q.Graw2 = q.Graw + (size_t)Bp * hp->N[i];
-        if (!hp->bwd[i] && hp->layer[i] == 0) { q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0]; }
+        if (!hp->bwd[i] && hp->layer[i] == 0) {
+          q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0];
+          q.outp = packed ? cm.ws->Rhp[0] : nullptr;
+        }
         pa.blk0[i] = ra.blk0[i];
       }
       pa.blk0[hp->n] = rblk;
@@ -585,6 +676,45 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const int K = m->dims[l], N = m->dims[l + 1];
       const float* c = static_cast<const float*>(dir[2 * l + 1]);
       const float* Gf = hbase + hp->g_off[hp->gf[l]];
+      if (packed) {
+        WskpBuilder wb;
+        WskpProb q{};
+        q.Ap = cm.ws->Rhp[l - 1]; q.Bq = cm.ws->Wf[l]; q.RA = Bp; q.RB = N; q.K = K; q.B = B; q.nsplit = 1;
+        if (l == L - 2) {   // raw K-split slabs: the head kernel combines them itself (adds Gf and c_l, applies the mask)
+          int sp = (240 + (Bp / 32) * (N / 32) - 1) / ((Bp / 32) * (N / 32));   // ~ one workgroup per CU
+          const int cap = pick_splits((N + tn - 1) / tn, K, 1);                  // what m->partial was sized for
+          if (sp > cap) sp = cap;
+          if (sp > K / 64) sp = K / 64;
+          if (sp < 1) sp = 1;
+          q.nsplit = sp; q.raw = 1; q.out = m->partial;
+          head_fuse = {m->partial, sp, Bp * N, c, m->mask[l], m->Rh[l], Gf};
+          fuse_head = true;
+        } else {
+          q.bias = c; q.mask = m->mask[l]; q.addend = Gf; q.out = m->Rh[l]; q.outp = cm.ws->Rhp[l];
+        }
+        wb.add(q);
+        if (gram_in_chain) {   // T_l = h_l Rh_{l-1}^T: K-split slabs, summed by the consumer (the G(raw) products)
+          WskpProb t{};
+          t.Ap = cm.ws->hpk[l]; t.Bq = cm.ws->Rhp[l - 1]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
+          t.nsplit = gram_ksplit(K); t.raw = 1; t.out = hbase + hp->tslab_off[l];
+          wb.add(t);
+          if (cm.first && l == 1 && 2 + (L - 1) + (L - 2) <= kWskpMax) {   // once per solve: S_l = h_l h_l^T, D_l = delta_l delta_l^T
+            for (int j = 0; j + 1 < L; ++j) {
+              WskpProb u{};
+              u.Ap = cm.ws->hpk[j]; u.Bq = cm.ws->hpk[j]; u.RA = Bp; u.RB = Bp; u.K = m->dims[j]; u.B = B; u.nsplit = 1; u.raw = 1;
+              u.out = hbase + hp->s_off[j];
+              wb.add(u);
+              if (j >= 1) {
+                u.Ap = cm.ws->dpk[j]; u.Bq = cm.ws->dpk[j]; u.K = m->dims[j + 1]; u.out = hbase + hp->d_off[j];
+                wb.add(u);
+              }
+            }
+            sd_in_chain = true;
+          }
+        }
+        wb.launch(st);
+        continue;
+      }
       if (l == L - 2) {   // the head kernel combines this layer's slabs itself (and adds Gf)
         GemmArgs a{};
         a.pr[0] = {m->Rh[l - 1], m->W[l], K, K};
@@ -606,7 +736,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       launch_head_forward(st, Bp, (const float*)m->Rh[l - 1], m->h[l], m->W[l], static_cast<const float*>(dir[2 * l]),
                           static_cast<const float*>(dir[2 * l + 1]), m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr,
                           (const float*)m->delta[l], (const float*)m->mask[l - 1], m->Rd[l - 1], &head_fuse,
-                          cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr, cg ? cm.ws->rz : nullptr, cm.rzx_acc, cm.first);
+                          cg ? cm.ws->partT1 : nullptr, cg ? cm.ws->partT2h : nullptr, cg ? cm.ws->rz : nullptr, cm.rzx_acc, cm.first,
+                          packed ? cm.ws->Rdp[l - 1] : nullptr);
     }
     if (cm.stop_after_head) {   // (projected Neumann's closing pass: Rz(v_K) is in the accumulator now)
       BHG_HIP_CHECK(hipGetLastError());
@@ -615,6 +746,23 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     // backward chain: Rd_{l-1} = mask_{l-1} * (Rd_l W_l + Gb_l); T2_l = 2 <Gb_l, Rh_{l-1}> from the tile epilogue
     for (int l = L - 2; l >= 1; --l) {
       const int K = m->dims[l + 1], N = m->dims[l];
+      if (packed) {
+        WskpBuilder wb;
+        WskpProb q{};
+        q.Ap = cm.ws->Rdp[l]; q.Bq = cm.ws->Wb[l]; q.RA = Bp; q.RB = N; q.K = K; q.B = B; q.nsplit = 1;
+        q.mask = m->mask[l - 1]; q.addend = hbase + hp->g_off[hp->gb[l]]; q.out = m->Rd[l - 1];
+        q.outp = l >= 2 ? cm.ws->Rdp[l - 1] : nullptr;
+        if (cg) { q.rh = m->Rh[l - 1]; q.partT2 = cm.ws->partT2 + cm.ws->t2_off[l]; }
+        wb.add(q);
+        if (gram_in_chain) {   // E_l = delta_l Rd_l^T
+          WskpProb t{};
+          t.Ap = cm.ws->dpk[l]; t.Bq = cm.ws->Rdp[l]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
+          t.nsplit = gram_ksplit(K); t.raw = 1; t.out = hbase + hp->eslab_off[l];
+          wb.add(t);
+        }
+        wb.launch(st);
+        continue;
+      }
       WskArgs w{};
       w.pr[0] = {m->Rd[l], m->W[l], K, N}; w.pairs = 1; w.M = Bp; w.N = N; w.K = K; w.B = B;
       w.mask = m->mask[l - 1]; w.out = m->Rd[l - 1]; w.addend = hbase + hp->g_off[hp->gb[l]];
@@ -831,8 +979,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     // ---- the step length, then every weight-shaped output with the recurrence in its epilogue
     // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
     // (projected Neumann: EVERY iteration — the closing pass needs G(raw) of the last one)
-    const bool proj_iter = hp && cm.proj && (cg ? (!cm.apply_out && !cm.skip_outputs) : true);
-    const bool alpha_alone = dbg(DBG_proj_alpha_alone, 0) != 0;   // A/B
+    const bool alpha_alone = dbg(DBG_proj_alpha_alone, 0) != 0 || gram_in_chain;   // A/B (packed Gram products: no Gram launch to ride in)
     const bool alpha_in_gram = cg && proj_iter && !alpha_alone;
     if (cg && !alpha_in_gram) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
@@ -845,14 +992,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       float* hbase = cm.ws->hoist;
       WskGroupArgs g{};
       int blk = 0;
-      for (int l = 1; l + 1 < L; ++l) {
+      for (int l = 1; l + 1 < L && !gram_in_chain; ++l) {
         const int st_ = gram_ksplit(m->dims[l]), se_ = gram_ksplit(m->dims[l + 1]);
         g.p[g.n] = {m->h[l], m->Rh[l - 1], hbase + hp->tslab_off[l], Bp, Bp, m->dims[l], B, st_};       // T_l = h_l Rh_{l-1}^T
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32) * st_;
         g.p[g.n] = {m->delta[l], m->Rd[l], hbase + hp->eslab_off[l], Bp, Bp, m->dims[l + 1], B, se_};   // E_l = delta_l Rd_l^T
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32) * se_;
       }
-      for (int l = 0; cm.first && l + 1 < L; ++l) {   // once per solve: S_l, D_l
+      for (int l = 0; cm.first && !sd_in_chain && l + 1 < L; ++l) {   // once per solve: S_l, D_l
         g.p[g.n] = {m->h[l], m->h[l], hbase + hp->s_off[l], Bp, Bp, m->dims[l], B, 1};
         g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
         if (l >= 1) {
@@ -863,7 +1010,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const bool full = cg && cm.proj >= 2;   // fully projected CG: r.raw, p.raw, raw.raw from batch-sized arrays (k_proj_step)
       g.blk0[g.n] = blk;
       if (alpha_in_gram) { g.do_alpha = 1; g.alpha = aa; }
-      launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
+      if (blk + (alpha_in_gram ? 1 : 0) > 0) launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
       HoistArgs ga{};
       int gblk = 0;
       const int ntm = Bp / kTM;
@@ -1221,6 +1368,8 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   hipStream_t st = static_cast<hipStream_t>(stream);
   CgCtx c;
   cg_ctx_init(&c, m, x, r, p, starts, chunks_dev, n_chunks, K, cg_alpha, hvp_shift, ws, fws, false);
+  if (c.hoist && packed_chain_on(c.w))
+    if (int rc = pack_operands(m, c.w, st)) return rc;
   for (int k = 0; k < K; ++k)
     if (int rc = cg_iteration(&c, k, 0, nullptr, 1.0, st)) return rc;
   BHG_HIP_CHECK(hipGetLastError());
@@ -1261,6 +1410,8 @@ int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, cons
     BHG_HIP_CHECK(hipGetLastError());
     return BHG_OK;
   }
+  if (k == 0 && phase == BHG_CG_GLOBAL_CHAIN && c.hoist && packed_chain_on(c.w))
+    if (int rc = pack_operands(m, c.w, st)) return rc;
   if (int rc = cg_iteration(&c, k, phase == BHG_CG_GLOBAL_CHAIN ? 1 : 2, php, 1.0 / (double)world, st)) return rc;
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
@@ -1296,6 +1447,8 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     std::lock_guard<std::mutex> lock(g_neumann_mu);
     g_neumann_projected[fws] = proj;
   }
+  if (hplan.ok && K > 0 && packed_chain_on(w))
+    if (int rc = pack_operands(m, w, st)) return rc;
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
     float* vout = (k & 1) ? v0 : v1;

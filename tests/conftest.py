@@ -55,6 +55,11 @@ class _DebugArms:
 
         _native.debug_set(key, None)
 
+    def reset(self):
+        from betty_amd import _native
+
+        _native.debug_reset()
+
 
 @pytest.fixture
 def bhg_debug():

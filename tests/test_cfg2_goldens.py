@@ -87,7 +87,13 @@ def _arms(algo):
                  # the per-iteration Gram products with one workgroup per tile (default: K split over workgroups, slabs summed
                  # by the consumer's loader) and with 256 k per workgroup (eight slabs on the longest)
                  ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
-                 ("fused-gram-256", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KCHUNK": "256"}))]
+                 ("fused-gram-256", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KCHUNK": "256"})),
+                 # round 4: the chain on row-major operands through the LDS-staged form (round 3's product), the Gram products in a
+                 # launch of their own, and the packed K loop with two / four register stages (default: three)
+                 ("fused-unpacked", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_CHAIN": "0"})),
+                 ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
+                 ("fused-packed-d2", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "2"})),
+                 ("fused-packed-d4", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "4"}))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
@@ -95,6 +101,8 @@ def _arms(algo):
         arms += [("fused-classic", dict(hvp="hip", fused=True, wsk=None, hoist="0")),
                  ("fused-hoist-noproj", dict(hvp="hip", fused=True, wsk=None, hoist="2", proj="0")),
                  ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
+                 ("fused-unpacked", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_CHAIN": "0"})),
+                 ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
                  ("autograd", dict(hvp="autograd"))]
     return arms
 
@@ -118,7 +126,7 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
         bhg_debug.delenv("BHG_MLP_PROJ", raising=False)
     else:
         bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
-    for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK"):
+    for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH"):
         bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         bhg_debug.setenv(key, val)

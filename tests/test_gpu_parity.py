@@ -878,8 +878,14 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         # the Neumann default without an accumulator vector: G(v) by recurrence, nothing N-sized after the first iteration,
         # plus the closing half pass that adds Rz(v_K)
         arms["full"] = {"keep": "0"}
+    # round 4: the chain through the constant weights runs on packed operands (k_wskp), the per-iteration Gram products as extra
+    # workgroups of its launches; round 3's forms (LDS-staged row-major chain, Gram launch of its own) stay as arms
+    arms["full-unpacked"] = dict(arms["full"], BHG_PACKED_CHAIN="0")
+    arms["full-gramlaunch"] = dict(arms["full"], BHG_PACKED_GRAM="0")
+    arms["hoisted-unpacked"] = dict(arms["hoisted"], BHG_PACKED_CHAIN="0")
     out = {}
     for name, env in arms.items():
+        bhg_debug.reset()
         for k in ("BHG_MLP_HOIST", "BHG_MLP_PROJ"):
             bhg_debug.delenv(k, raising=False)
         for k, v in env.items():
@@ -889,7 +895,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         h0, p0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations()
         out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
         dh, dp = lib.bhg_mlp_hoist_launches() - h0, lib.bhg_mlp_proj_iterations() - p0
-        want = {"classic": (0, 0), "hoisted": (K, 0), "projected": (1, K - 1), "full": (1, K - 1 if algo == "cg" else K)}[name]
+        want = {"classic": (0, 0), "hoisted": (K, 0), "projected": (1, K - 1), "full": (1, K - 1 if algo == "cg" else K)}[name.split("-")[0]]
         assert (dh, dp) == want, (name, dh, dp, want)
         again = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
         assert all(np.array_equal(u, v) for u, v in zip(again[0], out[name][0])), f"{name}: bit-reproducible"
