@@ -186,11 +186,33 @@ def host_info():
     return model, (len(phys) or None), os.cpu_count()
 
 
-def cpu_baseline(steps, K):
-    """The oracle (line-for-line restatement of the reference's CPU autograd path, pinned
-    bit-for-bit against it in tests/test_oracle.py) timed on this box's host cores."""
+def reference_cg():
+    """(fn, kind, where): the reference's OWN cg (betty/hypergradient/cg.py:8-70) when its package is importable — the staged,
+    git-ignored copy oracle/_ref/betty that `make -C oracle ref` takes from the checkout, or /root/reference itself — else the
+    line-for-line restatement oracle/hypergrad_oracle.py (pinned bit-for-bit against it, tests/test_oracle.py)."""
+    for where in (os.path.join(ROOT, "oracle", "_ref"), "/root/reference"):
+        if os.path.isdir(os.path.join(where, "betty", "hypergradient")):
+            try:
+                if where not in sys.path:
+                    sys.path.insert(0, where)
+                import betty.hypergradient  # noqa: F401
+
+                return sys.modules["betty.hypergradient.cg"].cg, "reference", where
+            except Exception as exc:  # a missing optional dependency of the reference package
+                print(f"bench.py: the reference at {where} does not import ({exc!r}); falling back to the restatement", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hypergrad_oracle as orc
+
+    return orc.cg, "port", os.path.join(ROOT, "oracle", "hypergrad_oracle.py")
+
+
+def cpu_baseline(steps, K):
+    """The reference's own CPU path (unmodified functions; the restatement only when the package is absent) timed on this
+    box's host cores, after the GPU regions."""
+    ref_cg, kind, where = reference_cg()
+
+    class orc:   # noqa: N801 - keeps the call sites below as they were
+        cg = staticmethod(ref_cg)
 
     # torch's CPU kernels stop scaling far below the 256 hardware threads of the GPU box's host (EPYC 9575F:
     # 8 thr 0.68 s, 16 thr 0.55 s, 32 thr 0.98 s, 64 thr 1.8 s, 128 thr 5.3 s per step): time a few thread
@@ -226,11 +248,101 @@ def cpu_baseline(steps, K):
         "host_model": model,
         "physical_cores": phys,
         "logical_cpus": logical,
-        "kind": "port",
+        "kind": kind,
+        "source": ("betty.hypergradient.cg.cg imported from " + where) if kind == "reference" else where,
         "sample": f"{steps} steps of the same workload (cg K={K}, N=10,034,826, batch {BATCH}), median, at the best of "
-        f"8/16/32 torch threads ({used_threads}); oracle/hypergrad_oracle.py on torch CPU fp32, "
-        f"min {times[0]:.3f}s max {times[-1]:.3f}s",
+        f"8/16/32 torch threads ({used_threads}); " + ("the reference's own cg() on torch CPU fp32" if kind == "reference" else
+                                                       "oracle/hypergrad_oracle.py on torch CPU fp32") +
+        f", min {times[0]:.3f}s max {times[-1]:.3f}s",
     }
+
+
+def projected_iteration_work():
+    """What ONE iteration of the projected solvers executes / must move (useful batch rows only), from the shapes alone:
+    flops on the matrix pipe — the chain through the constant weights, the B x B Gram products, the batch-deep G(raw) products —
+    and the analytic minimum of its own traffic: every chain weight read once forward and once backward, the batch-sized
+    recurrence arrays (G(r), G(p) read + written, G(raw) written + read) and the chain's activations written + read once."""
+    d, B = SIZES, BATCH
+    L = len(d) - 1
+    chain = sum(2.0 * B * d[l] * d[l + 1] * 2 for l in range(1, L - 1)) + 2.0 * B * d[-2] * d[-1] * 4
+    gram = sum(2.0 * B * B * (d[l] + d[l + 1]) for l in range(1, L - 1))
+    graw = sum(2.0 * B * B * d[l + 1] * (1 if l == 0 else 2) for l in range(L - 1)) + sum(2.0 * B * B * d[l] * 2 for l in range(1, L - 1))
+    weights = sum(2.0 * 4 * d[l] * d[l + 1] for l in range(1, L - 1))
+    gwidth = sum(d[l + 1] for l in range(L - 1)) + sum(d[l] for l in range(1, L - 1))
+    batch = 6.0 * 4 * B * gwidth + 2.0 * 2 * 4 * B * sum(d[l + 1] for l in range(L - 1))
+    return {"flops": chain + gram + graw, "flops_chain": chain, "flops_gram": gram, "flops_graw": graw,
+            "bytes_min": weights + batch, "bytes_weights": weights, "bytes_batch_sized": batch}
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "cfg2_full.npz")
+RIDGE_WELL = 0.3   # tests/golden/make_cfg2_golden.py
+
+
+def parity_check(args, device, jvp_fn, curr, prev, vector, K):
+    """Ties the number to a checked answer: the very solver that was just timed (same library, same arms) is run once more
+    with sync=False and compared with the committed outputs of the REFERENCE's CPU run (tests/golden/cfg2_full.npz, generated by
+    tests/golden/make_cfg2_golden.py from /root/reference).
+      metric instance (ridge 1e-2, seed 0 — what was timed): the reference's own fp32 answer sits `reference_own_spread` from its
+        fp64 answer (20 un-preconditioned CG iterations on an indefinite-plus-small-ridge Hessian), so rtol 1e-4 is undecidable
+        there; the product is held to 3x that spread against the fp64 truth (the rule of tests/test_cfg2_goldens.py);
+      well-conditioned variant (ridge 0.3, same shapes, same kernels, same K): rtol 1e-4 against the reference's fp32 output,
+        ASSERTED — bench.py refuses to print a throughput when it fails."""
+    import numpy as np
+
+    key = {("cg", 20): "cg20", ("neumann", 10): "neumann10"}.get((args.algo, K))
+    if key is None or args.mode != "replica" or not os.path.exists(GOLDEN):
+        return None
+    gold = np.load(GOLDEN)
+
+    def rel(got, want):
+        g = np.concatenate([t.detach().double().cpu().numpy().ravel() for t in got])
+        w = np.asarray(want, dtype=np.float64).ravel()
+        return float(np.linalg.norm(g - w) / np.linalg.norm(w)) if np.all(np.isfinite(g)) else float("inf")
+
+    out = jvp_fn(vector, curr, prev, False)
+    spread = float(gold[f"metric/0/{key}/ref_spread"])
+    res = {
+        "golden": f"tests/golden/cfg2_full.npz:metric/0/{key} + well/{int(gold['well/seeds'][0])}/{key} (outputs of the reference's "
+                  "own functions on the CPU, tests/golden/make_cfg2_golden.py)",
+        "metric_instance": {
+            "vs_reference_cpu_fp32": rel(out, gold[f"metric/0/{key}/fp32"]),
+            "vs_reference_fp64": rel(out, gold[f"metric/0/{key}/fp64"]),
+            "reference_own_spread": spread,
+        },
+    }
+    mi = res["metric_instance"]
+    mi["ok"] = bool(mi["vs_reference_fp64"] <= max(1e-4, 3.0 * spread))
+    wseed = int(gold["well/seeds"][0])
+    curr_w, prev_w, vector_w = build(device, seed=wseed, K=K, algo=args.algo, ridge=RIDGE_WELL)
+    if args.hvp == "analytic":
+        declare_structure(curr_w, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution)
+    elif args.hvp == "analytic-aten":
+        declare_structure(curr_w, "torch")
+    out_w = jvp_fn(vector_w, curr_w, prev_w, False)
+    rw = rel(out_w, gold[f"well/{wseed}/{key}/fp32"])
+    res["well_conditioned_variant"] = {"ridge": RIDGE_WELL, "seed": wseed, "vs_reference_cpu_fp32": rw,
+                                       "vs_reference_fp64": rel(out_w, gold[f"well/{wseed}/{key}/fp64"]),
+                                       "reference_own_spread": float(gold[f"well/{wseed}/{key}/ref_spread"]),
+                                       "rtol": 1e-4, "ok": bool(rw <= 1e-4)}
+    if not (res["well_conditioned_variant"]["ok"] and mi["ok"]):
+        raise SystemExit("bench.py: the timed solver does not reproduce the reference's CPU output — refusing to report a "
+                         "throughput for a wrong result: " + json.dumps(res))
+    return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU over RCCL."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -263,11 +375,15 @@ def main():
                     help="--hvp autograd only: let PyTorch's TunableOp pick the GEMM kernel of every shape of the double backward "
                          "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's)")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the in-run check of the timed solver against the committed reference-CPU goldens (A/B sweeps)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=INT",
                     help="select a measurement arm of libbhg through bhg_debug_set (the library reads no environment variable); "
                          "repeatable, e.g. --debug packed_chain=0 --debug mlp_proj=0.  Echoed in config.debug_arms")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner on the C-level stdout when a process group
     # comes up, so file descriptor 1 is pointed at stderr for the whole run and the line is written to the real stdout.
@@ -427,6 +543,7 @@ def main():
     finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
     if not finite:
         raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
+    parity = parity_check(args, device, jvp_fn, curr, prev, vector, K) if (world == 1 and not args.no_parity) else None
     out = None
     one_pass_solves = 0
     if args.mode == "global":
@@ -470,6 +587,7 @@ def main():
                     "avg_launch_us_hip_events": ev_us, "launches_timed": ev_n,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "achieved_on_traffic_GBps": (traffic / (us * 1e-6) / 1e9) if traffic else None,
+                    "own": None,
                     "composite_recurrence_plus_hvp_weights": {"algorithmic_bytes": comp, "achieved": comp / (us * 1e-6) / 1e9,
                                                               "frac": comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                                               "note": "round-2's figure (28N + 20N); the fused path neither writes nor re-reads H*p, "
@@ -477,6 +595,21 @@ def main():
                     "note": mall_note + "; `achieved` is SURVEY 8(d)'s yardstick — the 28*N bytes the REFERENCE's recurrence moves per "
                             "iteration divided by this solver's iteration time; the projected solver itself moves far fewer bytes (`traffic`), "
                             "its iteration is a chain of 8 dependent launches on batch-sized data plus one pass over the constant weights"}
+            if (solver_form or "").startswith(("fully", "projected")):
+                # the solver's OWN roofline next to the 8(d) yardstick: what it executes and must move, not what the reference moves
+                w = projected_iteration_work()
+                own_bytes = traffic if traffic else w["bytes_min"]
+                floor_us = 1e6 * max(own_bytes / (HBM_PEAK_GBPS * 1e9), w["flops"] / 157.3e12)
+                roof["own"] = {
+                    "bytes_min_analytic": w["bytes_min"], "bytes_weights": w["bytes_weights"], "bytes_batch_sized": w["bytes_batch_sized"],
+                    "traffic_measured": traffic, "flops_executed": w["flops"],
+                    "floor_us": floor_us, "floor_uses": "measured traffic" if traffic else "analytic minimum traffic",
+                    "frac_of_own_floor": floor_us / us,
+                    "frac_hbm_on_own_bytes": own_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "frac_mfma_on_executed_flops": w["flops"] / (us * 1e-6) / 157.3e12,
+                    "note": "floor_us = max(own bytes / 8 TB/s, executed flops / 157.3 TFLOP/s fp32 MFMA); the iteration is a chain of "
+                            "dependent launches on batch-sized data, bound by neither roof — this fraction says how far from them",
+                }
         elif ("cg_step" if args.algo == "cg" else "neumann_step") in spans:
             us, n = spans["cg_step" if args.algo == "cg" else "neumann_step"]
             roof = {
@@ -515,9 +648,16 @@ def main():
                            % ((chain + gram + graw) / 1e9, chain / 1e9, gram / 1e9, graw / 1e9)
                            if (solver_form or "").startswith("fully") else
                            "; fused: its output kernels also carry the recurrence's r/x (or v/p) update" if fused else ""),
-                "executed_flops_per_iteration": (chain + gram + graw) if (solver_form or "").startswith("fully") else None,
-                "achieved": flops / (us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": flops / (us * 1e-6) / 1e12 / 157.3, "flops_per_call": flops, "avg_call_us": us, "avg_call_us_source": src,
+                "executed_flops_per_iteration": (chain + gram + graw) if (solver_form or "").startswith(("fully", "projected")) else None,
+                # achieved / frac count what the matrix pipe EXECUTES; the reference HVP's flops over this solver's time is a
+                # speed-up yardstick, kept under its own name
+                "achieved": ((chain + gram + graw) if (solver_form or "").startswith(("fully", "projected")) else flops) / (us * 1e-6) / 1e12,
+                "peak": 157.3, "unit": "TFLOP/s",
+                "frac": ((chain + gram + graw) if (solver_form or "").startswith(("fully", "projected")) else flops) / (us * 1e-6) / 1e12 / 157.3,
+                "yardstick_reference_hvp": {"flops": flops, "over_this_solvers_time_TFLOPs": flops / (us * 1e-6) / 1e12,
+                                            "frac_of_peak": flops / (us * 1e-6) / 1e12 / 157.3,
+                                            "note": "the reference's HVP flops divided by this solver's time: not a roofline"},
+                "flops_per_call": flops, "avg_call_us": us, "avg_call_us_source": src,
                 "avg_call_us_hip_events": spans["hvp"][0], "calls_timed": n,
             }
         K_eff = 0 if args.algo == "darts" else K
@@ -566,6 +706,7 @@ def main():
                 "debug_arms": args.debug or None,
                 "lib_sha256": lib_sha256()[:16],
             },
+            "parity": parity,
             "roofline": roof,
             "hvp_roofline": hvp_roof,
             "value_with_kernel_timing": ((world if args.mode == "replica" else 1) * args.steps / elapsed_timed) if elapsed_timed else None,

@@ -152,9 +152,17 @@ struct WskpBuilder {
     if (!g.n) return;
     g.blk0[g.n] = blk;
     const int d = dbg(DBG_packed_depth, 3);   // register stages of the K loop (A/B)
-    if (d == 2) hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
-    else if (d == 4) hipLaunchKernelGGL(k_wskp<4>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
-    else hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskWaves), 0, st, g);
+    if (g.n <= 2) {   // the per-iteration launches: both descriptors as named kernel arguments (no dependent scalar loads)
+      Wskp2Args g2{};
+      g2.a = g.p[0];
+      g2.b = g.n == 2 ? g.p[1] : g.p[0];
+      g2.na = g.n == 2 ? g.blk0[1] : blk;
+      if (d == 2) hipLaunchKernelGGL(k_wskp2<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
+      else if (d == 4) hipLaunchKernelGGL(k_wskp2<4>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
+      else hipLaunchKernelGGL(k_wskp2<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
+    } else if (d == 2) hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
+    else if (d == 4) hipLaunchKernelGGL(k_wskp<4>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
+    else hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
     g = WskpArgs{};
     blk = 0;
   }
@@ -303,6 +311,15 @@ inline int gram_ksplit(int K) {
   const int per = c >= 32 ? c : 512;
   const int s = K / per;
   return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
+}
+// E_1 = delta_1 Rd_1^T rides in the LAST chain launch, whose tiles already fill the chip: split finer, so that its workgroups are
+// short guests on many CUs instead of long ones on a few (probe: 48 workgroups of 512 k stretch the launch by 3.8 us)
+inline int gram_esplit(int l, int K, bool in_chain) {
+  if (!(in_chain && l == 1)) return gram_ksplit(K);
+  int s = dbg(DBG_gram_e1_split, 3);
+  if (s > kGramSplitMax) s = kGramSplitMax;
+  if (s > K / 32) s = K / 32;
+  return s < 1 ? 1 : s;
 }
 struct HoistPlan {
   bool ok;
@@ -757,7 +774,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (gram_in_chain) {   // E_l = delta_l Rd_l^T
           WskpProb t{};
           t.Ap = cm.ws->dpk[l]; t.Bq = cm.ws->Rdp[l]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
-          t.nsplit = gram_ksplit(K); t.raw = 1; t.out = hbase + hp->eslab_off[l];
+          t.nsplit = gram_esplit(l, K, true); t.raw = 1; t.out = hbase + hp->eslab_off[l];
           wb.add(t);
         }
         wb.launch(st);
@@ -980,14 +997,19 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     // projected CG, not the last iteration: the step length rides in the launch of this iteration's Gram products
     // (projected Neumann: EVERY iteration — the closing pass needs G(raw) of the last one)
     const bool alpha_alone = dbg(DBG_proj_alpha_alone, 0) != 0 || gram_in_chain;   // A/B (packed Gram products: no Gram launch to ride in)
+    const bool small_alone = dbg(DBG_proj_small_alone, 0) != 0;   // A/B
+    const bool small_in_graw = proj_iter && (cm.proj >= 2 || !cg) && !small_alone;
+    // fully projected CG with the Gram products in the chain launches: nothing is left between the chain and the G(raw) launch but
+    // the step length — and its only readers inside that launch are the small slices' blocks, which recompute it from the same
+    // partials (alpha_compute, bit-identical in every block); the first of them publishes it and completes Rz(x)
+    const bool alpha_in_hoist = cg && proj_iter && cm.proj >= 2 && small_in_graw && gram_in_chain && cm.gphase == 0 &&
+                                dbg(DBG_alpha_in_hoist, 1) != 0;
     const bool alpha_in_gram = cg && proj_iter && !alpha_alone;
-    if (cg && !alpha_in_gram) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
+    if (cg && !alpha_in_gram && !alpha_in_hoist) hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kThreads), 0, st, aa);
     if (cg && cm.skip_outputs) {   // last iteration of a solve without a solution vector: r', p' and x are all dead
       BHG_HIP_CHECK(hipGetLastError());
       return BHG_OK;
     }
-    const bool small_alone = dbg(DBG_proj_small_alone, 0) != 0;   // A/B
-    const bool small_in_graw = proj_iter && (cm.proj >= 2 || !cg) && !small_alone;
     if (proj_iter) {   // projected CG: G(raw) of this iteration for the next one's recurrences
       float* hbase = cm.ws->hoist;
       WskGroupArgs g{};
@@ -1021,7 +1043,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           q.A = hbase + hp->s_off[l]; q.Bm = m->Rd[l];
           if (l >= 1) { q.A2 = hbase + hp->tslab_off[l]; q.B2m = m->delta[l]; q.a2_slabs = gram_ksplit(m->dims[l]); }
         } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
-          q.A = hbase + hp->eslab_off[l]; q.Bm = m->h[l]; q.a_slabs = gram_ksplit(m->dims[l + 1]);
+          q.A = hbase + hp->eslab_off[l]; q.Bm = m->h[l]; q.a_slabs = gram_esplit(l, m->dims[l + 1], gram_in_chain);
           q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
         }
         q.slabs = hbase + hp->graw_off[i];
@@ -1061,6 +1083,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         so.bf = bias_fz;
         so.bias_blocks = bias_blk;
         ga.small_blocks = so.head_blocks + bias_blk;
+        if (alpha_in_hoist) { ga.do_alpha = 1; ga.alpha = aa; }
       }
       if (cg) hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
       else hipLaunchKernelGGL(k_hoist<FUSE_NEUMANN>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);

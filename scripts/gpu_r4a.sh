@@ -2,6 +2,7 @@
 # round 4, call a: packed chain (k_wskp) — parity of every arm, same-box A/B of the packed / unpacked forms, one timeline
 set -u
 mkdir -p gpurun_out/r4a; export TMPDIR=/tmp
+[ -x build_probes/chain_probe ] && timeout 120 ./build_probes/chain_probe > gpurun_out/r4a/chain_probe.txt 2>&1
 O=gpurun_out/r4a
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "hoisted_and_projected or projected_solvers_edge or fused_solver_matches or without_a_solution or wsk" > $O/pytest_subset.log 2>&1; echo "pytest subset rc=$?"; grep -vE "^Extension|Warning|warn" $O/pytest_subset.log | tail -30
 timeout 900 python -m pytest tests/test_cfg2_goldens.py tests/test_gpu_global.py -m gpu -q -x -s > $O/pytest_goldens.log 2>&1; echo "pytest goldens rc=$?"; grep -vE "^Extension|Warning|warn" $O/pytest_goldens.log | tail -12
@@ -14,6 +15,9 @@ run gram_launch --debug packed_gram=0
 run depth2 --debug packed_depth=2
 run depth4 --debug packed_depth=4
 run default_again
+run alpha_launch --debug alpha_in_hoist=0
+run e1_split8 --debug gram_e1_split=8
+run e1_split2 --debug gram_e1_split=2
 run neumann --algo neumann --cg-iters 10
 run neumann_unpacked --algo neumann --cg-iters 10 --debug packed_chain=0
 for arm in default unpacked; do
