@@ -42,7 +42,7 @@ enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 
   X(mlp_hoist) X(hoist_wgs) X(proj_step_alone) X(mlp_no_side) X(mlp_no_fuse) X(mlp_no_outer_all) X(neumann_side)             \
   X(hoist_staged_mink) X(proj_alpha_alone) X(proj_small_alone) X(outer_order_by_work) X(outer_no_pre) X(outer_stagger)       \
   X(mlp_no_fused_solve) X(cg_eager_p) X(cg_x_every_iter) X(neumann_p_every_iter) X(head_no_prefetch) X(cg_spin_limit)        \
-  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(gram_e1_split) X(alpha_in_hoist)
+  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(gram_e1_split) X(alpha_in_hoist) X(graw_v2) X(gram_max_split) X(wskp_ragged)
 enum DbgKey : int {
 #define BHG_DBG_ENUM(n) DBG_##n,
   BHG_DBG_KEYS(BHG_DBG_ENUM)
@@ -53,6 +53,25 @@ constexpr int kDbgUnset = INT32_MIN;
 extern int g_dbg[DBG_COUNT];
 inline bool dbg_is_set(DbgKey k) { return g_dbg[k] != kDbgUnset; }
 inline int dbg(DbgKey k, int dflt) { return g_dbg[k] == kDbgUnset ? dflt : g_dbg[k]; }
+
+// ---- in-kernel time stamps (measurement builds only: make stamps -> libbhg_stamps.so, -DBHG_STAMPS) ------------------------------
+// BHG_STAMP(kernel_id, slot): thread 0 of the workgroup stores s_memrealtime (100 MHz, one clock for the whole chip) at
+// [kernel_id][blockIdx.x][slot].  The shipped library compiles every stamp to nothing.
+constexpr int kStampKernels = 4, kStampBlocks = 4096, kStampSlots = 8;
+#ifdef BHG_STAMPS
+#ifdef __HIPCC__
+// (d_stamps is defined by the translation unit that stamps: bhg_mlp.hip)
+#define BHG_STAMP(kid, slot)                                                                                            \
+  do {                                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < ::bhg::kStampBlocks) {                                                         \
+      unsigned long long* sp_ = ::bhg::d_stamps;                                                                        \
+      if (sp_) sp_[((kid) * ::bhg::kStampBlocks + blockIdx.x) * ::bhg::kStampSlots + (slot)] = wall_clock64();          \
+    }                                                                                                                   \
+  } while (0)
+#endif
+#else
+#define BHG_STAMP(kid, slot) do { } while (0)
+#endif
 
 // ---- error plumbing -------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -28,6 +28,10 @@
 
 #include "bhg_common.hpp"
 
+#ifdef BHG_STAMPS
+namespace bhg { __device__ unsigned long long* d_stamps = nullptr; }
+#endif
+
 namespace bhg {
 namespace {
 #include "mlp/gemm.inc"   // tile constants, GemmArgs, LDS tile loaders, gemm_body / k_gemm (split-K skinny GEMM on v_mfma_f32_32x32x2_f32)
@@ -138,14 +142,28 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
 
 // Grouped launch on packed operands (wskp.inc).  Block tables are rounded up to multiples of 8 so that a problem's tile t keeps
 // t % 8 == blockIdx.x % 8 (the XCD it runs on).
+// Row tiling of one problem (see wskp_body): chain products cover the B valid rows with 32-row tiles and, over a remainder of at
+// most 16 rows, 16 x 64 tiles; K-split / raw problems keep every row tile (their consumers read all RA rows or none of the padding).
+inline void wskp_tiling(WskpProb* q) {
+  q->nfull = q->RA / 32;
+  q->nstrip = 0;
+  if (dbg(DBG_wskp_ragged, 1) == 0 || q->raw || q->nsplit != 1 || q->RB % 64 != 0) return;
+  int nf = q->B / 32, rem = q->B % 32;
+  if (rem > 16) { ++nf; rem = 0; }
+  if (nf == 0) return;   // (a batch of <= 16 rows: one row of full tiles)
+  q->nfull = nf;
+  q->nstrip = rem > 0 ? q->RB / 64 : 0;
+}
 struct WskpBuilder {
   WskpArgs g{};
   int blk = 0;
-  bool add(const WskpProb& q) {
+  bool add(const WskpProb& q_in) {
     if (g.n >= kWskpMax) return false;
+    WskpProb q = q_in;
+    wskp_tiling(&q);
     g.p[g.n] = q;
     g.blk0[g.n++] = blk;
-    blk += (((q.RA / 32) * (q.RB / 32) * q.nsplit) + 7) & ~7;
+    blk += (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
     return true;
   }
   void launch(hipStream_t st) {
@@ -244,6 +262,8 @@ int pick_splits(int tiles, int K, int pairs) {
 
 #include "mlp/proj.inc"   // hoisted direction products (k_hoist, k_hoist_reduce) and the projected solvers' kernels (k_proj_scalars / _update / _step)
 
+#include "mlp/graw.inc"   // round 4: the closing launch of a projected iteration on packed Gram matrices (k_graw)
+
 // ---- per-device side stream + events -------------------------------------------------------------------------------
 struct SideState {
   hipStream_t side;
@@ -312,6 +332,16 @@ inline int gram_ksplit(int K) {
   const int s = K / per;
   return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
 }
+// CUs of the current device (per-device cache; 256 on an MI355X): grouped launches are sized to ONE resident round of workgroups
+int chip_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  if (cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  return cus[dev] = n;
+}
 // E_1 = delta_1 Rd_1^T rides in the LAST chain launch, whose tiles already fill the chip: split finer, so that its workgroups are
 // short guests on many CUs instead of long ones on a few (probe: 48 workgroups of 512 k stretch the launch by 3.8 us)
 inline int gram_esplit(int l, int K, bool in_chain) {
@@ -331,6 +361,9 @@ struct HoistPlan {
   size_t s_off[BHG_MLP_MAX_LAYERS], d_off[BHG_MLP_MAX_LAYERS];   // B x B Gram matrices, constant over a solve
   int dot_blocks, raw_blocks;   // fully projected CG: dot blocks of r.raw / p.raw; tiles of the G(raw) launch (raw.raw partials)
   size_t tslab_off[BHG_MLP_MAX_LAYERS], eslab_off[BHG_MLP_MAX_LAYERS];   // K-split slabs of T_l / E_l (kGramSplitMax each)
+  size_t sp_off[BHG_MLP_MAX_LAYERS], dp_off[BHG_MLP_MAX_LAYERS];         // the same four, PACKED ([Bp/16][Bp][16]: k_graw's M-side
+  size_t tslabp_off[BHG_MLP_MAX_LAYERS], eslabp_off[BHG_MLP_MAX_LAYERS]; // operands; two slabs at most)
+  int graw_tiles;                                                        // 64 x 32 tiles of the G(raw) launch (k_graw)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
@@ -396,6 +429,16 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
       hp->eslab_off[l] = off; off += (size_t)kGramSplitMax * Bp * Bp;
     }
   }
+  for (int l = 0; l + 1 < L; ++l) {
+    hp->sp_off[l] = off; off += (size_t)Bp * Bp;
+    if (l >= 1) {
+      hp->dp_off[l] = off; off += (size_t)Bp * Bp;
+      hp->tslabp_off[l] = off; off += (size_t)2 * Bp * Bp;
+      hp->eslabp_off[l] = off; off += (size_t)2 * Bp * Bp;
+    }
+  }
+  hp->graw_tiles = 0;
+  for (int i = 0; i < n; ++i) hp->graw_tiles += (Bp / 64) * (hp->N[i] / 32);
   hp->blk0[n] = blk;
   hp->floats = off;
   hp->ok = true;
@@ -427,6 +470,7 @@ struct FusedWs {
   float* hoist;                     // slabs + G arrays of the hoisted direction products (HoistPlan offsets)
   double* part_dot; double* pscal;  // fully projected CG: [2][dot_blocks] partials of r.raw / p.raw; {rr, rp, pp} over the MFMA layers
   double* part_raw;                 // fully projected CG: [raw_blocks] partials of raw.raw (tiles of the G(raw) launch)
+  double* part_graw;                // k_graw: [3][graw_tiles] partials of r.raw, p.raw, raw.raw
   float* pb0[2];                    // fully projected CG: the first bias's slice of the direction, two slots by iteration parity (k_proj_step)
   // packed operands of the chain and of the Gram products (wskp.inc); NULL when the hoisted forms do not apply
   float* Wf[BHG_MLP_MAX_LAYERS];    // W_l as the N-side operand of the forward chain   [d_l / 16][d_{l+1}][16],  l = 1 .. L-2
@@ -461,6 +505,7 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->hoist = static_cast<float*>(take(sizeof(float) * (hp.ok ? hp.floats : 1)));
   w->part_dot = static_cast<double*>(take(sizeof(double) * 2 * (hp.ok ? hp.dot_blocks : 1)));
   w->part_raw = static_cast<double*>(take(sizeof(double) * (hp.ok ? hp.raw_blocks : 1)));
+  w->part_graw = static_cast<double*>(take(sizeof(double) * 3 * (hp.ok ? hp.graw_tiles : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   for (int i = 0; i < 2; ++i) w->pb0[i] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[1]));
   if (hp.ok) {
@@ -611,6 +656,13 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   const bool packed = hp && packed_chain_on(*cm.ws);
   const bool gram_in_chain = packed && proj_iter && !cm.stop_after_head && dbg(DBG_packed_gram, 1) != 0;
   bool sd_in_chain = false;   // first iteration: S_l, D_l rode in the first chain launch as well
+  // k_graw (graw.inc) closes the iteration when the Gram matrices arrive packed; its loaders sum two K-split slabs at most.
+  // graw_single: what the NEXT iteration's recurrences are told about the layout of G(raw) (one slab per product, not one per pair)
+  const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0;
+  const bool graw2 = gram_in_chain && graw_single;
+  const int gram_cap = graw2 ? 2 : dbg(DBG_gram_max_split, kGramSplitMax);
+  auto tsplit = [&](int K) { const int s = gram_ksplit(K); return s < gram_cap ? s : gram_cap; };
+  auto esplit = [&](int l, int K) { const int s = gram_esplit(l, K, gram_in_chain); return s < gram_cap ? s : gram_cap; };
   if (hp && do_chain) {
     float* hbase = cm.ws->hoist;
     HoistArgs ha{};
@@ -655,7 +707,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         ProjProb& q = pa.p[i];
         q.Gr = hbase + (cg ? hp->gr_off[i] : hp->g_off[i]); q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
         // (products with two operand pairs leave one slab per pair, see the G(raw) launch)
-        if (graw_split() && !(hp->bwd[i] == 0 && hp->layer[i] == 0)) q.Graw2 = q.Graw + (size_t)Bp * hp->N[i];
+        if (!graw_single && graw_split() && !(hp->bwd[i] == 0 && hp->layer[i] == 0)) q.Graw2 = q.Graw + (size_t)Bp * hp->N[i];
         if (!hp->bwd[i] && hp->layer[i] == 0) {
           q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0];
           q.outp = packed ? cm.ws->Rhp[0] : nullptr;
@@ -670,6 +722,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         ProjScalArgs& sa = g.sa;
         sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
         sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
+        if (graw_single) {   // the last iteration closed with k_graw: three partials per tile workgroup
+          sa.part_dot = cm.ws->part_graw; sa.dot_blocks = hp->graw_tiles;
+          sa.part_raw = cm.ws->part_graw + 2 * (size_t)hp->graw_tiles; sa.raw_blocks = hp->graw_tiles;
+        }
         sa.part = cm.beta->part; sa.part_stride = cm.ws->nRR;   // the last iteration's epilogue partials (= its partRR_new)
         sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blocks(m);
         sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
@@ -698,7 +754,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         WskpProb q{};
         q.Ap = cm.ws->Rhp[l - 1]; q.Bq = cm.ws->Wf[l]; q.RA = Bp; q.RB = N; q.K = K; q.B = B; q.nsplit = 1;
         if (l == L - 2) {   // raw K-split slabs: the head kernel combines them itself (adds Gf and c_l, applies the mask)
-          int sp = (240 + (Bp / 32) * (N / 32) - 1) / ((Bp / 32) * (N / 32));   // ~ one workgroup per CU
+          // one workgroup per CU including the Gram product riding along: a second round of workgroups would start when the
+          // first ends (probe: 240 + 32 workgroups 9.1 us, 192 + 48 5.4 us)
+          const int riders = gram_in_chain ? (Bp / 32) * (Bp / 32) * tsplit(K) : 0;
+          const int tiles_l = (Bp / 32) * (N / 32);
+          int sp = (chip_cus() - riders) / tiles_l;
           const int cap = pick_splits((N + tn - 1) / tn, K, 1);                  // what m->partial was sized for
           if (sp > cap) sp = cap;
           if (sp > K / 64) sp = K / 64;
@@ -713,23 +773,26 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (gram_in_chain) {   // T_l = h_l Rh_{l-1}^T: K-split slabs, summed by the consumer (the G(raw) products)
           WskpProb t{};
           t.Ap = cm.ws->hpk[l]; t.Bq = cm.ws->Rhp[l - 1]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
-          t.nsplit = gram_ksplit(K); t.raw = 1; t.out = hbase + hp->tslab_off[l];
+          t.nsplit = tsplit(K); t.raw = 1; t.out = hbase + hp->tslab_off[l]; t.outp = graw2 ? hbase + hp->tslabp_off[l] : nullptr;
           wb.add(t);
-          if (cm.first && l == 1 && 2 + (L - 1) + (L - 2) <= kWskpMax) {   // once per solve: S_l = h_l h_l^T, D_l = delta_l delta_l^T
-            for (int j = 0; j + 1 < L; ++j) {
-              WskpProb u{};
-              u.Ap = cm.ws->hpk[j]; u.Bq = cm.ws->hpk[j]; u.RA = Bp; u.RB = Bp; u.K = m->dims[j]; u.B = B; u.nsplit = 1; u.raw = 1;
-              u.out = hbase + hp->s_off[j];
-              wb.add(u);
-              if (j >= 1) {
-                u.Ap = cm.ws->dpk[j]; u.Bq = cm.ws->dpk[j]; u.K = m->dims[j + 1]; u.out = hbase + hp->d_off[j];
-                wb.add(u);
-              }
-            }
-            sd_in_chain = true;
-          }
         }
         wb.launch(st);
+        if (gram_in_chain && cm.first && l == 1) {   // once per solve: S_l = h_l h_l^T, D_l = delta_l delta_l^T (launches of their own:
+          WskpBuilder sb;                            // beside the first chain product they would stretch it — K up to d_0)
+          for (int j = 0; j + 1 < L; ++j) {
+            WskpProb u{};
+            u.Ap = cm.ws->hpk[j]; u.Bq = cm.ws->hpk[j]; u.RA = Bp; u.RB = Bp; u.K = m->dims[j]; u.B = B; u.raw = 1;
+            u.nsplit = 1;   // (constant over the solve: one slab)
+            u.out = hbase + hp->s_off[j]; u.outp = hbase + hp->sp_off[j];
+            if (!sb.add(u)) { sb.launch(st); sb.add(u); }
+            if (j >= 1) {
+              u.Ap = cm.ws->dpk[j]; u.Bq = cm.ws->dpk[j]; u.K = m->dims[j + 1]; u.out = hbase + hp->d_off[j]; u.outp = hbase + hp->dp_off[j];
+              if (!sb.add(u)) { sb.launch(st); sb.add(u); }
+            }
+          }
+          sb.launch(st);
+          sd_in_chain = true;
+        }
         continue;
       }
       if (l == L - 2) {   // the head kernel combines this layer's slabs itself (and adds Gf)
@@ -774,7 +837,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (gram_in_chain) {   // E_l = delta_l Rd_l^T
           WskpProb t{};
           t.Ap = cm.ws->dpk[l]; t.Bq = cm.ws->Rdp[l]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
-          t.nsplit = gram_esplit(l, K, true); t.raw = 1; t.out = hbase + hp->eslab_off[l];
+          t.nsplit = esplit(l, K); t.raw = 1; t.out = hbase + hp->eslab_off[l]; t.outp = graw2 ? hbase + hp->eslabp_off[l] : nullptr;
           wb.add(t);
         }
         wb.launch(st);
@@ -1033,41 +1096,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       g.blk0[g.n] = blk;
       if (alpha_in_gram) { g.do_alpha = 1; g.alpha = aa; }
       if (blk + (alpha_in_gram ? 1 : 0) > 0) launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
-      HoistArgs ga{};
-      int gblk = 0;
-      const int ntm = Bp / kTM;
-      for (int i = 0; i < hp->n; ++i) {
-        const int l = hp->layer[i];
-        HoistProb& q = ga.p[i];
-        if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
-          q.A = hbase + hp->s_off[l]; q.Bm = m->Rd[l];
-          if (l >= 1) { q.A2 = hbase + hp->tslab_off[l]; q.B2m = m->delta[l]; q.a2_slabs = gram_ksplit(m->dims[l]); }
-        } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
-          q.A = hbase + hp->eslab_off[l]; q.Bm = m->h[l]; q.a_slabs = gram_esplit(l, m->dims[l + 1], gram_in_chain);
-          q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
-        }
-        q.slabs = hbase + hp->graw_off[i];
-        q.a_slab_stride = Bp * Bp;
-        if (full) q.X = hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l];   // raw.raw's share: <X, G(raw)>
-        q.K = Bp; q.N = hp->N[i]; q.splits = (q.A2 && graw_split()) ? 2 : 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
-        ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm * q.splits;
-      }
-      ga.blk0[hp->n] = gblk;
-      ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
-      if (full) {   // the projected inner products r.raw, p.raw ride behind the tiles
-        int dblk = 0, nd = 0;
-        for (int i = 0; i < hp->n; ++i) {
-          const int l = hp->layer[i];
-          ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i]};
-          ga.dblk0[nd++] = dblk; dblk += dot_blocks_of(Bp * (hp->N[i] / 4));
-        }
-        ga.dblk0[nd] = dblk;
-        ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot; ga.part_raw = cm.ws->part_raw;
-        BHG_REQUIRE(gblk == graw_blocks(hp, Bp), "tile count of the G(raw) launch and of its raw.raw partials disagree");
-        BHG_REQUIRE(dblk == hp->dot_blocks, "dot block count of the plan and of the launch disagree");
-      }
-      if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of this launch
-        SmallOutArgs& so = ga.so;
+      SmallOutArgs so{};
+      int small_blocks = 0;
+      if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of the closing launch
         so.head = head_outer_args(L - 1);
         so.hf = fuse_at(2 * (L - 1), part_base_w[L - 1]);
         so.head_gx = (so.head.N + 63) / 64;
@@ -1082,10 +1113,77 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         so.ba.d0 = ba.d0;
         so.bf = bias_fz;
         so.bias_blocks = bias_blk;
-        ga.small_blocks = so.head_blocks + bias_blk;
+        small_blocks = so.head_blocks + bias_blk;
+      }
+      if (graw2) {   // round 4: packed Gram matrices -> k_graw (64 x 32 tiles, inner products in the tile epilogue, one slab per product)
+        GrawArgs ka{};
+        int gb = small_blocks;   // (the small slices' blocks lead the grid)
+        for (int i = 0; i < hp->n; ++i) {
+          const int l = hp->layer[i];
+          GrawProb& q = ka.p[i];
+          if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
+            q.A1 = hbase + hp->sp_off[l]; q.B1 = m->Rd[l]; q.n1 = 1;
+            if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l]; q.B2 = m->delta[l]; q.n2 = tsplit(m->dims[l]); }
+          } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
+            q.A1 = hbase + hp->eslabp_off[l]; q.B1 = m->h[l]; q.n1 = esplit(l, m->dims[l + 1]);
+            q.A2 = hbase + hp->dp_off[l]; q.B2 = m->Rh[l - 1]; q.n2 = 1;
+          }
+          if (full) {
+            q.X = hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l];
+            q.Gr = hbase + hp->gr_off[i]; q.Gp = hbase + hp->g_off[i];
+          }
+          q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
+          ka.blk0[i] = gb; gb += (Bp / 64) * (hp->N[i] / 32);
+        }
+        ka.blk0[hp->n] = gb;
+        BHG_REQUIRE(gb - small_blocks == hp->graw_tiles, "tile count of k_graw and of the plan disagree");
+        ka.n = hp->n; ka.Bp = Bp; ka.B = B; ka.slab_stride = Bp * Bp;
+        ka.part = cm.ws->part_graw; ka.npart = hp->graw_tiles;
+        ka.small_blocks = small_blocks; ka.so = so;
+        if (alpha_in_hoist) { ka.do_alpha = 1; ka.alpha = aa; }
+        if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        else hipLaunchKernelGGL(k_graw<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+      }
+      HoistArgs ga{};
+      int gblk = 0;
+      const int ntm = Bp / kTM;
+      for (int i = 0; i < hp->n && !graw2; ++i) {
+        const int l = hp->layer[i];
+        HoistProb& q = ga.p[i];
+        if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
+          q.A = hbase + hp->s_off[l]; q.Bm = m->Rd[l];
+          if (l >= 1) { q.A2 = hbase + hp->tslab_off[l]; q.B2m = m->delta[l]; q.a2_slabs = gram_in_chain ? tsplit(m->dims[l]) : gram_ksplit(m->dims[l]); }
+        } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
+          q.A = hbase + hp->eslab_off[l]; q.Bm = m->h[l]; q.a_slabs = gram_in_chain ? esplit(l, m->dims[l + 1]) : gram_ksplit(m->dims[l + 1]);
+          q.A2 = hbase + hp->d_off[l]; q.B2m = m->Rh[l - 1];
+        }
+        q.slabs = hbase + hp->graw_off[i];
+        q.a_slab_stride = Bp * Bp;
+        if (full) q.X = hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l];   // raw.raw's share: <X, G(raw)>
+        q.K = Bp; q.N = hp->N[i]; q.splits = (q.A2 && graw_split()) ? 2 : 1; q.rc = 1; q.lda = Bp; q.ldb = hp->N[i];
+        ga.blk0[i] = gblk; gblk += (hp->N[i] / 32) * ntm * q.splits;
+      }
+      ga.blk0[hp->n] = gblk;
+      ga.n = hp->n; ga.Bp = Bp; ga.gemm_blocks = gblk; ga.do_beta = 0;
+      if (full && !graw2) {   // the projected inner products r.raw, p.raw ride behind the tiles
+        int dblk = 0, nd = 0;
+        for (int i = 0; i < hp->n; ++i) {
+          const int l = hp->layer[i];
+          ga.dp[nd] = {hbase + hp->gr_off[i], hbase + hp->g_off[i], hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l], hp->N[i]};
+          ga.dblk0[nd++] = dblk; dblk += dot_blocks_of(Bp * (hp->N[i] / 4));
+        }
+        ga.dblk0[nd] = dblk;
+        ga.nd = nd; ga.dot_blocks = dblk; ga.B = B; ga.part_dot = cm.ws->part_dot; ga.part_raw = cm.ws->part_raw;
+        BHG_REQUIRE(gblk == graw_blocks(hp, Bp), "tile count of the G(raw) launch and of its raw.raw partials disagree");
+        BHG_REQUIRE(dblk == hp->dot_blocks, "dot block count of the plan and of the launch disagree");
+      }
+      if (small_in_graw) {
+        ga.so = so;
+        ga.small_blocks = small_blocks;
         if (alpha_in_hoist) { ga.do_alpha = 1; ga.alpha = aa; }
       }
-      if (cg) hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
+      if (graw2) {
+      } else if (cg) hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
       else hipLaunchKernelGGL(k_hoist<FUSE_NEUMANN>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
     }
     // one launch for all outputs when every MFMA layer is all-interior
@@ -1147,6 +1245,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ProjScalArgs sa{};
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
       sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
+      if (graw_single) {
+        sa.part_dot = cm.ws->part_graw; sa.dot_blocks = hp->graw_tiles;
+        sa.part_raw = cm.ws->part_graw + 2 * (size_t)hp->graw_tiles; sa.raw_blocks = hp->graw_tiles;
+      }
       sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
       sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;
       sa.r_small = cm.beta->r; sa.p_small = cm.beta->p; sa.snt = cm.beta->nt;
@@ -1633,5 +1735,26 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }
+
+#ifdef BHG_STAMPS
+static unsigned long long* g_stamps_dev = nullptr;
+int bhg_debug_stamps_enable(int on) {
+  const size_t bytes = sizeof(unsigned long long) * bhg::kStampKernels * bhg::kStampBlocks * bhg::kStampSlots;
+  if (on && !g_stamps_dev) {
+    BHG_HIP_CHECK(hipMalloc(&g_stamps_dev, bytes));
+  }
+  if (g_stamps_dev) BHG_HIP_CHECK(hipMemset(g_stamps_dev, 0, bytes));
+  unsigned long long* p = on ? g_stamps_dev : nullptr;
+  BHG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bhg::d_stamps), &p, sizeof(p)));
+  return BHG_OK;
+}
+int bhg_debug_stamps_read(unsigned long long* host, size_t count) {
+  BHG_REQUIRE(g_stamps_dev && host, "stamps are not enabled");
+  const size_t total = (size_t)bhg::kStampKernels * bhg::kStampBlocks * bhg::kStampSlots;
+  BHG_HIP_CHECK(hipDeviceSynchronize());
+  BHG_HIP_CHECK(hipMemcpy(host, g_stamps_dev, sizeof(unsigned long long) * (count < total ? count : total), hipMemcpyDeviceToHost));
+  return BHG_OK;
+}
+#endif
 
 }  // extern "C"

@@ -16,10 +16,11 @@ run depth2 --debug packed_depth=2
 run depth4 --debug packed_depth=4
 run default_again
 run alpha_launch --debug alpha_in_hoist=0
-run e1_split8 --debug gram_e1_split=8
-run e1_split2 --debug gram_e1_split=2
+run graw_v1 --debug graw_v2=0
+run graw_v1_e1_split3 --debug graw_v2=0 --debug gram_e1_split=3
 run neumann --algo neumann --cg-iters 10
 run neumann_unpacked --algo neumann --cg-iters 10 --debug packed_chain=0
+BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_stamps.so timeout 200 python scripts/stamp_trace.py 2>&1 | grep -vE "Warning|warn" | tee $O/stamps_default.txt
 for arm in default unpacked; do
   extra=""; [ $arm = unpacked ] && extra="packed_chain=0"
   cd /tmp && rm -rf /tmp/tr_$arm && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$arm -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused $extra > /tmp/tr_$arm.log 2>&1; echo "trace $arm rc=$?"

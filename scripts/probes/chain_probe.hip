@@ -20,9 +20,19 @@ using namespace bhg;
 __global__ void k_touch(float* p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = p[i] * 1.0001f + 1.f;
 }
+static bool g_ragged = true;
 struct Builder {
   WskpArgs g{}; int blk = 0;
-  void add(const WskpProb& q) { g.p[g.n] = q; g.blk0[g.n++] = blk; blk += (((q.RA / 32) * (q.RB / 32) * q.nsplit) + 7) & ~7; }
+  void add(const WskpProb& q_in) {
+    WskpProb q = q_in;
+    q.nfull = q.RA / 32; q.nstrip = 0;
+    if (g_ragged && !q.raw && q.nsplit == 1 && q.RB % 64 == 0) {
+      int nf = q.B / 32, rem = q.B % 32;
+      if (rem > 16) { ++nf; rem = 0; }
+      if (nf > 0) { q.nfull = nf; q.nstrip = rem > 0 ? q.RB / 64 : 0; }
+    }
+    g.p[g.n] = q; g.blk0[g.n++] = blk; blk += (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
+  }
 };
 template <int D>
 void run(const char* name, Builder b, float* junk, int junk_n, unsigned long long* stamps_dev) {
@@ -87,17 +97,24 @@ int main() {
     WskpProb q{}; q.Ap = A; q.Bq = Bm; q.RA = Bp; q.RB = Bp; q.K = K; q.B = B; q.nsplit = ns; q.raw = 1; q.out = slabs + (size_t)slot * 8 * Bp * Bp; return q; };
   auto pre_head = [&](int ns) { WskpProb q{}; q.Ap = Rh1p; q.Bq = W2f; q.RA = Bp; q.RB = d3; q.K = d2; q.B = B; q.nsplit = ns; q.raw = 1; q.out = partial; return q; };
 #define BOTH(name, expr) { Builder b; expr; run<3>(name, b, junk, junk_n, stamps); } { Builder b; expr; run<2>(name, b, junk, junk_n, stamps); }
+  g_ragged = false;
+  BOTH("fwd W1 alone, 4 x 48 tiles", b.add(chain(Rh0p, W1f, d2, d1, Rh1, Rh1p, false)));
+  BOTH("bwd W1 alone, 4 x 64 tiles", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)));
+  g_ragged = true;
   BOTH("fwd W1 alone", b.add(chain(Rh0p, W1f, d2, d1, Rh1, Rh1p, false)));
   BOTH("fwd W1 + T1(4)", b.add(chain(Rh0p, W1f, d2, d1, Rh1, Rh1p, false)); b.add(gram(h1p, Rh0p, d1, 4, 0)));
   BOTH("fwd W2 split5 alone", b.add(pre_head(5)));
   BOTH("fwd W2 split5 + T2(3)", b.add(pre_head(5)); b.add(gram(h2p, Rh1p, d2, 3, 1)));
   BOTH("fwd W2 split4 + T2(3)", b.add(pre_head(4)); b.add(gram(h2p, Rh1p, d2, 3, 1)));
-  BOTH("fwd W2 split8 + T2(6)", b.add(pre_head(8)); b.add(gram(h2p, Rh1p, d2, 6, 1)));
+  BOTH("fwd W2 split5 + T2(2)", b.add(pre_head(5)); b.add(gram(h2p, Rh1p, d2, 2, 1)));
+  BOTH("fwd W1 + T1(1)", b.add(chain(Rh0p, W1f, d2, d1, Rh1, Rh1p, false)); b.add(gram(h1p, Rh0p, d1, 1, 0)));
+  BOTH("fwd W1 + T1(2)", b.add(chain(Rh0p, W1f, d2, d1, Rh1, Rh1p, false)); b.add(gram(h1p, Rh0p, d1, 2, 0)));
   BOTH("bwd W2 alone", b.add(chain(Rd2p, W2b, d2, d3, Rd1, Rd1p, true)));
   BOTH("bwd W2 + E2(1)", b.add(chain(Rd2p, W2b, d2, d3, Rd1, Rd1p, true)); b.add(gram(dl2p, Rd2p, d3, 1, 2)));
   BOTH("bwd W1 alone", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)));
   BOTH("bwd W1 + E1(3)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 3, 3)));
-  BOTH("bwd W1 + E1(8)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 8, 3)));
+  BOTH("bwd W1 + E1(2)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 2, 3)));
+  BOTH("bwd W1 + E1(1)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 1, 3)));
   BOTH("E1(3) alone", b.add(gram(dl1p, Rd1p, d2, 3, 3)));
   BOTH("all four grams", b.add(gram(h1p, Rh0p, d1, 4, 0)); b.add(gram(h2p, Rh1p, d2, 3, 1)); b.add(gram(dl2p, Rd2p, d3, 1, 2)); b.add(gram(dl1p, Rd1p, d2, 3, 3)));
   return 0;

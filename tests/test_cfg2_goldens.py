@@ -92,6 +92,8 @@ def _arms(algo):
                  # launch of their own, and the packed K loop with two / four register stages (default: three)
                  ("fused-unpacked", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_CHAIN": "0"})),
                  ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
+                 ("fused-graw-v1", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAW_V2": "0"})),
+                 ("fused-alpha-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_ALPHA_IN_HOIST": "0"})),
                  ("fused-packed-d2", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "2"})),
                  ("fused-packed-d4", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "4"}))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
@@ -126,7 +128,8 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
         bhg_debug.delenv("BHG_MLP_PROJ", raising=False)
     else:
         bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
-    for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH"):
+    for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH", "BHG_GRAW_V2",
+                "BHG_ALPHA_IN_HOIST"):
         bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         bhg_debug.setenv(key, val)
