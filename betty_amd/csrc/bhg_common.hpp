@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -42,7 +43,7 @@ enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 
   X(mlp_hoist) X(hoist_wgs) X(proj_step_alone) X(mlp_no_side) X(mlp_no_fuse) X(mlp_no_outer_all) X(neumann_side)             \
   X(hoist_staged_mink) X(proj_alpha_alone) X(proj_small_alone) X(outer_order_by_work) X(outer_no_pre) X(outer_stagger)       \
   X(mlp_no_fused_solve) X(cg_eager_p) X(cg_x_every_iter) X(neumann_p_every_iter) X(head_no_prefetch) X(cg_spin_limit)        \
-  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(gram_e1_split) X(alpha_in_hoist) X(graw_v2) X(gram_max_split) X(wskp_ragged)
+  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(alpha_in_hoist) X(graw_v2) X(wskp_ragged) X(pstep_v2)
 enum DbgKey : int {
 #define BHG_DBG_ENUM(n) DBG_##n,
   BHG_DBG_KEYS(BHG_DBG_ENUM)
@@ -135,11 +136,121 @@ __device__ __forceinline__ void st4(float* __restrict__ base, int e, int len, fl
   if (e + 2 < len) base[e + 2] = v.z;
 }
 
-// ---- deterministic block reductions (fp64) --------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+// ---- kernel arguments: one latency for all of them ------------------------------------------------------------------
+// A miss of the scalar cache on the kernarg segment costs ~1.4 us on this system (stamps of k_graw: a tile whose descriptor shares
+// the first lines of the argument struct reaches its first load 1.8 us after entry, one whose descriptor sits further back 4.6 us —
+// two more DEPENDENT misses).  kernarg_warm<BYTES>() touches every 64-byte line of the struct with independent scalar loads and
+// waits once: what the kernel then reads through run-time indices (block tables, per-problem descriptors) hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+  typedef const __attribute__((address_space(4))) unsigned* KP;
+  KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned acc = 0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // valid in lane 0
+  for (int o = 0; o < BYTES; o += 64) acc |= kp[o / 4];
+  asm volatile("" ::"s"(acc));
+}
+// Strided share of a partial array, summed in index order like `for (i = t; i < n; i += stride) acc += p[i]` — but U clamped
+// loads are in flight together instead of one round trip per element (a loop-carried add behind every load: 7 trips for 448
+// partials on one wave).
+template <int U>
+__device__ __forceinline__ double sum_strided(const double* __restrict__ p, const int n, const int t, const int stride) {
+  double acc = 0.0;
+  for (int i0 = t; i0 < n; i0 += U * stride) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * stride;
+      v[u] = p[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * stride < n) acc += v[u];
+  }
+  return acc;
+}
+
+// The same in two phases, for SEVERAL arrays at once: strided_load() only issues the (clamped, unconditional) loads, strided_sum()
+// adds the live ones in index order.  A kernel that sums five partial arrays with five loops pays five dependent trips to the
+// Infinity Cache (stamps: 7-9 us for the step length's 650 partials); with every array's loads issued before the first add, one.
+// Requires n <= U * stride (callers fall back to sum_strided otherwise); p may be NULL when n == 0 (`dummy` is read instead).
+template <int U>
+struct StridedRegs { double v[U]; };
+template <int U>
+__device__ __forceinline__ void strided_load(StridedRegs<U>& r, const double* __restrict__ p, const int n, const int t, const int stride,
+                                             const double* __restrict__ dummy) {
+  const double* q = (p && n > 0) ? p : dummy;
+  const int last = (p && n > 0) ? n - 1 : 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = t + u * stride;
+    r.v[u] = q[i < n && i <= last ? i : last];
+  }
+}
+template <int U>
+__device__ __forceinline__ double strided_sum(const StridedRegs<U>& r, const int n, const int t, const int stride) {
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (t + u * stride < n) acc += r.v[u];
+  return acc;
+}
+
+// ---- deterministic block reductions (fp64) --------------------------------------------
+// Sum over the 64 lanes of a wave, fixed order, result in EVERY lane.  Data-parallel-primitive moves inside the 16-lane rows
+// (xor 1, xor 2, half-row mirror, row mirror: every lane of a row ends with the row's sum — each step adds the two partners in
+// both orders, which is the same bits), then the four row sums, (r0 + r1) + (r2 + r3), through v_readlane.  ~40 instructions
+// without a trip through the LDS crossbar; the __shfl_down ladder it replaces is six DEPENDENT ds_bpermute pairs per double
+// (~150 cycles each): 0.4 us per call, 2.6 us for the six sums of k_proj_step's scalar phase (its ISA: bpermute, wait, bpermute).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(const double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+__device__ __forceinline__ double readlane_f64(const double v, const int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_mov_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);   // row_mirror
+  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+  return (r0 + r1) + (r2 + r3);  // valid in every lane
+}
+// The same for a float (the head kernel's class dot products).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_mov_f32<0xB1>(v);
+  v += dpp_mov_f32<0x4E>(v);
+  v += dpp_mov_f32<0x141>(v);
+  v += dpp_mov_f32<0x140>(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// Three block sums with ONE pair of barriers (the fused CG epilogues emit r'.r', r'.p, p.p per workgroup: three block_sum calls
+// were six barriers).  Same values as three block_sum calls.  `red`: 3 * kWaves doubles of LDS.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red) {
+  const double wa = wave_sum(a), wb = wave_sum(b), wc = wave_sum(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` against the previous use
+  if (lane == 0) { red[w] = wa; red[kWaves + w] = wb; red[2 * kWaves + w] = wc; }
+  __syncthreads();
+  double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) { sa += red[i]; sb += red[kWaves + i]; sc += red[2 * kWaves + i]; }
+  a = sa; b = sb; c = sc;
 }
 // Sum over the block; result valid in every thread.  `red` is kWaves doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red) {

@@ -170,16 +170,22 @@ struct WskpBuilder {
     if (!g.n) return;
     g.blk0[g.n] = blk;
     const int d = dbg(DBG_packed_depth, 3);   // register stages of the K loop (A/B)
-    if (g.n <= 2) {   // the per-iteration launches: both descriptors as named kernel arguments (no dependent scalar loads)
-      Wskp2Args g2{};
-      g2.a = g.p[0];
-      g2.b = g.n == 2 ? g.p[1] : g.p[0];
-      g2.na = g.n == 2 ? g.blk0[1] : blk;
-      if (d == 2) hipLaunchKernelGGL(k_wskp2<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
-      else if (d == 4) hipLaunchKernelGGL(k_wskp2<4>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
-      else hipLaunchKernelGGL(k_wskp2<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g2);
+    // the per-iteration launches: a chain product + up to two Gram riders, named kernel arguments (no dependent scalar loads)
+    bool riders = g.n <= 3;
+    for (int i = 1; i < g.n && riders; ++i) {
+      const WskpProb& r = g.p[i];
+      riders = r.raw && r.nsplit == 1 && r.RA == g.p[0].RA && r.RB == g.p[0].RA && r.B == g.p[0].B && !r.bias && !r.mask && !r.addend &&
+               !r.partT2 && r.nstrip == 0 && r.nfull == r.RA / 32;
+    }
+    if (riders) {
+      WskpcArgs c{};
+      c.a = g.p[0];
+      c.na = g.n >= 2 ? g.blk0[1] : blk;
+      if (g.n >= 2) { c.r0 = {g.p[1].Ap, g.p[1].Bq, g.p[1].out, g.p[1].outp, g.p[1].K, 0}; c.nr0 = (g.n == 3 ? g.blk0[2] : blk) - g.blk0[1]; }
+      if (g.n == 3) c.r1 = {g.p[2].Ap, g.p[2].Bq, g.p[2].out, g.p[2].outp, g.p[2].K, 0};
+      if (d == 2) hipLaunchKernelGGL(k_wskpc<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c);
+      else hipLaunchKernelGGL(k_wskpc<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c);
     } else if (d == 2) hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
-    else if (d == 4) hipLaunchKernelGGL(k_wskp<4>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
     else hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
     g = WskpArgs{};
     blk = 0;
@@ -264,6 +270,8 @@ int pick_splits(int tiles, int K, int pairs) {
 
 #include "mlp/graw.inc"   // round 4: the closing launch of a projected iteration on packed Gram matrices (k_graw)
 
+#include "mlp/pstep.inc"   // round 4: k_proj_step with its kernel arguments in two scalar-memory round trips (k_pstep)
+
 // ---- per-device side stream + events -------------------------------------------------------------------------------
 struct SideState {
   hipStream_t side;
@@ -341,15 +349,6 @@ int chip_cus() {
   int n = 0;
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
   return cus[dev] = n;
-}
-// E_1 = delta_1 Rd_1^T rides in the LAST chain launch, whose tiles already fill the chip: split finer, so that its workgroups are
-// short guests on many CUs instead of long ones on a few (probe: 48 workgroups of 512 k stretch the launch by 3.8 us)
-inline int gram_esplit(int l, int K, bool in_chain) {
-  if (!(in_chain && l == 1)) return gram_ksplit(K);
-  int s = dbg(DBG_gram_e1_split, 3);
-  if (s > kGramSplitMax) s = kGramSplitMax;
-  if (s > K / 32) s = K / 32;
-  return s < 1 ? 1 : s;
 }
 struct HoistPlan {
   bool ok;
@@ -658,11 +657,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   bool sd_in_chain = false;   // first iteration: S_l, D_l rode in the first chain launch as well
   // k_graw (graw.inc) closes the iteration when the Gram matrices arrive packed; its loaders sum two K-split slabs at most.
   // graw_single: what the NEXT iteration's recurrences are told about the layout of G(raw) (one slab per product, not one per pair)
-  const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0;
+  const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 && Bp == 128;   // (k_graw: K = 128)
   const bool graw2 = gram_in_chain && graw_single;
-  const int gram_cap = graw2 ? 2 : dbg(DBG_gram_max_split, kGramSplitMax);
-  auto tsplit = [&](int K) { const int s = gram_ksplit(K); return s < gram_cap ? s : gram_cap; };
-  auto esplit = [&](int l, int K) { const int s = gram_esplit(l, K, gram_in_chain); return s < gram_cap ? s : gram_cap; };
+  // Gram products riding in chain launches: ONE K slab each — every rider sits in a launch whose tiles have the same K (T_1 with
+  // the forward product through W_1; E_l and T_{l+1} with the backward product through W_l), so it ends when they do
+  auto tsplit = [&](int K) { return gram_in_chain ? 1 : gram_ksplit(K); };
+  auto esplit = [&](int l, int K) { (void)l; return gram_in_chain ? 1 : gram_ksplit(K); };
   if (hp && do_chain) {
     float* hbase = cm.ws->hoist;
     HoistArgs ha{};
@@ -737,6 +737,22 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         g.r_b0 = cm.fa + cm.starts[1];
         g.p0_rd = cm.second ? cm.fd + cm.starts[1] : cm.ws->pb0[cm.kpar ^ 1];
         g.p0_wr = cm.ws->pb0[cm.kpar];
+        if (graw_single && cm.beta->nt <= 16 && dbg(DBG_pstep_v2, 1) != 0) {   // the same work, arguments laid out for two round trips
+          PstepArgs ps{};
+          PstepHdr& h = ps.h;
+          for (int i = 0; i <= hp->n; ++i) h.blk0[i] = pa.blk0[i];
+          h.n = pa.n; h.Bp = pa.Bp; h.B = pa.B; h.kpar_prev = pa.kpar_prev; h.shift = pa.shift; h.update_blocks = rblk;
+          h.scal = sa.scal; h.r_b0 = g.r_b0; h.p0_rd = g.p0_rd; h.p0_wr = g.p0_wr; h.r_small = sa.r_small; h.p_small = sa.p_small;
+          h.part_dot = sa.part_dot; h.part_raw = sa.part_raw; h.part = sa.part; h.pscal = sa.pscal;
+          h.dot_blocks = sa.dot_blocks; h.raw_blocks = sa.raw_blocks; h.part_stride = sa.part_stride;
+          h.off0 = sa.off0; h.n0 = sa.n0; h.off1 = sa.off1; h.n1 = sa.n1; h.first = sa.first; h.kpar = sa.kpar; h.snt = sa.snt;
+          for (int i = 0; i < hp->n; ++i) {
+            const ProjProb& q = pa.p[i];
+            ps.p[i] = {q.Gr, q.Gp, q.Graw, q.bias, q.mask, q.out, q.outp, q.N, 0};
+          }
+          for (int t = 0; t < sa.snt; ++t) { ps.t.slen[t] = sa.slen[t]; ps.t.soff[t] = sa.soff[t]; }
+          hipLaunchKernelGGL(k_pstep, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+        } else
         hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
       } else {
         hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
@@ -756,7 +772,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (l == L - 2) {   // raw K-split slabs: the head kernel combines them itself (adds Gf and c_l, applies the mask)
           // one workgroup per CU including the Gram product riding along: a second round of workgroups would start when the
           // first ends (probe: 240 + 32 workgroups 9.1 us, 192 + 48 5.4 us)
-          const int riders = gram_in_chain ? (Bp / 32) * (Bp / 32) * tsplit(K) : 0;
+          const int riders = (gram_in_chain && l == 1) ? (Bp / 32) * (Bp / 32) : 0;
           const int tiles_l = (Bp / 32) * (N / 32);
           int sp = (chip_cus() - riders) / tiles_l;
           const int cap = pick_splits((N + tn - 1) / tn, K, 1);                  // what m->partial was sized for
@@ -770,10 +786,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           q.bias = c; q.mask = m->mask[l]; q.addend = Gf; q.out = m->Rh[l]; q.outp = cm.ws->Rhp[l];
         }
         wb.add(q);
-        if (gram_in_chain) {   // T_l = h_l Rh_{l-1}^T: K-split slabs, summed by the consumer (the G(raw) products)
+        if (gram_in_chain && l == 1) {   // T_1 = h_1 Rh_0^T (same K as this launch's tiles)
           WskpProb t{};
           t.Ap = cm.ws->hpk[l]; t.Bq = cm.ws->Rhp[l - 1]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
-          t.nsplit = tsplit(K); t.raw = 1; t.out = hbase + hp->tslab_off[l]; t.outp = graw2 ? hbase + hp->tslabp_off[l] : nullptr;
+          t.nsplit = 1; t.raw = 1; t.out = hbase + hp->tslab_off[l]; t.outp = graw2 ? hbase + hp->tslabp_off[l] : nullptr;
           wb.add(t);
         }
         wb.launch(st);
@@ -834,11 +850,16 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         q.outp = l >= 2 ? cm.ws->Rdp[l - 1] : nullptr;
         if (cg) { q.rh = m->Rh[l - 1]; q.partT2 = cm.ws->partT2 + cm.ws->t2_off[l]; }
         wb.add(q);
-        if (gram_in_chain) {   // E_l = delta_l Rd_l^T
+        if (gram_in_chain) {   // E_l = delta_l Rd_l^T, and T_{l+1} = h_{l+1} Rh_l^T: both reduce over d_{l+1}, like this launch's tiles
           WskpProb t{};
           t.Ap = cm.ws->dpk[l]; t.Bq = cm.ws->Rdp[l]; t.RA = Bp; t.RB = Bp; t.K = K; t.B = B;
-          t.nsplit = esplit(l, K); t.raw = 1; t.out = hbase + hp->eslab_off[l]; t.outp = graw2 ? hbase + hp->eslabp_off[l] : nullptr;
+          t.nsplit = 1; t.raw = 1; t.out = hbase + hp->eslab_off[l]; t.outp = graw2 ? hbase + hp->eslabp_off[l] : nullptr;
           wb.add(t);
+          if (l + 1 <= L - 2) {
+            t.Ap = cm.ws->hpk[l + 1]; t.Bq = cm.ws->Rhp[l];
+            t.out = hbase + hp->tslab_off[l + 1]; t.outp = graw2 ? hbase + hp->tslabp_off[l + 1] : nullptr;
+            wb.add(t);
+          }
         }
         wb.launch(st);
         continue;
@@ -1117,27 +1138,31 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       if (graw2) {   // round 4: packed Gram matrices -> k_graw (64 x 32 tiles, inner products in the tile epilogue, one slab per product)
         GrawArgs ka{};
-        int gb = small_blocks;   // (the small slices' blocks lead the grid)
+        int gb = (small_blocks + 15) & ~15;   // (the small slices' blocks lead the grid; every table entry a multiple of 16)
+        int real_tiles = 0;
         for (int i = 0; i < hp->n; ++i) {
           const int l = hp->layer[i];
           GrawProb& q = ka.p[i];
           if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
-            q.A1 = hbase + hp->sp_off[l]; q.B1 = m->Rd[l]; q.n1 = 1;
-            if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l]; q.B2 = m->delta[l]; q.n2 = tsplit(m->dims[l]); }
+            q.A1 = hbase + hp->sp_off[l]; q.B1 = m->Rd[l];
+            if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l]; q.B2 = m->delta[l]; }
           } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
-            q.A1 = hbase + hp->eslabp_off[l]; q.B1 = m->h[l]; q.n1 = esplit(l, m->dims[l + 1]);
-            q.A2 = hbase + hp->dp_off[l]; q.B2 = m->Rh[l - 1]; q.n2 = 1;
+            q.A1 = hbase + hp->eslabp_off[l]; q.B1 = m->h[l];
+            q.A2 = hbase + hp->dp_off[l]; q.B2 = m->Rh[l - 1];
           }
-          if (full) {
-            q.X = hp->bwd[i] ? (const float*)m->Rh[l - 1] : (const float*)m->Rd[l];
+          q.Gr = q.Gp = q.B1;   // (always loadable)
+          if (full) {           // the inner products' partner: Rd_l (= B1) forward, Rh_{l-1} (= B2) backward
             q.Gr = hbase + hp->gr_off[i]; q.Gp = hbase + hp->g_off[i];
+            q.dots = hp->bwd[i] ? 2 : 1;
           }
           q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
-          ka.blk0[i] = gb; gb += (Bp / 64) * (hp->N[i] / 32);
+          q.pb0 = real_tiles;
+          real_tiles += (Bp / 64) * (hp->N[i] / 32);
+          ka.blk0[i] = gb; gb += (((Bp / 64) * (hp->N[i] / 32)) + 15) & ~15;
         }
         ka.blk0[hp->n] = gb;
-        BHG_REQUIRE(gb - small_blocks == hp->graw_tiles, "tile count of k_graw and of the plan disagree");
-        ka.n = hp->n; ka.Bp = Bp; ka.B = B; ka.slab_stride = Bp * Bp;
+        BHG_REQUIRE(real_tiles == hp->graw_tiles, "tile count of k_graw and of the plan disagree");
+        ka.n = hp->n; ka.Bp = Bp; ka.B = B;
         ka.part = cm.ws->part_graw; ka.npart = hp->graw_tiles;
         ka.small_blocks = small_blocks; ka.so = so;
         if (alpha_in_hoist) { ka.do_alpha = 1; ka.alpha = aa; }

@@ -17,7 +17,8 @@ run depth4 --debug packed_depth=4
 run default_again
 run alpha_launch --debug alpha_in_hoist=0
 run graw_v1 --debug graw_v2=0
-run graw_v1_e1_split3 --debug graw_v2=0 --debug gram_e1_split=3
+run pstep_v1 --debug pstep_v2=0
+
 run neumann --algo neumann --cg-iters 10
 run neumann_unpacked --algo neumann --cg-iters 10 --debug packed_chain=0
 BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_stamps.so timeout 200 python scripts/stamp_trace.py 2>&1 | grep -vE "Warning|warn" | tee $O/stamps_default.txt
@@ -26,5 +27,5 @@ for arm in default unpacked; do
   cd /tmp && rm -rf /tmp/tr_$arm && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$arm -o t -- python $GRAFT_REPO_ROOT/scripts/iter_trace.py 3 cg fused $extra > /tmp/tr_$arm.log 2>&1; echo "trace $arm rc=$?"
   cd $GRAFT_REPO_ROOT
   f=$(ls /tmp/tr_$arm/*kernel_trace.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && python scripts/print_iter_timeline.py $f "k_proj_step" | tee $O/timeline_$arm.txt
+  [ -n "$f" ] && M=k_pstep; [ $arm = unpacked ] && M=k_proj_step; python scripts/print_iter_timeline.py $f "$M" | tee $O/timeline_$arm.txt
 done

@@ -40,9 +40,13 @@ void run(const char* name, Builder b, float* junk, int junk_n, unsigned long lon
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 100;
   auto launch = [&](WskpArgs& g) {
-    if (g.n <= 2) {
-      Wskp2Args g2{}; g2.a = g.p[0]; g2.b = g.n == 2 ? g.p[1] : g.p[0]; g2.na = g.n == 2 ? g.blk0[1] : b.blk; g2.stamps = g.stamps;
-      hipLaunchKernelGGL(k_wskp2<D>, dim3(b.blk), dim3(64 * kWskpWaves), 0, 0, g2);
+    bool riders = g.n <= 3;
+    for (int i = 1; i < g.n && riders; ++i) riders = g.p[i].raw && g.p[i].nsplit == 1 && g.p[i].RB == g.p[0].RA;
+    if (riders) {
+      WskpcArgs c{}; c.a = g.p[0]; c.na = g.n >= 2 ? g.blk0[1] : b.blk; c.stamps = g.stamps;
+      if (g.n >= 2) { c.r0 = {g.p[1].Ap, g.p[1].Bq, g.p[1].out, g.p[1].outp, g.p[1].K, 0}; c.nr0 = (g.n == 3 ? g.blk0[2] : b.blk) - g.blk0[1]; }
+      if (g.n == 3) c.r1 = {g.p[2].Ap, g.p[2].Bq, g.p[2].out, g.p[2].outp, g.p[2].K, 0};
+      hipLaunchKernelGGL(k_wskpc<D>, dim3(b.blk), dim3(64 * kWskpWaves), 0, 0, c);
     } else hipLaunchKernelGGL(k_wskp<D>, dim3(b.blk), dim3(64 * kWskpWaves), 0, 0, g);
   };
   for (int i = 0; i < 3; ++i) launch(b.g);
@@ -115,6 +119,7 @@ int main() {
   BOTH("bwd W1 + E1(3)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 3, 3)));
   BOTH("bwd W1 + E1(2)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 2, 3)));
   BOTH("bwd W1 + E1(1)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 1, 3)));
+  BOTH("bwd W1 + E1(1) + T2(1)", b.add(chain(Rd1p, W1b, d1, d2, Rd0, nullptr, true)); b.add(gram(dl1p, Rd1p, d2, 1, 3)); b.add(gram(h2p, Rh1p, d2, 1, 1)));
   BOTH("E1(3) alone", b.add(gram(dl1p, Rd1p, d2, 3, 3)));
   BOTH("all four grams", b.add(gram(h1p, Rh0p, d1, 4, 0)); b.add(gram(h2p, Rh1p, d2, 3, 1)); b.add(gram(dl2p, Rd2p, d3, 1, 2)); b.add(gram(dl1p, Rd1p, d2, 3, 3)));
   return 0;

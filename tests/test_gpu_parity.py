@@ -884,6 +884,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
     arms["full-gramlaunch"] = dict(arms["full"], BHG_PACKED_GRAM="0")
     arms["full-grawv1"] = dict(arms["full"], BHG_GRAW_V2="0")        # Gram products in the chain launches, G(raw) by k_hoist (three slabs)
     arms["full-alphalaunch"] = dict(arms["full"], BHG_ALPHA_IN_HOIST="0")
+    arms["full-pstepv1"] = dict(arms["full"], BHG_PSTEP_V2="0")         # k_proj_step instead of k_pstep (same work, lazily fetched arguments)
     arms["hoisted-unpacked"] = dict(arms["hoisted"], BHG_PACKED_CHAIN="0")
     out = {}
     for name, env in arms.items():
