@@ -136,12 +136,12 @@ SYMBOLS = {
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_neumann_solve": (
         c_int,
-        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, c_void_p],
+        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, POINTER(c_int), c_void_p],
     ),
     "bhg_mlp_wsk_launches": (c_int64, []),
     "bhg_mlp_hoist_launches": (c_int64, []),
     "bhg_mlp_proj_iterations": (c_int64, []),
-    "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

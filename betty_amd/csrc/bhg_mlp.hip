@@ -23,8 +23,6 @@
 // outputs stored or consumed), and the C entry points bhg_mlp_* of include/bhg.h.
 #include <stdlib.h>
 
-#include <mutex>
-#include <unordered_map>
 
 #include "bhg_common.hpp"
 
@@ -80,8 +78,6 @@ inline bool wsk_eligible(const WskArgs& a) {
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 int64_t g_hoist_launches = 0; // bhg_mlp_hoist_launches()
 int64_t g_proj_iterations = 0; // bhg_mlp_proj_iterations()
-std::mutex g_neumann_mu;        // which fused workspaces hold a PROJECTED Neumann solve (its Rz sum includes the last direction)
-std::unordered_map<const void*, bool> g_neumann_projected;
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
@@ -363,6 +359,7 @@ struct HoistPlan {
   size_t sp_off[BHG_MLP_MAX_LAYERS], dp_off[BHG_MLP_MAX_LAYERS];         // the same four, PACKED ([Bp/16][Bp][16]: k_graw's M-side
   size_t tslabp_off[BHG_MLP_MAX_LAYERS], eslabp_off[BHG_MLP_MAX_LAYERS]; // operands; two slabs at most)
   int graw_tiles;                                                        // 64 x 32 tiles of the G(raw) launch (k_graw)
+  bool proj_ok;                                                          // the projected solvers pay off and fit (cost model below)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
@@ -416,11 +413,24 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->gr_off[i] = off;   off += (size_t)Bp * hp->N[i];
     hp->graw_off[i] = off; off += (size_t)2 * Bp * hp->N[i];   // up to two slabs (one per operand pair)
   }
+  // Cost model of the projected solvers: their per-iteration Gram and G(raw) work is O(B^2 d) against the direct
+  // products' O(B d^2), and their B x B matrices ((2 + 16 + 6) Bp^2 floats per layer) grow quadratically — 2.5 GB at Bp = 4096.
+  // Projection is taken only while the padded batch does not exceed the narrowest hidden layer (proj_max_ratio, in percent of it:
+  // default 100) and the Gram region stays under proj_ws_cap_mb (default 1024); otherwise the plan keeps the hoisted chain on the
+  // N-sized residual and carves no Gram region at all.
+  {
+    int minw = m->dims[1];
+    for (int l = 1; l <= L - 1; ++l) minw = m->dims[l] < minw ? m->dims[l] : minw;
+    size_t gram = 0;
+    for (int l = 0; l + 1 < L; ++l) gram += (size_t)Bp * Bp * (l >= 1 ? (2 + 2 * kGramSplitMax + 6) : 2);
+    hp->proj_ok = (int64_t)Bp * 100 <= (int64_t)minw * dbg(DBG_proj_max_ratio, 100) &&
+                  gram * sizeof(float) <= (size_t)dbg(DBG_proj_ws_cap_mb, 1024) * 1024 * 1024;
+  }
   hp->dot_blocks = 0;
   for (int i = 0; i < n; ++i) hp->dot_blocks += dot_blocks_of(Bp * (hp->N[i] / 4));
   hp->raw_blocks = 0;
   for (int i = 0; i < n; ++i) hp->raw_blocks += (hp->N[i] / 32) * ntm * 2;   // at most two workgroups (operand pairs) per tile
-  for (int l = 0; l + 1 < L; ++l) {
+  for (int l = 0; hp->proj_ok && l + 1 < L; ++l) {
     hp->s_off[l] = off; off += (size_t)Bp * Bp;
     if (l >= 1) {
       hp->d_off[l] = off; off += (size_t)Bp * Bp;
@@ -428,7 +438,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
       hp->eslab_off[l] = off; off += (size_t)kGramSplitMax * Bp * Bp;
     }
   }
-  for (int l = 0; l + 1 < L; ++l) {
+  for (int l = 0; hp->proj_ok && l + 1 < L; ++l) {
     hp->sp_off[l] = off; off += (size_t)Bp * Bp;
     if (l >= 1) {
       hp->dp_off[l] = off; off += (size_t)Bp * Bp;
@@ -1361,16 +1371,11 @@ int64_t bhg_mlp_hoist_launches(void) { return bhg::g_hoist_launches; }
 int64_t bhg_mlp_proj_iterations(void) { return bhg::g_proj_iterations; }
 
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff, float alpha,
-                                int K, void* fws, size_t fws_bytes, void* stream) {
+                                int K, int projected, void* fws, size_t fws_bytes, void* stream) {
   // coefficient of the accumulator-free Neumann solve: p_final = -alpha * sum_{k=0..K} v_k  (neumann.py:64,66 and the
   // negation of 45/54)  =>  coeff = -alpha * ( coeff(v_K)  +  (prob - onehot) . sum_{k<K} Rz(v_k) / B )
   BHG_REQUIRE(fws && fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
-  bool projected = false;   // the last bhg_mlp_neumann_solve on this workspace already added Rz(v_K) to the sum
-  {
-    std::lock_guard<std::mutex> lock(g_neumann_mu);
-    auto it = g_neumann_projected.find(fws);
-    projected = it != g_neumann_projected.end() && it->second;
-  }
+  // projected (what bhg_mlp_neumann_solve reported for THIS solve): its closing pass already added Rz(v_K) to the sum
   if (!projected)
     if (int rc = bhg_mlp_mixed_coeff(m, v_last, labels, coeff, stream)) return rc;   // coeff(v_K): one R-forward
   FusedWs w;
@@ -1448,7 +1453,7 @@ static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p
   // projection level: 1 = G(r) by recurrence, the N-sized r / p still updated by k_outer_all (needed when the caller wants x);
   // 2 = fully projected (default without a solution vector): no N-sized state after the first iteration
   // (BHG_MLP_PROJ: 0 off | 1 default | 9 level 1 even without a solution vector — the A/B arm of level 2)
-  c->proj_level = (!c->hoist || proj_mode() == 0 || global) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
+  c->proj_level = (!c->hoist || !c->hplan.proj_ok || proj_mode() == 0 || global) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
 }
 // gphase 0: the whole iteration (one rank) | 1: up to this rank's p.H_data p | 2: from the step length on (see ChainMode)
 static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_world, hipStream_t st) {
@@ -1568,7 +1573,7 @@ int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, cons
 }
 
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K, float alpha,
-                          float hvp_shift, void* fws, size_t fws_bytes, void* stream) {
+                          float hvp_shift, void* fws, size_t fws_bytes, int* projected_out, void* stream) {
   if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
   // p == NULL: the N-sized accumulator is not materialised.  The mixed second derivative is linear in the direction and
   // only needs Rz(p_K) = sum_{k=0..K} Rz(v_k): the head kernel of iteration k leaves Rz(v_k) anyway (k < K, summed into the
@@ -1592,11 +1597,8 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
   hplan.ok = false;
   const bool want_proj = !p && K > 0 && proj_mode() != 0 && hoist_mode() != 0;
   if (hoist_mode() == 2 || want_proj) hoist_plan(m, &hplan);
-  const bool proj = want_proj && hplan.ok && use_head(m);
-  {
-    std::lock_guard<std::mutex> lock(g_neumann_mu);
-    g_neumann_projected[fws] = proj;
-  }
+  const bool proj = want_proj && hplan.ok && hplan.proj_ok && use_head(m);
+  if (projected_out) *projected_out = proj ? 1 : 0;   // the caller hands it to bhg_mlp_neumann_mixed_coeff (no hidden per-workspace state)
   if (hplan.ok && K > 0 && packed_chain_on(w))
     if (int rc = pack_operands(m, w, st)) return rc;
   for (int k = 0; k < K; ++k) {

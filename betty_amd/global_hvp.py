@@ -102,7 +102,6 @@ class _OnePassState:
         self.php = torch.zeros(1, dtype=torch.float64, device=full_layout.device)
 
 
-_ONE_PASS = {}
 ONE_PASS_STATS = {"solves": 0, "scalar_all_reduces": 0, "residual_all_reduces": 0}   # test / measurement hook
 
 
@@ -110,9 +109,9 @@ def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: f
     """The replicated-state form described in the module docstring; returns what cg_global returns."""
     from . import _native  # noqa: PLC0415
 
-    st = _ONE_PASS.get(id(full))
+    st = full.__dict__.get("_bhg_one_pass")   # (owned by the layout object: dies with it; no id()-keyed global)
     if st is None:
-        st = _ONE_PASS[id(full)] = _OnePassState(full)
+        st = full.__dict__["_bhg_one_pass"] = _OnePassState(full)
     x, r, p = full.state(3)
     skip_x = bool(provider.fused_cg_global_skips_solution(full, K))
     # right-hand side: the mean over the ranks of the local gradients of the upper loss

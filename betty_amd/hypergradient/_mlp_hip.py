@@ -23,7 +23,6 @@ from .. import _native
 
 TILE_M = 128  # activation buffers hold a multiple of 128 rows (the MFMA workgroup tile height)
 
-_BUFFERS = {}
 
 
 class _Buffers:
@@ -101,10 +100,14 @@ class HipMLPState:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0:
                 raise ValueError("weights and biases must be contiguous, 16-byte aligned fp32 tensors")
         dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
-        key = (id(spec.layers[0]), dims, BP, str(x.device))  # one set of buffers per inner network and batch tile count
-        buf = _BUFFERS.get(key)
+        # one set of buffers per inner network and batch tile count, owned BY the network's first layer (a per-module dict:
+        # the buffers die with the module — round 3 kept them in a process-global dict keyed by id(), never evicted, and an id
+        # recycled by a new module would have found a dead network's buffers)
+        key = (dims, BP, str(x.device))
+        owner = spec.layers[0].__dict__.setdefault("_bhg_buffers", {})
+        buf = owner.get(key)
         if buf is None:
-            buf = _BUFFERS[key] = _Buffers(dims, BP, x.device, lib)
+            buf = owner[key] = _Buffers(dims, BP, x.device, lib)
         self.buf, self.B, self.L, self.Ws = buf, B, L, Ws
         d = buf.desc
         d.B = B
@@ -259,13 +262,16 @@ class HipMLPState:
         keep_p=False: the library gets p = NULL; mixed_coeff() of this solve is then formed from the Rz sums the head
         kernel collected plus one R-forward of the last direction."""
         fws, starts = self._fused_args(layout)
+        projected = ctypes.c_int(0)
         _native.check(
             self.lib.bhg_mlp_neumann_solve(ctypes.byref(self.desc), v0.data_ptr(), v1.data_ptr(), p.data_ptr() if keep_p else None,
-                                           starts, int(K), float(alpha), float(shift), fws.data_ptr(), fws.numel(), _stream()),
+                                           starts, int(K), float(alpha), float(shift), fws.data_ptr(), fws.numel(), ctypes.byref(projected),
+                                           _stream()),
             "bhg_mlp_neumann_solve",
         )
         # v_K sits in v0 after an even number of iterations, in v1 after an odd one
         self._solve = FusedSolve("neumann", float(alpha), int(K), layout, v_last=v0 if K % 2 == 0 else v1, materialised=keep_p)
+        self._solve.projected = int(projected.value)   # which form ran: travels with the token to bhg_mlp_neumann_mixed_coeff
         return self._solve
 
     def mixed_coeff(self, dir_views, solve: FusedSolve = None):
@@ -283,7 +289,8 @@ class HipMLPState:
                 tab, _keep = self._dir_table(views)
                 _native.check(
                     self.lib.bhg_mlp_neumann_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(),
-                                                         solve.alpha, solve.K, buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                                                         solve.alpha, solve.K, int(getattr(solve, "projected", 0)), buf.fws.data_ptr(),
+                                                         buf.fws.numel(), _stream()),
                     "bhg_mlp_neumann_mixed_coeff",
                 )
                 return buf.coeff[:B].clone()

