@@ -413,17 +413,24 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->gr_off[i] = off;   off += (size_t)Bp * hp->N[i];
     hp->graw_off[i] = off; off += (size_t)2 * Bp * hp->N[i];   // up to two slabs (one per operand pair)
   }
-  // Cost model of the projected solvers: their per-iteration Gram and G(raw) work is O(B^2 d) against the direct
-  // products' O(B d^2), and their B x B matrices ((2 + 16 + 6) Bp^2 floats per layer) grow quadratically — 2.5 GB at Bp = 4096.
-  // Projection is taken only while the padded batch does not exceed the narrowest hidden layer (proj_max_ratio, in percent of it:
-  // default 100) and the Gram region stays under proj_ws_cap_mb (default 1024); otherwise the plan keeps the hoisted chain on the
-  // N-sized residual and carves no Gram region at all.
+  // Cost model of the projected solvers: per iteration they trade the hoisted direction products on the N-sized
+  // residual, F_h = 2 B (sum_{l<=L-2} d_l d_{l+1} + sum_{1<=l<=L-2} d_l d_{l+1}) flops (and its 4 N bytes), for B x B Gram products
+  // and batch-deep G(raw) products, F_p = 2 B^2 (sum_{1<=l<=L-2} (d_l + d_{l+1}) + sum G(raw) widths) — quadratic in the batch,
+  // like their Gram region ((2 + 16 + 6) Bp^2 floats per layer: 2.5 GB at Bp = 4096).  Projection is taken while
+  // F_p <= proj_max_ratio % of F_h (default 400: the projected form also drops every N-sized read and launch) and the Gram region stays
+  // under proj_ws_cap_mb (default 1024); otherwise the plan keeps the hoisted chain and carves no Gram region at all.
   {
-    int minw = m->dims[1];
-    for (int l = 1; l <= L - 1; ++l) minw = m->dims[l] < minw ? m->dims[l] : minw;
+    double fh = 0.0, fp = 0.0;
+    for (int l = 0; l + 1 < L; ++l) fh += (double)m->dims[l] * m->dims[l + 1] * (l >= 1 ? 2.0 : 1.0);
+    fh *= 2.0 * Bp;
+    for (int l = 0; l + 1 < L; ++l) {
+      fp += (double)m->dims[l + 1] * (l == 0 ? 1.0 : 2.0);                                 // Gf_l(raw)
+      if (l >= 1) fp += 2.0 * m->dims[l] + (double)m->dims[l] + (double)m->dims[l + 1];     // Gb_l(raw); T_l, E_l
+    }
+    fp *= 2.0 * Bp * (double)Bp;
     size_t gram = 0;
     for (int l = 0; l + 1 < L; ++l) gram += (size_t)Bp * Bp * (l >= 1 ? (2 + 2 * kGramSplitMax + 6) : 2);
-    hp->proj_ok = (int64_t)Bp * 100 <= (int64_t)minw * dbg(DBG_proj_max_ratio, 100) &&
+    hp->proj_ok = fp * 100.0 <= fh * (double)dbg(DBG_proj_max_ratio, 400) &&
                   gram * sizeof(float) <= (size_t)dbg(DBG_proj_ws_cap_mb, 1024) * 1024 * 1024;
   }
   hp->dot_blocks = 0;

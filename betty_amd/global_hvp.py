@@ -37,6 +37,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -102,6 +104,7 @@ class _OnePassState:
         self.php = torch.zeros(1, dtype=torch.float64, device=full_layout.device)
 
 
+_ONE_PASS = weakref.WeakKeyDictionary()
 ONE_PASS_STATS = {"solves": 0, "scalar_all_reduces": 0, "residual_all_reduces": 0}   # test / measurement hook
 
 
@@ -109,9 +112,9 @@ def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: f
     """The replicated-state form described in the module docstring; returns what cg_global returns."""
     from . import _native  # noqa: PLC0415
 
-    st = full.__dict__.get("_bhg_one_pass")   # (owned by the layout object: dies with it; no id()-keyed global)
+    st = _ONE_PASS.get(full)   # (weak-keyed by the layout object: dies with it; round 3 keyed a plain dict by id())
     if st is None:
-        st = full.__dict__["_bhg_one_pass"] = _OnePassState(full)
+        st = _ONE_PASS[full] = _OnePassState(full)
     x, r, p = full.state(3)
     skip_x = bool(provider.fused_cg_global_skips_solution(full, K))
     # right-hand side: the mean over the ranks of the local gradients of the upper loss

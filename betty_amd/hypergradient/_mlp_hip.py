@@ -15,6 +15,7 @@ K HVPs — the hot part — always run on the HIP kernels).
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -22,6 +23,8 @@ import torch.nn.functional as F
 from .. import _native
 
 TILE_M = 128  # activation buffers hold a multiple of 128 rows (the MFMA workgroup tile height)
+
+_BUFFERS = weakref.WeakKeyDictionary()   # first nn.Linear of an inner network -> {(dims, BP, device): _Buffers}
 
 
 
@@ -75,10 +78,11 @@ class FusedSolve:
     is the solution of exactly that run (whose Rz the solver accumulated on its way).  A hand-driven ``hvp()`` or another
     solve on the same state retires the token."""
 
-    __slots__ = ("kind", "alpha", "K", "layout", "v_last", "materialised")
+    __slots__ = ("kind", "alpha", "K", "layout", "v_last", "materialised", "projected")
 
-    def __init__(self, kind, alpha, K, layout, v_last=None, materialised=True):
+    def __init__(self, kind, alpha, K, layout, v_last=None, materialised=True, projected=0):
         self.kind, self.alpha, self.K, self.layout, self.v_last, self.materialised = kind, alpha, K, layout, v_last, materialised
+        self.projected = projected   # Neumann: what bhg_mlp_neumann_solve reported (its closing pass already summed Rz(v_K))
 
     def __bool__(self):
         return True
@@ -100,11 +104,11 @@ class HipMLPState:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0:
                 raise ValueError("weights and biases must be contiguous, 16-byte aligned fp32 tensors")
         dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
-        # one set of buffers per inner network and batch tile count, owned BY the network's first layer (a per-module dict:
-        # the buffers die with the module — round 3 kept them in a process-global dict keyed by id(), never evicted, and an id
-        # recycled by a new module would have found a dead network's buffers)
+        # one set of buffers per inner network and batch tile count, in a WEAK-keyed map on the network's first layer: the buffers
+        # die with the module (round 3 kept them in a plain dict keyed by id(), never evicted, and an id recycled by a new module
+        # would have found a dead network's buffers); nothing is attached to the module itself (deepcopy / pickling stay clean)
         key = (dims, BP, str(x.device))
-        owner = spec.layers[0].__dict__.setdefault("_bhg_buffers", {})
+        owner = _BUFFERS.setdefault(spec.layers[0], {})
         buf = owner.get(key)
         if buf is None:
             buf = owner[key] = _Buffers(dims, BP, x.device, lib)

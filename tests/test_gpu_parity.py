@@ -897,6 +897,9 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         for k, v in env.items():
             if k != "keep":
                 bhg_debug.setenv(k, v)
+        # this test is about the FORMS: the cost model that gates projection by batch size / layer widths (its own test:
+        # test_projection_is_gated_by_batch_size) must not pick the arm here — the eight-layer net is 32-96 wide
+        bhg_debug.setenv("BHG_PROJ_MAX_RATIO", "100000000")
         keep = env.get("keep", "1") == "1"
         h0, p0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations()
         out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
@@ -927,6 +930,7 @@ def test_projected_solvers_edge_cases(algo, ridge, alpha, K, bhg_debug):
         outs = {}
         for arm in ("0", "1"):
             bhg_debug.setenv("BHG_MLP_HOIST", arm)
+            bhg_debug.setenv("BHG_PROJ_MAX_RATIO", "100000000")   # (the recurrences are under test, not the cost model that gates them)
             p0 = lib.bhg_mlp_proj_iterations()
             outs[arm], _ = _run_solver(algo, dims, B, ridge, K, 5 + K, True, alpha=alpha, keep=False)
             projected = lib.bhg_mlp_proj_iterations() - p0
@@ -1467,6 +1471,9 @@ def _reference_nas_modules():
 
 
 @pytest.mark.skipif(not os.path.isfile(os.path.join(_NAS_DIR, "model_search.py")), reason="reference NAS example not staged")
+@pytest.mark.skipif(os.environ.get("BHG_RUN_SLOW") != "1",
+                    reason="12.5 minutes on a fresh box (383 s reference + 364 s product per Neumann-20 step: every conv shape of the "
+                           "supernet is a first-time MIOpen compile there); set BHG_RUN_SLOW=1.  Last run: profiles/r04_cfg5_as_named.log")
 def test_cfg5_reference_network_16_10_8_neumann20_batch64(be):
     """Product (opaque double backward + k_neumann_step on 1,399 tensors through the device pointer table) against the oracle's
     restatement of neumann.py on the same device tensors — i.e. the reference's algorithm on the same GPU, whose time is printed

@@ -1,6 +1,8 @@
 """Host orchestration of betty_amd.hypergradient (flat state, autograd views, sync semantics,
 registry / get_grads) on CPU, with the kernels replaced by the C oracle through the test-only
 checker backend.  The GPU suite (test_gpu_parity.py) runs the same cases through the HIP kernels."""
+import os
+import sys
 import numpy as np
 import pytest
 import torch
@@ -428,3 +430,27 @@ def test_structure_guard_rejects_a_training_step_the_closed_form_does_not_descri
         prov.prepare()
     prov.verify = False          # the documented opt-out
     prov.prepare()
+
+
+def test_cfg5_named_network_is_the_references_own():
+    """BASELINE cfg 5 names `Network(16, 10, 8)` + `Architecture` of examples/neural_architecture_search/model_search.py:129-234,
+    302-317.  The GPU test builds exactly that model from the reference's files (staged test-only by `make -C oracle ref`): here,
+    without a GPU, its size is pinned — 1,930,618 parameters in 1,399 tensors, 2 x 14 x 8 = 224 architecture parameters."""
+    import importlib
+    import types
+
+    nas = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "examples_nas")
+    if not os.path.isfile(os.path.join(nas, "model_search.py")):
+        pytest.skip("reference NAS example not staged (make -C oracle ref)")
+    if "utils" not in sys.modules or not hasattr(sys.modules["utils"], "accuracy"):
+        stub = types.ModuleType("utils")
+        stub.accuracy = lambda output, target, topk=(1,): [torch.zeros(()) for _ in topk]
+        sys.modules["utils"] = stub
+    sys.path.insert(0, nas)
+    try:
+        ms = importlib.import_module("model_search")
+    finally:
+        sys.path.remove(nas)
+    net, arch = ms.Network(16, 10, 8, torch.nn.CrossEntropyLoss()), ms.Architecture(4)
+    assert (sum(p.numel() for p in net.parameters()), len(list(net.parameters()))) == (1_930_618, 1_399)
+    assert sum(p.numel() for p in arch.parameters()) == 224
