@@ -138,12 +138,22 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
 
 // Grouped launch on packed operands (wskp.inc).  Block tables are rounded up to multiples of 8 so that a problem's tile t keeps
 // t % 8 == blockIdx.x % 8 (the XCD it runs on).
+// CUs of the current device (per-device cache; 256 on an MI355X): grouped launches are sized to ONE resident round of workgroups
+int chip_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  if (cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  return cus[dev] = n;
+}
 // Row tiling of one problem (see wskp_body): chain products cover the B valid rows with 32-row tiles and, over a remainder of at
 // most 16 rows, 16 x 64 tiles; K-split / raw problems keep every row tile (their consumers read all RA rows or none of the padding).
-inline void wskp_tiling(WskpProb* q) {
+inline void wskp_tiling(WskpProb* q, bool ragged) {
   q->nfull = q->RA / 32;
   q->nstrip = 0;
-  if (dbg(DBG_wskp_ragged, 1) == 0 || q->raw || q->nsplit != 1 || q->RB % 64 != 0) return;
+  if (!ragged || q->raw || q->nsplit != 1 || q->RB % 64 != 0) return;
   int nf = q->B / 32, rem = q->B % 32;
   if (rem > 16) { ++nf; rem = 0; }
   if (nf == 0) return;   // (a batch of <= 16 rows: one row of full tiles)
@@ -155,17 +165,29 @@ struct WskpBuilder {
   int blk = 0;
   bool add(const WskpProb& q_in) {
     if (g.n >= kWskpMax) return false;
-    WskpProb q = q_in;
-    wskp_tiling(&q);
-    g.p[g.n] = q;
-    g.blk0[g.n++] = blk;
-    blk += (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
+    g.p[g.n++] = q_in;
     return true;
+  }
+  // Row tiling of the launch: every row tile (4 x N/32 tiles at B = 100) while that fits ONE resident round of workgroups — a
+  // 16 x 64 remainder tile loads 25 % more per MFMA and ends ~1 us after the 32 x 32 tiles of its launch (probe: 11.8 vs 10.9 us
+  // for the product through W_1) — and the ragged tiling only where it makes the round fit (the product through W_1^T with its two
+  // Gram riders: 224 + 16 + 16 workgroups on 256 CUs instead of 256 + 32).  Debug key wskp_ragged: 0 never, 2 always.
+  void tile(bool ragged) {
+    blk = 0;
+    for (int i = 0; i < g.n; ++i) {
+      WskpProb& q = g.p[i];
+      wskp_tiling(&q, ragged);
+      g.blk0[i] = blk;
+      blk += (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
+    }
   }
   void launch(hipStream_t st) {
     if (!g.n) return;
+    const int mode = dbg(DBG_wskp_ragged, 1);
+    tile(mode == 2);
+    if (mode == 1 && blk > chip_cus()) tile(true);
     g.blk0[g.n] = blk;
-    const int d = dbg(DBG_packed_depth, 3);   // register stages of the K loop (A/B)
+    const int d = dbg(DBG_packed_depth, 2);   // register stages of the K loop (A/B: 2 is ~1 us per iteration ahead of 3 in six same-box pairs)
     // the per-iteration launches: a chain product + up to two Gram riders, named kernel arguments (no dependent scalar loads)
     bool riders = g.n <= 3;
     for (int i = 1; i < g.n && riders; ++i) {
@@ -335,16 +357,6 @@ inline int gram_ksplit(int K) {
   const int per = c >= 32 ? c : 512;
   const int s = K / per;
   return s < 1 ? 1 : (s > kGramSplitMax ? kGramSplitMax : s);
-}
-// CUs of the current device (per-device cache; 256 on an MI355X): grouped launches are sized to ONE resident round of workgroups
-int chip_cus() {
-  static int cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
-  if (cus[dev] > 0) return cus[dev];
-  int n = 0;
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-  return cus[dev] = n;
 }
 struct HoistPlan {
   bool ok;

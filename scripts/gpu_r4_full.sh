@@ -36,7 +36,7 @@ run cg_round3_product --debug packed_chain=0
 run cg_gram_launch --debug packed_gram=0
 run cg_graw_v1 --debug graw_v2=0
 run cg_pstep_v1 --debug pstep_v2=0
-run cg_depth2 --debug packed_depth=2
+run cg_depth3 --debug packed_depth=3
 run neumann_fused --algo neumann --cg-iters 10
 run neumann_round3_product --algo neumann --cg-iters 10 --debug packed_chain=0
 run cg_keep_solution --keep-solution

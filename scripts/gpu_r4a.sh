@@ -12,12 +12,12 @@ d=json.loads(open('$O/bench_$tag.json').read().strip().splitlines()[-1]); print(
 run default
 run unpacked --debug packed_chain=0
 run gram_launch --debug packed_gram=0
-run depth2 --debug packed_depth=2
-run depth4 --debug packed_depth=4
+run depth3 --debug packed_depth=3
 run default_again
-run alpha_launch --debug alpha_in_hoist=0
 run graw_v1 --debug graw_v2=0
 run pstep_v1 --debug pstep_v2=0
+run ragged_always --debug wskp_ragged=2
+run ragged_never --debug wskp_ragged=0
 
 run neumann --algo neumann --cg-iters 10
 run neumann_unpacked --algo neumann --cg-iters 10 --debug packed_chain=0
