@@ -8,7 +8,7 @@ mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
 for ARM in fused; do
   EXTRA=""; [ $ARM = nofuse ] && EXTRA="--no-fuse"
   for C in FETCH_SIZE WRITE_SIZE; do
-    cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${ARM}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-kernel-timing --no-slope $EXTRA > /tmp/pmc_${ARM}_$C.log 2>&1; echo "$ARM $C rc=$?"
+    cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${ARM}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-kernel-timing --no-slope --no-parity $EXTRA > /tmp/pmc_${ARM}_$C.log 2>&1; echo "$ARM $C rc=$?"
   done
 done
 cd $GRAFT_REPO_ROOT
@@ -39,13 +39,13 @@ for arm in ("fused",):
         n = (fe.get(k) or wr.get(k))[0]
         tab[k] = {"launches": n, "fetch_bytes": 2 * 1024 * (fe.get(k, (0, 0))[1]), "write_bytes": 1024 * (wr.get(k, (0, 0))[1])}
     out["per_kernel"][arm] = tab
-    loop = [k for k in tab if any(s in k for s in ("k_gemm", "k_hoist", "k_wsk_group", "k_wskp", "k_graw", "k_pstep", "k_pack", "k_proj_", "k_reduce_mask", "k_head_forward<true", "k_outer", "k_cg_alpha", "k_cg_beta", "k_cg_pdir", "k_bias", "k_head_outer", "k_cg_resident"))]
-    # bytes per CG iteration = sum over loop kernels of (avg bytes per launch x launches) / (steps x K); the once-per-step
-    # passes use some of the same kernels (forward / backward / mixed coefficient), so this is an upper bound
-    tot = sum((tab[k]["fetch_bytes"] + tab[k]["write_bytes"]) * tab[k]["launches"] for k in loop) / (steps * K)
-    out["traffic_bytes"]["cg_iter_fused" if arm == "fused" else "cg_iter_unfused"] = tot
-    if arm == "nofuse" and "k_cg_resident" in tab:
-        out["traffic_bytes"]["k_cg_resident"] = tab["k_cg_resident"]["fetch_bytes"] + tab["k_cg_resident"]["write_bytes"]
+    # the seven steady-state launches of a projected iteration; everything else is once per solve
+    loop = [k for k in tab if k.startswith(("k_wskpc", "k_graw", "k_pstep")) or k == "k_head_forward<true, 3, true, true>"]
+    solves = tab["k_cg_init"]["launches"] if "k_cg_init" in tab else steps
+    tot = sum((tab[k]["fetch_bytes"] + tab[k]["write_bytes"]) * tab[k]["launches"] for k in loop) / (solves * K)
+    out["traffic_bytes"]["cg_iter_fused"] = tot
+    out["traffic_bytes"]["outside_the_iterations_per_step"] = sum((tab[k]["fetch_bytes"] + tab[k]["write_bytes"]) * tab[k]["launches"] for k in tab if k not in loop) / solves
+    out["steady_state_kernels"] = loop
 json.dump(out, open("gpurun_out/pmc/r04_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["traffic_bytes"], indent=1))
 for arm in out["per_kernel"]:

@@ -48,5 +48,6 @@ run cg_global_ws1 --mode global
 BHG_ALL_RANKS_ON_GPU0=1 timeout 300 python bench.py --gpus 2 --dist-backend gloo --steps 40 --cpu-steps 0 2> $O/bench_selflaunch_2ranks_one_gpu_gloo.err > $O/bench_selflaunch_2ranks_one_gpu_gloo.json; echo "self-launch --gpus 2 rc=$?"; tail -c 400 $O/bench_selflaunch_2ranks_one_gpu_gloo.json
 BHG_LIB=$GRAFT_REPO_ROOT/betty_amd/csrc/libbhg_stamps.so timeout 200 python scripts/stamp_trace.py 2>&1 | grep -vE "Warning|warn" | tee $O/stamps_default.txt
 [ -x build_probes/chain_probe ] && timeout 120 ./build_probes/chain_probe > $O/chain_probe.txt 2>&1
+timeout 400 python scripts/opaque_compare.py 2>&1 | grep -E "^cfg" | tee $O/opaque_product_vs_reference_on_gpu.txt
 bash scripts/gpu_pmc4.sh 2>&1 | tail -30
 bash scripts/gpu_pmc_sq4.sh 2>&1 | tail -14
