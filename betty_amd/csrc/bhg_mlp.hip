@@ -474,6 +474,21 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
 
 // Workgroups (= raw.raw partials) of the G(raw) launch: a product with two operand pairs takes one workgroup per pair and tile
 // unless BHG_PROJ_GRAW_SPLIT=0 (only the first layer's forward product has a single pair).
+// column tile of k_graw: 32, or 64 (debug key graw_cols = 64; every product's width must allow it).  Same-box A/B at cfg 2, twice:
+// 667.4 / 668.0 steps/s with 32 columns, 660.3 / 661.6 with 64 — the 64-column workgroup has its CU to itself and its phases
+// (operands 4.6 us, MFMAs 4.1 us, epilogue 2.9 us; stamps) no longer overlap with another workgroup's.
+int graw_cols(const HoistPlan* hp) {
+  if (dbg(DBG_graw_cols, 32) != 64) return 32;
+  for (int i = 0; i < hp->n; ++i)
+    if (hp->N[i] % 64) return 32;
+  return 64;
+}
+int graw_tile_count(const HoistPlan* hp, int Bp) {
+  const int ct = graw_cols(hp);
+  int t = 0;
+  for (int i = 0; i < hp->n; ++i) t += (Bp / 64) * (hp->N[i] / ct);
+  return t;
+}
 int graw_blocks(const HoistPlan* hp, int Bp) {
   int n = 0;
   for (int i = 0; i < hp->n; ++i) {
@@ -688,6 +703,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   // graw_single: what the NEXT iteration's recurrences are told about the layout of G(raw) (one slab per product, not one per pair)
   const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 && Bp == 128;   // (k_graw: K = 128)
   const bool graw2 = gram_in_chain && graw_single;
+  // rnew: k_graw applies r' = r - alpha Hp to G(r) itself (GrawArgs.rnew) — like graw_single, what the NEXT iteration's recurrences
+  // are told (G(r) is up to date, there is no G(raw)); the conditions are those of the step length computed inside k_graw
+  const bool rnew = graw_single && cg && cm.proj >= 2 && cm.gphase == 0 && dbg(DBG_proj_small_alone, 0) == 0 &&
+                    dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0;
   // Gram products riding in chain launches: ONE K slab each — every rider sits in a launch whose tiles have the same K (T_1 with
   // the forward product through W_1; E_l and T_{l+1} with the backward product through W_l), so it ends when they do
   auto tsplit = [&](int K) { return gram_in_chain ? 1 : gram_ksplit(K); };
@@ -737,6 +756,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         q.Gr = hbase + (cg ? hp->gr_off[i] : hp->g_off[i]); q.Gp = hbase + hp->g_off[i]; q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
         // (products with two operand pairs leave one slab per pair, see the G(raw) launch)
         if (!graw_single && graw_split() && !(hp->bwd[i] == 0 && hp->layer[i] == 0)) q.Graw2 = q.Graw + (size_t)Bp * hp->N[i];
+        if (rnew) q.Graw = nullptr;   // (the last iteration's k_graw left r' in G(r))
         if (!hp->bwd[i] && hp->layer[i] == 0) {
           q.bias = static_cast<const float*>(dir[1]); q.mask = m->mask[0]; q.out = m->Rh[0];
           q.outp = packed ? cm.ws->Rhp[0] : nullptr;
@@ -752,8 +772,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
         sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
         if (graw_single) {   // the last iteration closed with k_graw: three partials per tile workgroup
-          sa.part_dot = cm.ws->part_graw; sa.dot_blocks = hp->graw_tiles;
-          sa.part_raw = cm.ws->part_graw + 2 * (size_t)hp->graw_tiles; sa.raw_blocks = hp->graw_tiles;
+          const int gt = graw_tile_count(hp, Bp);
+          sa.part_dot = cm.ws->part_graw; sa.dot_blocks = gt;
+          sa.part_raw = cm.ws->part_graw + 2 * (size_t)gt; sa.raw_blocks = gt;
         }
         sa.part = cm.beta->part; sa.part_stride = cm.ws->nRR;   // the last iteration's epilogue partials (= its partRR_new)
         sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blocks(m);
@@ -769,7 +790,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (graw_single && cm.beta->nt <= 16 && dbg(DBG_pstep_v2, 1) != 0) {   // the same work, arguments laid out for two round trips
           PstepArgs ps{};
           PstepHdr& h = ps.h;
-          for (int i = 0; i <= hp->n; ++i) h.blk0[i] = pa.blk0[i];
+          // U float4s per thread of an update block: every block repeats the scalar phase (~12 KB of partials), so fewer, fatter
+          // blocks (944 -> 238 at cfg 2) repeat it less often
+          const int pu = dbg(DBG_pstep_unroll, 4);
+          const int U = pu >= 4 ? 4 : (pu >= 2 ? 2 : 1);
+          int ublk = 0;
+          for (int i = 0; i < hp->n; ++i) { h.blk0[i] = ublk; ublk += (Bp * (hp->N[i] / 4) + 256 * U - 1) / (256 * U); }
+          h.blk0[hp->n] = ublk;
+          const int rblk = ublk;   // (shadows the one-float4-per-thread count of k_proj_step / k_hoist_reduce)
           h.n = pa.n; h.Bp = pa.Bp; h.B = pa.B; h.kpar_prev = pa.kpar_prev; h.shift = pa.shift; h.update_blocks = rblk;
           h.scal = sa.scal; h.r_b0 = g.r_b0; h.p0_rd = g.p0_rd; h.p0_wr = g.p0_wr; h.r_small = sa.r_small; h.p_small = sa.p_small;
           h.part_dot = sa.part_dot; h.part_raw = sa.part_raw; h.part = sa.part; h.pscal = sa.pscal;
@@ -780,7 +808,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
             ps.p[i] = {q.Gr, q.Gp, q.Graw, q.bias, q.mask, q.out, q.outp, q.N, 0};
           }
           for (int t = 0; t < sa.snt; ++t) { ps.t.slen[t] = sa.slen[t]; ps.t.soff[t] = sa.soff[t]; }
-          hipLaunchKernelGGL(k_pstep, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+          if (U == 4) hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+          else if (U == 2) hipLaunchKernelGGL(k_pstep<2>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+          else hipLaunchKernelGGL(k_pstep<1>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
         } else
         hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
       } else {
@@ -1167,7 +1197,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       if (graw2) {   // round 4: packed Gram matrices -> k_graw (64 x 32 tiles, inner products in the tile epilogue, one slab per product)
         GrawArgs ka{};
-        int gb = (small_blocks + 15) & ~15;   // (the small slices' blocks lead the grid; every table entry a multiple of 16)
+        const int ct = graw_cols(hp);
+        // CT = 32: the small slices' blocks lead the grid; CT = 64: the tiles do (one CU each), the small blocks fill second slots
+        const bool small_first = ct == 32;
+        int gb = small_first ? (small_blocks + 15) & ~15 : 0;   // (every table entry a multiple of 16)
         int real_tiles = 0;
         for (int i = 0; i < hp->n; ++i) {
           const int l = hp->layer[i];
@@ -1186,16 +1219,23 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           }
           q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
           q.pb0 = real_tiles;
-          real_tiles += (Bp / 64) * (hp->N[i] / 32);
-          ka.blk0[i] = gb; gb += (((Bp / 64) * (hp->N[i] / 32)) + 15) & ~15;
+          real_tiles += (Bp / 64) * (hp->N[i] / ct);
+          ka.blk0[i] = gb; gb += (((Bp / 64) * (hp->N[i] / ct)) + 15) & ~15;
         }
-        ka.blk0[hp->n] = gb;
-        BHG_REQUIRE(real_tiles == hp->graw_tiles, "tile count of k_graw and of the plan disagree");
+        ka.blk0[hp->n] = gb; ka.tile_end = gb;
+        BHG_REQUIRE(real_tiles == graw_tile_count(hp, Bp) && real_tiles <= hp->graw_tiles, "tile count of k_graw and of the plan disagree");
         ka.n = hp->n; ka.Bp = Bp; ka.B = B;
-        ka.part = cm.ws->part_graw; ka.npart = hp->graw_tiles;
+        ka.part = cm.ws->part_graw; ka.npart = real_tiles;
         ka.small_blocks = small_blocks; ka.so = so;
+        ka.small0 = small_first ? 0 : gb;
+        if (!small_first) gb += small_blocks;
         if (alpha_in_hoist) { ka.do_alpha = 1; ka.alpha = aa; }
-        if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        BHG_REQUIRE(!rnew || (alpha_in_hoist && full), "k_graw was to apply the residual step but has no step length");
+        ka.rnew = rnew ? 1 : 0;
+        if (ct == 64) {
+          if (cg) hipLaunchKernelGGL(k_graw64<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+          else hipLaunchKernelGGL(k_graw64<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        } else if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
         else hipLaunchKernelGGL(k_graw<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
       }
       HoistArgs ga{};
@@ -1300,8 +1340,9 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       sa.part_dot = cm.ws->part_dot; sa.dot_blocks = hp->dot_blocks;
       sa.part_raw = cm.ws->part_raw; sa.raw_blocks = graw_blocks(hp, Bp);
       if (graw_single) {
-        sa.part_dot = cm.ws->part_graw; sa.dot_blocks = hp->graw_tiles;
-        sa.part_raw = cm.ws->part_graw + 2 * (size_t)hp->graw_tiles; sa.raw_blocks = hp->graw_tiles;
+        const int gt = graw_tile_count(hp, Bp);
+        sa.part_dot = cm.ws->part_graw; sa.dot_blocks = gt;
+        sa.part_raw = cm.ws->part_graw + 2 * (size_t)gt; sa.raw_blocks = gt;
       }
       sa.part = cm.partRR_new; sa.part_stride = cm.ws->nRR;
       sa.off0 = part_base_w[L - 1]; sa.n0 = outer_blocks(m, L - 1, head); sa.off1 = part_base_bias; sa.n1 = bias_blk;

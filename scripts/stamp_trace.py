@@ -40,8 +40,8 @@ def show(name, kid, classes):
     t0 = a[live, 0].min()
     end = a[live, 4].max()
     print(f"{name}: {int(live.sum())} workgroups, span {(end - t0) * 0.01:.2f} us")
-    for cname, lo, hi in classes:
-        sel = a[lo:hi][a[lo:hi, 0] > 0]
+    for cname, pick in classes:
+        sel = a[live][pick(a[live])]
         if len(sel) == 0:
             continue
         rel = (sel - t0) * 0.01
@@ -50,7 +50,7 @@ def show(name, kid, classes):
             v = rel[:, s][sel[:, s] > 0]
             cols.append("   -   " if len(v) == 0 else f"{np.median(v):5.2f}/{v.max():5.2f}")
         print(f"   {cname:22s} n={len(sel):4d}  entry {cols[0]}  s1 {cols[1]}  s2 {cols[2]}  s3 {cols[3]}  exit {cols[4]}   (median/max us since the launch's first stamp)")
-# block classes at cfg 2: k_graw = 124 small blocks (60 head + 64 bias) then 472 tiles; k_proj_step = 975 update blocks + small
-show("k_graw", 0, [("head outer (alpha)", 0, 60), ("bias (alpha)", 60, 124), ("tiles Gf_0 (1 pair)", 124, 124 + 128), ("tiles rest", 124 + 128, 124 + 472)])
-nb = int((st[1][:, 0] > 0).sum())
-show("k_proj_step", 1, [("update blocks", 0, 944), ("small blocks", 944, nb)])
+# classes by which slots a workgroup stamped: k_graw's tile workgroups stamp s2 (MFMAs done) and s3, its small-slice blocks only
+# s1 (step length known); k_pstep's update blocks stamp s1 (beta known), its small blocks do not
+show("k_graw", 0, [("small slices (alpha)", lambda a: (a[:, 2] == 0) & (a[:, 4] > 0)), ("tiles", lambda a: a[:, 2] > 0)])
+show("k_pstep", 1, [("update blocks", lambda a: a[:, 1] > 0), ("small blocks", lambda a: (a[:, 1] == 0) & (a[:, 4] > 0))])
