@@ -289,6 +289,23 @@ int pick_splits(int tiles, int K, int pairs) {
 #include "mlp/graw.inc"   // round 4: the closing launch of a projected iteration on packed Gram matrices (k_graw)
 
 #include "mlp/pstep.inc"   // round 4: k_proj_step with its kernel arguments in two scalar-memory round trips (k_pstep)
+#include "mlp/wskpl.inc"   // round 4: the chain's first product by linearity, with the update launch riding in it (k_wskpl)
+
+// One chain product (no riders) with `nu` update blocks leading its grid (k_wskpu).  Tiling as WskpBuilder::launch does it.
+void launch_wskpu(const WskpProb& q_in, const PstepArgs& ps, int nu, hipStream_t st) {
+  WskpuArgs u{};
+  WskpProb q = q_in;
+  const int mode = dbg(DBG_wskp_ragged, 1);
+  wskp_tiling(&q, mode == 2);
+  int blk = (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
+  if (mode == 1 && blk > chip_cus()) {
+    wskp_tiling(&q, true);
+    blk = (((q.nfull * (q.RB / 32) + q.nstrip) * q.nsplit) + 7) & ~7;
+  }
+  u.c.a = q; u.c.na = blk;
+  u.nu = nu; u.ps = ps;
+  hipLaunchKernelGGL((k_wskpu<2, 4>), dim3(nu + blk), dim3(64 * kWskpWaves), 0, st, u);
+}
 
 // ---- per-device side stream + events -------------------------------------------------------------------------------
 struct SideState {
@@ -371,6 +388,9 @@ struct HoistPlan {
   size_t sp_off[BHG_MLP_MAX_LAYERS], dp_off[BHG_MLP_MAX_LAYERS];         // the same four, PACKED ([Bp/16][Bp][16]: k_graw's M-side
   size_t tslabp_off[BHG_MLP_MAX_LAYERS], eslabp_off[BHG_MLP_MAX_LAYERS]; // operands; two slabs at most)
   int graw_tiles;                                                        // 64 x 32 tiles of the G(raw) launch (k_graw)
+  // the chain's first product by linearity (k_wskpl; L >= 4 and the projected forms only): Z(p) = Rh_0(p) W_1^T in two slots by
+  // iteration parity, packed Rh_0(r'), the second slot of Gf_1(p) (slot 0 is g_off[gf[1]]), a copy of r|b0
+  size_t z1_off[2], rh0rp_off, gp1alt_off, rb0c_off; bool lin_ok;
   bool proj_ok;                                                          // the projected solvers pay off and fit (cost model below)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
@@ -465,6 +485,13 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
       hp->eslabp_off[l] = off; off += (size_t)2 * Bp * Bp;
     }
   }
+  hp->lin_ok = hp->proj_ok && L >= 4;
+  if (hp->lin_ok) {
+    for (int i = 0; i < 2; ++i) { hp->z1_off[i] = off; off += (size_t)Bp * m->dims[2]; }
+    hp->rh0rp_off = off; off += (size_t)Bp * m->dims[1];
+    hp->gp1alt_off = off; off += (size_t)Bp * m->dims[2];
+    hp->rb0c_off = off; off += (size_t)((m->dims[1] + 63) & ~63);
+  }
   hp->graw_tiles = 0;
   for (int i = 0; i < n; ++i) hp->graw_tiles += (Bp / 64) * (hp->N[i] / 32);
   hp->blk0[n] = blk;
@@ -515,6 +542,8 @@ struct FusedWs {
   double* part_raw;                 // fully projected CG: [raw_blocks] partials of raw.raw (tiles of the G(raw) launch)
   double* part_graw;                // k_graw: [3][graw_tiles] partials of r.raw, p.raw, raw.raw
   float* pb0[2];                    // fully projected CG: the first bias's slice of the direction, two slots by iteration parity (k_proj_step)
+  float* pb1[2];                    // the second bias's slice likewise (k_wskpl)
+  unsigned long long* gran;         // 64 granules of 64 bytes: beta, published inside k_wskpl for its own tiles
   // packed operands of the chain and of the Gram products (wskp.inc); NULL when the hoisted forms do not apply
   float* Wf[BHG_MLP_MAX_LAYERS];    // W_l as the N-side operand of the forward chain   [d_l / 16][d_{l+1}][16],  l = 1 .. L-2
   float* Wb[BHG_MLP_MAX_LAYERS];    // W_l^T as the N-side operand of the backward chain [d_{l+1} / 16][d_l][16]
@@ -551,6 +580,8 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
   w->part_graw = static_cast<double*>(take(sizeof(double) * 3 * (hp.ok ? hp.graw_tiles : 1)));
   w->pscal = static_cast<double*>(take(sizeof(double) * 8));
   for (int i = 0; i < 2; ++i) w->pb0[i] = static_cast<float*>(take(sizeof(float) * (size_t)m->dims[1]));
+  for (int i = 0; i < 2; ++i) w->pb1[i] = static_cast<float*>(take(sizeof(float) * (size_t)(m->L >= 2 ? m->dims[2] : 1)));
+  w->gran = static_cast<unsigned long long*>(take(64 * 64));
   if (hp.ok) {
     const int L = m->L;
     const size_t Bp = (size_t)m->Bp;
@@ -630,6 +661,7 @@ struct ChainMode {
   //   gphase 2: step length from the all-reduced php[0] * inv_world, then the outputs with their epilogues
   int gphase; double* php; double inv_world;
   int second;                   // fully projected CG: iteration 1 (the scalars k_proj_step completes are those of the FIRST iteration)
+  int lin;                      // fully projected CG: the chain's first product by linearity, update launch inside it (k_wskpl; cg_ctx_init decides)
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -707,6 +739,16 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   // are told (G(r) is up to date, there is no G(raw)); the conditions are those of the step length computed inside k_graw
   const bool rnew = graw_single && cg && cm.proj >= 2 && cm.gphase == 0 && dbg(DBG_proj_small_alone, 0) == 0 &&
                     dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0;
+  // lin: the chain's first product by linearity with the update launch riding in it (k_wskpl, wskpl.inc) — like rnew a property of
+  // the whole solve: every iteration's first product, every k_graw (Rh_0(r') for the next one) and cg_iteration (the second bias's
+  // direction in slots) follow it
+  const bool lin = cm.lin != 0;
+  BHG_REQUIRE(!lin || (rnew && hp && hp->lin_ok && cm.beta && cm.beta->nt <= 16 && proj_step_merged() && L >= 4),
+              "the linear first product was planned for a solve that cannot run it");
+  PstepArgs lin_ps{};   // the update blocks' arguments, built where k_pstep would be launched, used by the first product's launch
+  int lin_nu = 0, lin_U = 4;
+  bool lin_update_pending = false;   // the update blocks ride in the launch after the first product (k_wskpu)
+  auto gp1 = [&](int par) { return cm.ws->hoist + (par ? hp->gp1alt_off : hp->g_off[hp->gf[1]]); };   // Gf_1(p): two slots (lin)
   // Gram products riding in chain launches: ONE K slab each — every rider sits in a launch whose tiles have the same K (T_1 with
   // the forward product through W_1; E_l and T_{l+1} with the backward product through W_l), so it ends when they do
   auto tsplit = [&](int K) { return gram_in_chain ? 1 : gram_ksplit(K); };
@@ -792,7 +834,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           PstepHdr& h = ps.h;
           // U float4s per thread of an update block: every block repeats the scalar phase (~12 KB of partials), so fewer, fatter
           // blocks (944 -> 238 at cfg 2) repeat it less often
-          const int pu = dbg(DBG_pstep_unroll, 4);
+          const int pu = lin ? 4 : dbg(DBG_pstep_unroll, 4);
           const int U = pu >= 4 ? 4 : (pu >= 2 ? 2 : 1);
           int ublk = 0;
           for (int i = 0; i < hp->n; ++i) { h.blk0[i] = ublk; ublk += (Bp * (hp->N[i] / 4) + 256 * U - 1) / (256 * U); }
@@ -805,10 +847,32 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           h.off0 = sa.off0; h.n0 = sa.n0; h.off1 = sa.off1; h.n1 = sa.n1; h.first = sa.first; h.kpar = sa.kpar; h.snt = sa.snt;
           for (int i = 0; i < hp->n; ++i) {
             const ProjProb& q = pa.p[i];
-            ps.p[i] = {q.Gr, q.Gp, q.Graw, q.bias, q.mask, q.out, q.outp, q.N, 0};
+            ps.p[i] = {q.Gr, q.Gp, q.Graw, q.bias, q.mask, q.out, q.outp, q.N, q.Graw ? 1 : 0};
+            if (lin && i == hp->gf[1]) { ps.p[i].Gp = gp1(cm.kpar ^ 1); ps.p[i].X = gp1(cm.kpar); ps.p[i].xkind = 2; }
+            if (lin) ps.p[i].outp = nullptr;   // (nobody reads a packed Rh_0(p): the first product runs on Rh_0(r'))
+          }
+          if (lin) {
+            h.p1_rd = cm.second ? cm.fd + cm.starts[3] : cm.ws->pb1[cm.kpar ^ 1];
+            h.p1_wr = cm.ws->pb1[cm.kpar];
+            h.gran = cm.ws->gran;
+            h.rb0_copy = hbase + hp->rb0c_off;
+            h.prio = dbg(DBG_lin_prio, 0);
+            // launched update blocks (debug key lin_nub; 0 = one per virtual block): few, fat blocks leave most CUs to the tiles
+            // (1 = as many as leave the launch ONE workgroup per CU with the ragged row tiling: that instance needs 288 registers)
+            int nub = dbg(DBG_lin_nub, 0);
+            if (nub > 0) {
+              WskpProb tq{};
+              tq.RA = Bp; tq.RB = m->dims[2]; tq.B = B; tq.nsplit = 1;
+              wskp_tiling(&tq, true);
+              const int tiles = ((tq.nfull * (tq.RB / 32) + tq.nstrip + 7) & ~7) + (Bp / 32) * (Bp / 32);
+              const int room = chip_cus() - tiles - sgrid;
+              if (nub == 1 || nub > room) nub = room;
+            }
+            h.nub = (nub > 0 && nub < rblk) ? nub : 0;
           }
           for (int t = 0; t < sa.snt; ++t) { ps.t.slen[t] = sa.slen[t]; ps.t.soff[t] = sa.soff[t]; }
-          if (U == 4) hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+          if (lin) { lin_ps = ps; lin_nu = (h.nub > 0 ? h.nub : rblk) + sgrid; lin_U = U; }
+          else if (U == 4) hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
           else if (U == 2) hipLaunchKernelGGL(k_pstep<2>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
           else hipLaunchKernelGGL(k_pstep<1>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
         } else
@@ -825,6 +889,60 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const float* c = static_cast<const float*>(dir[2 * l + 1]);
       const float* Gf = hbase + hp->g_off[hp->gf[l]];
       if (packed) {
+      if (lin && l == 1) {   // by linearity on Rh_0(r'), the update blocks in the same launch (wskpl.inc)
+        BHG_REQUIRE(cm.first || lin_nu > 0, "no update blocks for the linear first product");
+        WskplArgs la{};
+        WskpProb& q = la.a;
+        q.Ap = cm.first ? cm.ws->Rhp[0] : hbase + hp->rh0rp_off;   // (first iteration: p = r, Rh_0 from the N-sized pass)
+        q.Bq = cm.ws->Wf[1]; q.RA = Bp; q.RB = N; q.K = K; q.B = B; q.nsplit = 1;
+        q.mask = m->mask[1]; q.out = m->Rh[1]; q.outp = cm.ws->Rhp[1];
+        q.znew = hbase + hp->z1_off[cm.kpar];
+        if (cm.first) { q.addend = Gf; q.bias = c; }
+        else {
+          q.addend = hbase + hp->gr_off[hp->gf[1]]; q.addend2 = gp1(cm.kpar ^ 1);
+          q.bias = cm.fa + cm.starts[3]; q.bias2 = lin_ps.h.p1_rd;
+          q.zold = hbase + hp->z1_off[cm.kpar ^ 1];
+          q.gran = cm.ws->gran;
+        }
+        const int rider_blocks = gram_in_chain ? (Bp / 32) * (Bp / 32) : 0;
+        wskp_tiling(&q, false);
+        int na = (q.nfull * (q.RB / 32) + q.nstrip + 7) & ~7;
+        if (dbg(DBG_wskp_ragged, 1) == 2 || (dbg(DBG_wskp_ragged, 1) == 1 && na + rider_blocks > chip_cus()) ||
+            (!cm.first && lin_ps.h.nub > 0)) {
+          wskp_tiling(&q, true);
+          na = (q.nfull * (q.RB / 32) + q.nstrip + 7) & ~7;
+        }
+        la.na = na;
+        if (gram_in_chain) {   // T_1 = h_1 Rh_0^T, linear as well: T_1(p') = T_1(r') + beta T_1(p); two slots by parity
+          float* tnew = hbase + hp->tslab_off[1] + (size_t)cm.kpar * Bp * Bp;
+          float* tnewp = graw2 ? hbase + hp->tslabp_off[1] + (size_t)cm.kpar * Bp * Bp : nullptr;
+          la.r0 = {cm.ws->hpk[1], q.Ap, tnew, tnewp, K, 0};
+          la.r0_old = cm.first ? nullptr : hbase + hp->tslab_off[1] + (size_t)(cm.kpar ^ 1) * Bp * Bp;
+        }
+        la.nu = cm.first ? 0 : lin_nu;
+        // (debug key lin_order = 1: small blocks, tiles, update blocks — measured 66 us per iteration against 59.7: the update waves,
+        //  dispatched last, are the YOUNGEST on their SIMDs and lose every arbitration to the tiles' waves; dispatched first they win it)
+        // update blocks in the NEXT launch — when that is the pre-head product (L = 4), whose tiles leave raw K-split slabs and read
+        // nothing the update blocks write; a deeper net's second product adds Gf_2(p) in its epilogue, so its update blocks stay here
+        const bool upd_next = !cm.first && L == 4 && dbg(DBG_lin_update_next, 1) != 0 && lin_ps.h.nub == 0;
+        if (upd_next) {   // only the small slices' blocks (the first publishes beta) ride here, ahead of the tiles
+          la.ns = lin_nu - lin_ps.h.update_blocks;
+          la.nt = na + rider_blocks;
+        } else
+        if (!cm.first && dbg(DBG_lin_order, 0) != 0) {
+          la.ns = lin_nu - (lin_ps.h.nub > 0 ? lin_ps.h.nub : lin_ps.h.update_blocks);
+          la.nt = na + rider_blocks;
+        }
+        la.ps = lin_ps;
+        const int grid = (upd_next ? la.ns : la.nu) + na + rider_blocks;
+        lin_update_pending = upd_next;
+        BHG_REQUIRE(cm.first || lin_U == 4, "the update blocks inside k_wskpl are built for four float4 per thread");
+        if (la.ps.h.nub > 0) hipLaunchKernelGGL((k_wskpl<2, 4, true>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
+        else hipLaunchKernelGGL((k_wskpl<2, 4, false>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
+        if (cm.first)   // r|b0 as k_graw's tiles will read it (its bias blocks update the slice in the same launch)
+          BHG_HIP_CHECK(hipMemcpyAsync(hbase + hp->rb0c_off, cm.fa + cm.starts[1], sizeof(float) * (size_t)m->dims[1],
+                                       hipMemcpyDeviceToDevice, st));
+      } else {
         WskpBuilder wb;
         WskpProb q{};
         q.Ap = cm.ws->Rhp[l - 1]; q.Bq = cm.ws->Wf[l]; q.RA = Bp; q.RB = N; q.K = K; q.B = B; q.nsplit = 1;
@@ -851,7 +969,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           t.nsplit = 1; t.raw = 1; t.out = hbase + hp->tslab_off[l]; t.outp = graw2 ? hbase + hp->tslabp_off[l] : nullptr;
           wb.add(t);
         }
-        wb.launch(st);
+        if (lin_update_pending && wb.g.n == 1) {   // (l = 2: nothing this product reads is written by the update blocks)
+          launch_wskpu(wb.g.p[0], lin_ps, lin_ps.h.update_blocks, st);
+          lin_update_pending = false;
+        } else wb.launch(st);
+      }
         if (gram_in_chain && cm.first && l == 1) {   // once per solve: S_l = h_l h_l^T, D_l = delta_l delta_l^T (launches of their own:
           WskpBuilder sb;                            // beside the first chain product they would stretch it — K up to d_0)
           for (int j = 0; j + 1 < L; ++j) {
@@ -886,6 +1008,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         launch_gemm_wsk<LAYOUT_KC>(w, st, K >= staged_mink);
       }
     }
+    BHG_REQUIRE(!lin_update_pending, "the update blocks found no launch to ride in");
     {
       const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
       launch_head_forward(st, Bp, (const float*)m->Rh[l - 1], m->h[l], m->W[l], static_cast<const float*>(dir[2 * l]),
@@ -1053,6 +1176,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     ba.blk0[L] = bias_blk;
     // fully projected CG (k_proj_step): the first bias's slice of the direction lives in the slot dir[1] names
     if (cg && cm.proj >= 2 && hp && proj_step_merged()) ba.d0 = static_cast<const float*>(dir[1]);
+    if (lin) ba.d1 = static_cast<const float*>(dir[3]);
   }
   FuseArgs bias_fz = fbase;
   bias_fz.a = cm.fa; bias_fz.b = cm.fb; bias_fz.d = cm.fd; bias_fz.part_base = part_base_bias;   // offsets travel in ba.foff
@@ -1190,7 +1314,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           so.ba.foff[l] = ba.foff[l];
         }
         so.ba.blk0[L] = ba.blk0[L];
-        so.ba.d0 = ba.d0;
+        so.ba.d0 = ba.d0; so.ba.d1 = lin ? static_cast<const float*>(dir[3]) : nullptr;
         so.bf = bias_fz;
         so.bias_blocks = bias_blk;
         small_blocks = so.head_blocks + bias_blk;
@@ -1207,14 +1331,14 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           GrawProb& q = ka.p[i];
           if (!hp->bwd[i]) {   // Gf_l(raw) = S_l Rd_l + T_l delta_l
             q.A1 = hbase + hp->sp_off[l]; q.B1 = m->Rd[l];
-            if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l]; q.B2 = m->delta[l]; }
+            if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l] + ((lin && l == 1) ? (size_t)cm.kpar * Bp * Bp : 0); q.B2 = m->delta[l]; }
           } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
             q.A1 = hbase + hp->eslabp_off[l]; q.B1 = m->h[l];
             q.A2 = hbase + hp->dp_off[l]; q.B2 = m->Rh[l - 1];
           }
           q.Gr = q.Gp = q.B1;   // (always loadable)
           if (full) {           // the inner products' partner: Rd_l (= B1) forward, Rh_{l-1} (= B2) backward
-            q.Gr = hbase + hp->gr_off[i]; q.Gp = hbase + hp->g_off[i];
+            q.Gr = hbase + hp->gr_off[i]; q.Gp = (lin && i == hp->gf[1]) ? gp1(cm.kpar) : hbase + hp->g_off[i];
             q.dots = hp->bwd[i] ? 2 : 1;
           }
           q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
@@ -1232,6 +1356,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (alpha_in_hoist) { ka.do_alpha = 1; ka.alpha = aa; }
         BHG_REQUIRE(!rnew || (alpha_in_hoist && full), "k_graw was to apply the residual step but has no step length");
         ka.rnew = rnew ? 1 : 0;
+        if (lin) {   // Rh_0(r') for the next iteration's first product; beta's granules cleared for its publication
+          ka.rh0p = hbase + hp->rh0rp_off; ka.mask0 = m->mask[0]; ka.rb0 = hbase + hp->rb0c_off;
+          ka.pb0s = static_cast<const float*>(dir[1]); ka.gran = cm.ws->gran; ka.rh0_prod = hp->gf[0];
+        }
         if (ct == 64) {
           if (cg) hipLaunchKernelGGL(k_graw64<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
           else hipLaunchKernelGGL(k_graw64<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
@@ -1474,7 +1602,7 @@ struct CgCtx {
   const bhg_mlp* m; float* x; float* r; float* p; const int64_t* starts; const bhg_chunk* chunks_dev; int n_chunks, K;
   float cg_alpha, shift;
   FusedWs w; double* scal; const double* partR0; int n_init, pgrid, bgrid;
-  bool lazy, hoist; int proj_level;
+  bool lazy, hoist, lin; int proj_level;
   BetaArgs ba; HoistPlan hplan;
   const void* dir[2 * BHG_MLP_MAX_LAYERS];
 };
@@ -1514,6 +1642,11 @@ static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p
   // 2 = fully projected (default without a solution vector): no N-sized state after the first iteration
   // (BHG_MLP_PROJ: 0 off | 1 default | 9 level 1 even without a solution vector — the A/B arm of level 2)
   c->proj_level = (!c->hoist || !c->hplan.proj_ok || proj_mode() == 0 || global) ? 0 : ((proj_mode() == 9 || x) ? 1 : 2);
+  // the chain's first product by linearity (k_wskpl): fully projected CG closing with k_graw that applies the residual step (the
+  // conditions of run_chain's graw_single and rnew), a net with a product between the first and the pre-head one, few small tensors
+  c->lin = c->proj_level == 2 && c->hplan.lin_ok && packed_chain_on(c->w) && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 &&
+           m->Bp == 128 && dbg(DBG_proj_small_alone, 0) == 0 && dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0 &&
+           c->ba.nt <= 16 && proj_step_merged() && dbg(DBG_pstep_v2, 1) != 0 && dbg(DBG_lin_first, 1) != 0;
 }
 // gphase 0: the whole iteration (one rank) | 1: up to this rank's p.H_data p | 2: from the step length on (see ChainMode)
 static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_world, hipStream_t st) {
@@ -1560,6 +1693,8 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
   cm.second = k == 1;
   if (c->proj_level == 2 && proj_step_merged())   // the first bias's direction: flat p in iteration 0, then the slot of the parity
     c->dir[1] = k == 0 ? static_cast<const void*>(c->p + c->starts[1]) : static_cast<const void*>(w.pb0[k & 1]);
+  if (c->lin) c->dir[3] = k == 0 ? static_cast<const void*>(c->p + c->starts[3]) : static_cast<const void*>(w.pb1[k & 1]);
+  cm.lin = c->lin ? 1 : 0;
   if (int rc = run_chain(m, c->dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)

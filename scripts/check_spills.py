@@ -42,6 +42,23 @@ def kernels_of(obj, tmp):
     return out
 
 
+def scratch_ops(obj, tmp, kernel):
+    """scratch_* / stack buffer_* instructions between the kernel's symbol and the next one (-1: symbol not found)."""
+    co = os.path.join(tmp, os.path.basename(obj) + ".co")
+    dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", co], text=True)
+    n, inside = -1, False
+    for line in dis.splitlines():
+        if line.endswith(">:"):
+            if inside:
+                break
+            inside = f"<{kernel}>:" in line
+            if inside:
+                n = 0
+        elif inside and ("scratch_" in line or ("buffer_" in line and " offen" in line and "s[0:3]" in line)):
+            n += 1
+    return n
+
+
 def short(n):
     import re
 
@@ -62,13 +79,21 @@ def main():
     objs = sorted(glob.glob(os.path.join(ROOT, "betty_amd", "csrc", "build", "*.o")))
     if not objs:
         sys.exit("check_spills: no objects under betty_amd/csrc/build — run make first")
-    bad, allk = [], []
+    bad, allk, frames = [], [], []
     with tempfile.TemporaryDirectory() as tmp:
         for o in objs:
             for name, d in kernels_of(o, tmp):
                 allk.append((name, d))
-                if d.get(".vgpr_spill_count", 0) or d.get(".private_segment_fixed_size", 0):
+                if d.get(".vgpr_spill_count", 0):
                     bad.append((name, d))
+                elif d.get(".private_segment_fixed_size", 0):
+                    # a frame may be left behind by SGPR spills that ended up in VGPR lanes: what counts is scratch TRAFFIC
+                    n = scratch_ops(o, tmp, name)
+                    if n != 0:
+                        d["scratch_instructions"] = n
+                        bad.append((name, d))
+                    else:
+                        frames.append((name, d))
     allk.sort(key=lambda t: -t[1].get(".vgpr_count", 0))
     if "--list" in sys.argv:
         for name, d in allk:
@@ -79,6 +104,9 @@ def main():
         for name, d in bad:
             print("  SPILL:", short(name), d, file=sys.stderr)
         sys.exit(f"check_spills: {len(bad)} kernel(s) spill registers / use scratch")
+    for name, d in frames:
+        print(f"  note: {short(name)} declares a {d['.private_segment_fixed_size']}-byte frame but has no scratch instruction "
+              f"(SGPR spills to VGPR lanes: {d.get('.sgpr_spill_count', 0)})")
     print("check_spills: no VGPR spills, no scratch")
 
 

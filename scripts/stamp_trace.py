@@ -53,4 +53,10 @@ def show(name, kid, classes):
 # classes by which slots a workgroup stamped: k_graw's tile workgroups stamp s2 (MFMAs done) and s3, its small-slice blocks only
 # s1 (step length known); k_pstep's update blocks stamp s1 (beta known), its small blocks do not
 show("k_graw", 0, [("small slices (alpha)", lambda a: (a[:, 2] == 0) & (a[:, 4] > 0)), ("tiles", lambda a: a[:, 2] > 0)])
-show("k_pstep", 1, [("update blocks", lambda a: a[:, 1] > 0), ("small blocks", lambda a: (a[:, 1] == 0) & (a[:, 4] > 0))])
+show("k_pstep / update blocks of k_wskpl (s2: operands requested, s3: partial sums in LDS, s1: beta known)", 1,
+     [("update blocks", lambda a: a[:, 1] > 0), ("small blocks", lambda a: (a[:, 1] == 0) & (a[:, 4] > 0))])
+show("k_wskpl tiles (entry: before the K loop, s1: after it, s2: partial tiles in LDS, s3: beta polled)", 2, [("tiles", lambda a: a[:, 4] > 0)])
+# the three share one clock: offsets of the classes of k_wskpl relative to its first update block
+a1, a2 = st[1], st[2]
+if (a1[:, 0] > 0).any() and (a2[:, 0] > 0).any():
+    print("k_wskpl: first tile stamp - first update-block stamp = %.2f us" % ((a2[a2[:, 0] > 0, 0].min() - a1[a1[:, 0] > 0, 0].min()) * 0.01))
