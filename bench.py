@@ -571,9 +571,11 @@ def main():
             alg = rec_bytes                     # 28*N per CG iteration, 20*N per Neumann iteration
             comp = rec_bytes + 20.0 * N         # + Appendix A.3's HVP weight traffic (read W, V twice, write H*dir once)
             roof = {"bound": "hbm",
-                    "kernel": ("bhg_mlp_cg_solve: one whole CG-HVP iteration — fully projected form, SEVEN dependent launches: k_pstep (scalars + "
-                               "recurrences), the R-chain through the constant weights on packed operands (k_wskpc x2, k_head_forward, k_wskpc x2; "
-                               "the B x B Gram products ride in them), k_graw (G(raw) products with the inner products in their epilogue, small "
+                    "kernel": ("bhg_mlp_cg_solve: one whole CG-HVP iteration — fully projected form, SIX dependent launches: the R-chain "
+                               "through the constant weights on packed operands (k_wskpl: first product by linearity on Rh_0(r'), beta computed "
+                               "and published inside the launch; k_wskpu: pre-head product + the recurrences G(p') = G(r') + beta G(p); "
+                               "k_head_forward; k_wskpc x2; the B x B Gram products ride in them), then k_graw (G(raw) products with the inner "
+                               "products, the residual step G(r') = G(r) - alpha (G(raw) + shift G(p)) and Rh_0(r') in their epilogue, small "
                                "slices' outputs, step length)" if (args.algo == "cg" and solver_form and solver_form.startswith("fully")) else
                                "bhg_mlp_cg_solve: one whole fused CG-HVP iteration (R-chain + k_cg_alpha + k_outer_all, whose "
                                "epilogue carries the r/p update)" if args.algo == "cg" else
@@ -594,7 +596,7 @@ def main():
                                                                       "so this counts bytes the kernels do not move — yardstick only"},
                     "note": mall_note + "; `achieved` is SURVEY 8(d)'s yardstick — the 28*N bytes the REFERENCE's recurrence moves per "
                             "iteration divided by this solver's iteration time; the projected solver itself moves far fewer bytes (`traffic`), "
-                            "its iteration is a chain of 7 dependent launches on batch-sized data plus two passes over the constant weights of the chain"}
+                            "its iteration is a chain of 6 dependent launches on batch-sized data plus two passes over the constant weights of the chain"}
             if (solver_form or "").startswith(("fully", "projected")):
                 # the solver's OWN roofline next to the 8(d) yardstick: what it executes and must move, not what the reference moves
                 w = projected_iteration_work()

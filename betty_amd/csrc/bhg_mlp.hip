@@ -485,7 +485,10 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
       hp->eslabp_off[l] = off; off += (size_t)2 * Bp * Bp;
     }
   }
-  hp->lin_ok = hp->proj_ok && L >= 4;
+  // L == 4 exactly: the update blocks then ride in the pre-head launch (k_wskpu) and find beta published.  In a deeper net they stay in
+  // k_wskpl AHEAD of the block that publishes beta and spin for it: correct while they all fit on the chip at once (the 5- and 6-layer
+  // nets of the test suite), a deadlock for a wide one (more update blocks than resident slots) — so deeper nets keep the k_pstep launch.
+  hp->lin_ok = hp->proj_ok && L == 4;
   if (hp->lin_ok) {
     for (int i = 0; i < 2; ++i) { hp->z1_off[i] = off; off += (size_t)Bp * m->dims[2]; }
     hp->rh0rp_off = off; off += (size_t)Bp * m->dims[1];

@@ -39,8 +39,9 @@ for arm in ("fused",):
         n = (fe.get(k) or wr.get(k))[0]
         tab[k] = {"launches": n, "fetch_bytes": 2 * 1024 * (fe.get(k, (0, 0))[1]), "write_bytes": 1024 * (wr.get(k, (0, 0))[1])}
     out["per_kernel"][arm] = tab
-    # the seven steady-state launches of a projected iteration; everything else is once per solve
-    loop = [k for k in tab if k.startswith(("k_wskpc", "k_graw", "k_pstep")) or k == "k_head_forward<true, 3, true, true>"]
+    # the steady-state launches of a projected iteration (k_wskpl, k_wskpu, k_head_forward, k_wskpc x2, k_graw; the first iteration's
+    # k_wskpl / k_wskpc / k_graw launches carry the same names and are counted with them); everything else is once per solve
+    loop = [k for k in tab if k.startswith(("k_wskpc", "k_wskpl", "k_wskpu", "k_graw", "k_pstep")) or k == "k_head_forward<true, 3, true, true>"]
     solves = tab["k_cg_init"]["launches"] if "k_cg_init" in tab else steps
     tot = sum((tab[k]["fetch_bytes"] + tab[k]["write_bytes"]) * tab[k]["launches"] for k in loop) / (solves * K)
     out["traffic_bytes"]["cg_iter_fused"] = tot
