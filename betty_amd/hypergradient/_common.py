@@ -147,7 +147,14 @@ class PersistentOpaqueGraphs:
     DistributedDataParallel hooks fire as always).  First step of a signature: eager (warm-up); second: capture; from the
     third on: replay.  Anything that changes the signature (parameter storage, batch shapes, direction buffer) recaptures.
     Not taken under DistributedDataParallel-wrapped upper modules reached inside the capture (their forward does host
-    bookkeeping).  Measured (MI355X, cfg 2, opaque HVP, CG K = 20): see DESIGN.md section 5."""
+    bookkeeping).  Measured (MI355X, cfg 2, opaque HVP, CG K = 20): see DESIGN.md section 5.
+
+    STATIC-CLOSURE REQUIREMENT: the eager backward through the captured autograd graph is made to pass autograd's in-place check
+    by setting the version counters of the TRACKED tensors (parameters, buffers, the static batch copies) back to their
+    capture-time values (`saved_versions`, through the private `torch._C._autograd._unsafe_set_version_counter`).  Any other
+    tensor `training_step` closes over and that is saved for backward is either caught by that check (an error) or, if it is
+    rewritten in place between steps without autograd noticing, silently stale: a `training_step` that uses such tensors must
+    not opt in.  `persistent_graphs_for` refuses (returns None) when the private API is absent."""
 
     def __init__(self):
         self.sig = None
@@ -262,6 +269,8 @@ def _persistent_mixed(self, prev, neg_x_views, sync: bool):
     persistent graphs are not taken under DDP — so there is no reducer hook a `backward` would have to fire)."""
     upper = list(prev.trainable_parameters())
     key = (tuple((id(p), p.data_ptr()) for p in upper), GraphedHVP._key(neg_x_views))
+    if getattr(self, "g3_dead", False):   # a capture of this hop failed once: stay eager for good (no retry, no warning per step)
+        return mixed_vjp(self.in_grad, prev, neg_x_views, sync, retain_graph=True)
     if getattr(self, "g3", None) is None or self.g3_key != key:
         with self.saved_versions():
             try:
@@ -275,7 +284,9 @@ def _persistent_mixed(self, prev, neg_x_views, sync: bool):
                 GRAPH_STATS["captures"] += 1
             except Exception as exc:   # stay eager for this hop
                 self.g3 = None
-                warnings.warn(f"betty_amd: hipGraph capture of the mixed second derivative failed ({type(exc).__name__}: {exc})", RuntimeWarning)
+                self.g3_dead = True
+                warnings.warn(f"betty_amd: hipGraph capture of the mixed second derivative failed ({type(exc).__name__}: {exc}); "
+                              "this hop stays eager for the rest of the run", RuntimeWarning)
                 torch.cuda.synchronize(neg_x_views[0].device)
                 return mixed_vjp(self.in_grad, prev, neg_x_views, sync, retain_graph=True)
     self.g3.replay()
@@ -304,6 +315,10 @@ def persistent_graphs_for(curr, K: int, tensors, prev=None):
     if _uses_ddp(curr) or (prev is not None and _uses_ddp(prev)):   # a DDP forward does host bookkeeping: not capturable
         return None
     if getattr(curr, "hypergradient_graph", False) != "persistent":
+        return None
+    if not hasattr(getattr(torch._C, "_autograd", None), "_unsafe_set_version_counter"):   # the private API saved_versions() needs
+        warnings.warn("betty_amd: this PyTorch has no torch._C._autograd._unsafe_set_version_counter — persistent HVP graphs are off",
+                      RuntimeWarning)
         return None
     cache = getattr(curr, "_bhg_persistent_graphs", None)
     if cache is None:

@@ -94,6 +94,11 @@ def _arms(algo):
                  ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
                  ("fused-graw-v1", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAW_V2": "0"})),
                  ("fused-alpha-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_ALPHA_IN_HOIST": "0"})),
+                 # the chain's first product by linearity (default) with its update blocks inside k_wskpl, with the k_pstep launch,
+                 # and k_graw storing G(raw) instead of applying the residual step
+                 ("fused-upd-in-first", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_UPDATE_NEXT": "0"})),
+                 ("fused-kpstep-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_FIRST": "0"})),
+                 ("fused-graw-stores-raw", dict(hvp="hip", fused=True, wsk=None, env={"BHG_RNEW_IN_GRAW": "0"})),
                  ("fused-packed-d2", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "2"})),
                  ("fused-packed-d4", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "4"}))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
@@ -129,7 +134,7 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
     else:
         bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
     for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH", "BHG_GRAW_V2",
-                "BHG_ALPHA_IN_HOIST"):
+                "BHG_ALPHA_IN_HOIST", "BHG_LIN_UPDATE_NEXT", "BHG_LIN_FIRST", "BHG_RNEW_IN_GRAW"):
         bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         bhg_debug.setenv(key, val)

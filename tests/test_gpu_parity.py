@@ -889,6 +889,13 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
     arms["full-alphalaunch"] = dict(arms["full"], BHG_ALPHA_IN_HOIST="0")
     arms["full-pstepv1"] = dict(arms["full"], BHG_PSTEP_V2="0")         # k_proj_step instead of k_pstep (same work, lazily fetched arguments)
     arms["hoisted-unpacked"] = dict(arms["hoisted"], BHG_PACKED_CHAIN="0")
+    if algo == "cg":
+        # four-layer nets with a batch of <= 128: the chain's first product by linearity (k_wskpl), the recurrences riding in the
+        # pre-head launch (k_wskpu) — the arms: update blocks inside k_wskpl; the k_pstep launch; k_graw storing G(raw) instead of
+        # applying the residual step (on other nets the three arms run the default's launches)
+        arms["full-updfirst"] = dict(arms["full"], BHG_LIN_UPDATE_NEXT="0")
+        arms["full-kpstep"] = dict(arms["full"], BHG_LIN_FIRST="0")
+        arms["full-grawraw"] = dict(arms["full"], BHG_RNEW_IN_GRAW="0")
     out = {}
     for name, env in arms.items():
         bhg_debug.reset()
