@@ -462,8 +462,13 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     fp *= 2.0 * Bp * (double)Bp;
     size_t gram = 0;
     for (int l = 0; l + 1 < L; ++l) gram += (size_t)Bp * Bp * (l >= 1 ? (2 + 2 * kGramSplitMax + 6) : 2);
+    // (and every batch-sized array small enough for proj_update_one's row index — (i + 0.5) * (1 / nv) in fp32 instead of an integer
+    //  division — to be exact: float4 indices below 2^20; it first fails at 2.0 M, tests/test_proj_global_protocol.py)
+    size_t widest = 0;
+    for (int i = 0; i < n; ++i) widest = (size_t)hp->N[i] > widest ? (size_t)hp->N[i] : widest;
     hp->proj_ok = fp * 100.0 <= fh * (double)dbg(DBG_proj_max_ratio, 400) &&
-                  gram * sizeof(float) <= (size_t)dbg(DBG_proj_ws_cap_mb, 1024) * 1024 * 1024;
+                  gram * sizeof(float) <= (size_t)dbg(DBG_proj_ws_cap_mb, 1024) * 1024 * 1024 &&
+                  (size_t)Bp * (widest / 4) <= ((size_t)1 << 20);
   }
   hp->dot_blocks = 0;
   for (int i = 0; i < n; ++i) hp->dot_blocks += dot_blocks_of(Bp * (hp->N[i] / 4));

@@ -4,7 +4,8 @@
 #   80b4f0d8 / e861d9e8  k_wskpl + k_wskpu (scripts/gpu_r4f.sh last call, scripts/gpu_r4g.sh): six launches, 701-702 steps/s -> the r04 files
 #   d1a20ddf  a later edit that lost one host line (update blocks' arguments): every arm that launches k_wskpl crashed; the arms that do
 #             not (lin_first=0, packed_chain=0, rnew_in_graw=0, Neumann, keep-solution) are valid and kept, labelled
-# The shipped library (167c0d7f) = e861d9e8 + one host-side condition (four-layer nets only); device code byte-identical.
+# The shipped library (3d11e78e) = e861d9e8 + two host-side conditions in hoist_plan (four-layer nets only for the linear first
+# product; projected forms only below 2^20 float4s per batch-sized array); device code byte-identical.
 set -u
 c() { [ -f "$1" ] && cp "$1" "$2"; }
 p=profiles

@@ -111,3 +111,59 @@ def test_factor_exchange_over_gloo(world):
     for rank, err, gathers, reduces, nbytes in res:
         assert err <= 1e-10, (rank, err)
         assert (gathers, reduces) == (2 * L + K, K)
+
+
+# ---- identities behind the one-rank kernels of round 4, in fp64 ------------------------------------------------
+def test_linear_first_product_and_residual_step_identities_fp64():
+    """k_wskpl runs the chain's first product on Rh_0(r') and adds beta times the last iteration's product; k_graw forms r'|b0 and
+    G(r') itself.  In exact arithmetic, with p' = r' + beta p and r' = r - alpha (H p + shift p):
+        Rh_0(p') W_1^T = Rh_0(r') W_1^T + beta Rh_0(p) W_1^T            T_1(p') = T_1(r') + beta T_1(p)
+        Gf_0(r') = Gf_0(r) - alpha (S_0 Rd_0(p) + shift Gf_0(p))        r'|b0 = r|b0 - alpha (colsum_b Rd_0(p) + shift p|b0)."""
+    dims, B = [24, 32, 16, 12, 5], 20
+    Ws, bs, x, y, w, vec_r = P.make_problem(dims, B, 5)
+    _, _, _, _, _, vec_p = P.make_problem(dims, B, 6)
+    st = P.local_state(Ws, bs, x, y, w)
+    L, alpha, beta, shift = len(Ws), 0.37, 0.81, 0.25
+    proj = lambda v: ([st["hs"][l] @ v[2 * l].t() for l in range(L - 1)], [None] + [st["deltas"][l] @ v[2 * l] for l in range(1, L - 1)])
+    chain = lambda v: P.r_chain(st, Ws, *proj(v), v[1::2], v[2 * (L - 1)])
+    Rz_p, Rhs_p, Rds_p = chain(vec_p)
+    # H p (weight-shaped, one rank) and the residual step in N-space
+    Hp = []
+    for l in range(L):
+        HW = Rds_p[l].t() @ st["hs"][l]
+        if l >= 1:
+            HW = HW + st["deltas"][l].t() @ Rhs_p[l - 1]
+        Hp += [HW + shift * vec_p[2 * l], Rds_p[l].sum(0) + shift * vec_p[2 * l + 1]]
+    r1 = [a - alpha * b for a, b in zip(vec_r, Hp)]
+    p1 = [a + beta * b for a, b in zip(r1, vec_p)]
+    Rh0 = lambda v: st["masks"][0] * (st["hs"][0] @ v[0].t() + v[1])
+    close = lambda a, b: float((a - b).norm() / b.norm()) <= 1e-12
+    assert close(Rh0(r1) @ Ws[1].t() + beta * (Rh0(vec_p) @ Ws[1].t()), Rh0(p1) @ Ws[1].t())
+    T1 = lambda v: st["hs"][1] @ Rh0(v).t()
+    assert close(T1(r1) + beta * T1(vec_p), T1(p1))
+    S0 = st["hs"][0] @ st["hs"][0].t()
+    Gf0 = lambda v: st["hs"][0] @ v[0].t()
+    assert close(Gf0(vec_r) - alpha * (S0 @ Rds_p[0] + shift * Gf0(vec_p)), Gf0(r1))
+    assert close(vec_r[1] - alpha * (Rds_p[0].sum(0) + shift * vec_p[1]), r1[1])
+
+
+def test_row_index_by_fp32_reciprocal_is_exact():
+    """proj_update_one (proj.inc) finds the row of flat float4 index i in a [Bp][nv] array as int((i + 0.5) * (1 / nv)) in fp32,
+    in place of an integer division.  hoist_plan takes the projected forms only while Bp * nv <= 2^20: exact there, for every
+    shape and with the reciprocal perturbed by +-2 ulp (v_rcp_f32 is accurate to 1 ulp); it first fails at 2.0 M indices."""
+    import numpy as np
+
+    def exact(nv, Bp):
+        idx = np.arange(Bp * nv, dtype=np.int64)
+        rcp = np.float32(1.0) / np.float32(nv)
+        for r in (rcp, np.nextafter(np.nextafter(rcp, np.float32(0)), np.float32(0)), np.nextafter(np.nextafter(rcp, np.float32(1)), np.float32(1))):
+            m = ((idx.astype(np.float32) + np.float32(0.5)) * r).astype(np.int32)
+            if not (m == idx // nv).all():
+                return False
+        return True
+
+    for nv in (8, 24, 96, 384, 512, 768, 1000, 1536, 2048, 3000, 4096, 8192):
+        for Bp in (128, 256, 512, 1024, 2048, 4096):
+            if Bp * nv <= 2 ** 20:
+                assert exact(nv, Bp), (nv, Bp)
+    assert not exact(2048, 1024)   # 2^21 indices: why the plan stops at 2^20
