@@ -13,7 +13,7 @@ for f in bench_default.json bench_default_kernel_stats.csv bench_line_under_rocp
   b=${f%.*}; e=${f##*.}; [ -f $p/r04_$f ] && git mv -f $p/r04_$f $p/r04_pass1_$f 2>/dev/null
 done
 c gpurun_out/r4g/bench_default.json $p/r04_bench_default.json
-grep -vE "^Extension|Warning|warn" gpurun_out/r4g/pytest_gpu_full.log | grep -E "passed|failed|skipped|durations|s call|s setup" > $p/r04_pytest_gpu.log
+grep -E "passed|failed|^[0-9.]+s (call|setup)|slowest" gpurun_out/r4g/pytest_gpu_full.log > $p/r04_pytest_gpu.log
 c gpurun_out/r4g/smoke.log $p/r04_smoke.log
 c gpurun_out/r4f/timeline_default.txt $p/r04_timeline_fused_fully_projected.txt
 c gpurun_out/r4/timeline_lin0.txt $p/r04_timeline_kpstep_launch_arm.txt
