@@ -87,13 +87,20 @@ class Problem:
                 p.grad = g if p.grad is None else p.grad + g
 
 
-def declare_structure(curr, impl, fused=True, keep_solution=False):
+def declare_structure(curr, impl, fused=True, keep_solution=False, native_upper=True):
     """Opt the inner problem into the analytic MFMA HVP (betty_amd/hypergradient/structured.py)."""
-    from betty_amd.hypergradient.structured import WeightedCEMLP
+    from betty_amd.hypergradient.structured import SigmoidMLPWeightNet, WeightedCEMLP
+
+    # the meta-weight-net's own closed form (csrc/bhg_mwn.hip) unless --upper autograd; under DDP the declaration asks for the
+    # data-parallel mean that the wrapper's reducer would have taken (SigmoidMLPWeightNet.average_over)
+    def wnet(prev):
+        if not native_upper:
+            return None
+        return SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=True if prev.fwd is not prev.module else None)
 
     curr.hypergradient_structure = lambda prev: WeightedCEMLP(
         curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=curr.ridge, impl=impl,
-        fused=fused, keep_solution=keep_solution,
+        fused=fused, keep_solution=keep_solution, weight_net=wnet(prev),
     )
 
 
@@ -315,7 +322,7 @@ def parity_check(args, device, jvp_fn, curr, prev, vector, K):
     wseed = int(gold["well/seeds"][0])
     curr_w, prev_w, vector_w = build(device, seed=wseed, K=K, algo=args.algo, ridge=RIDGE_WELL)
     if args.hvp == "analytic":
-        declare_structure(curr_w, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution)
+        declare_structure(curr_w, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution, native_upper=args.upper == "closed-form")
     elif args.hvp == "analytic-aten":
         declare_structure(curr_w, "torch")
     out_w = jvp_fn(vector_w, curr_w, prev_w, False)
@@ -359,6 +366,9 @@ def main():
     ap.add_argument("--variant", choices=["auto", "stream", "resident"], default="auto")
     ap.add_argument("--hvp", choices=["analytic", "analytic-aten", "autograd"], default="analytic",
                     help="analytic = MFMA R-op kernels for the declared MLP structure; autograd = opaque double backward")
+    ap.add_argument("--upper", choices=["closed-form", "autograd"], default="closed-form",
+                    help="analytic HVP only: the meta-weight-net's sample weights and their VJP in closed form (csrc/bhg_mwn.hip, declared "
+                         "through SigmoidMLPWeightNet) or through PyTorch autograd (the round-4 path: A/B)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="analytic HVP only: K x (HVP kernels + recurrence kernel) instead of the one-pass fused solver (A/B)")
     ap.add_argument("--keep-solution", action="store_true",
@@ -374,7 +384,9 @@ def main():
     ap.add_argument("--tunableop", action="store_true",
                     help="--hvp autograd only: let PyTorch's TunableOp pick the GEMM kernel of every shape of the double backward "
                          "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's)")
-    ap.add_argument("--no-slope", action="store_true", help="skip the K/2 region (event-free per-iteration time)")
+    ap.add_argument("--no-slope", action="store_true", help="skip the K/2 regions (event-free per-iteration time)")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="timed regions of `--steps` steps each (full and, interleaved, K/2): the line reports the MEDIAN region and the spread")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the in-run check of the timed solver against the committed reference-CPU goldens (A/B sweeps)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
@@ -431,7 +443,7 @@ def main():
         curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
         jvp_fn = hg.jvp_fn_mapping[args.algo]
     if args.hvp == "analytic":
-        declare_structure(curr, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution)
+        declare_structure(curr, "hip", fused=not args.no_fuse, keep_solution=args.keep_solution, native_upper=args.upper == "closed-form")
     elif args.hvp == "analytic-aten":  # same closed form on rocBLAS/ATen ops (A/B reference for the MFMA kernels)
         declare_structure(curr, "torch")
     else:   # opaque double backward: opt into the hipGraph replay of the K HVPs (betty_amd/hypergradient/_common.py)
@@ -477,10 +489,45 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream.
+    # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream, bracketed by barrier +
+    # synchronize on both sides.  Repeated `--reps` times (default 5): `value` / `ms_per_step` are the MEDIAN region, every region
+    # and the min-max spread are in the line (`regions`).  One region of 20 steps is 30 ms: a single sample of it moves by
+    # several percent with the clock state of the box (round-4 verdict).
+    # Region 1b — the same `steps` steps with HALF the iterations, equally free of events, INTERLEAVED with the full regions
+    # (full, half, full, half, ...: slow drifts of the box cancel inside a pair): the difference of a pair is K/2 full iterations
+    # per step on the SAME clock as the headline (no per-launch events, no profiler):  iteration = (t(K) - t(K/2)) / (K/2) per
+    # pair, reported as the median over the pairs with its spread;  outside the K loop = t(K) - K * iteration (it absorbs what
+    # the short last iteration saves).
+    reps = max(1, args.reps)
+    slope = args.algo in ("cg", "neumann") and K >= 2 and not args.no_slope
+    key = "cg_iterations" if args.algo == "cg" else "neumann_iterations"
     h0, p0 = int(be.lib.bhg_mlp_hoist_launches()), int(be.lib.bhg_mlp_proj_iterations())
-    elapsed = timed_region(args.steps)
-    n_hoist, n_proj = int(be.lib.bhg_mlp_hoist_launches()) - h0, int(be.lib.bhg_mlp_proj_iterations()) - p0
+    t_full, t_half = [], []
+    n_hoist = n_proj = 0
+    for rep in range(reps):
+        c0, c1 = int(be.lib.bhg_mlp_hoist_launches()), int(be.lib.bhg_mlp_proj_iterations())
+        t_full.append(timed_region(args.steps))
+        if rep == 0:
+            n_hoist, n_proj = int(be.lib.bhg_mlp_hoist_launches()) - c0, int(be.lib.bhg_mlp_proj_iterations()) - c1
+        if slope:
+            setattr(curr.config, key, K // 2)
+            step()
+            t_half.append(timed_region(args.steps))
+            setattr(curr.config, key, K)
+            step()
+    if dist is not None:   # every region: the max over the ranks
+        t = torch.tensor(t_full + t_half, device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = [float(v) for v in t.tolist()]
+        t_full, t_half = t[:len(t_full)], t[len(t_full):]
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+    elapsed = med(t_full)
+    elapsed_half = med(t_half) if t_half else None
+    pair_iter_us = [1e6 * (a - b) / (args.steps * (K - K // 2)) for a, b in zip(t_full, t_half)]
     solver_form = None
     if fused and args.algo == "cg":
         if n_proj == args.steps * (K - 1) and n_hoist == args.steps:
@@ -497,18 +544,6 @@ def main():
         solver_form = ("projected Neumann solver (libbhg default without an accumulator vector): G(v') = G(v) - alpha (G(raw) + shift G(v)) "
                        "through B x B Gram matrices, nothing N-sized after the first iteration, closing half pass for Rz(v_K); "
                        "bhg_mlp_proj_iterations = %d" % n_proj) if n_proj == args.steps * K else "classic chain"
-    # Region 1b — the same `steps` steps with HALF the iterations, equally free of events: the difference of the two
-    # regions is K/2 full iterations per step on the SAME clock as the headline (no per-launch events, no profiler), so
-    # the roofline span and the headline agree by construction:  iteration = (t(K) - t(K/2)) / (K/2);
-    # outside the K loop = t(K) - K * iteration (it absorbs what the short last iteration saves).
-    elapsed_half = None
-    if args.algo in ("cg", "neumann") and K >= 2 and not args.no_slope:
-        key = "cg_iterations" if args.algo == "cg" else "neumann_iterations"
-        setattr(curr.config, key, K // 2)
-        step()
-        elapsed_half = timed_region(args.steps)
-        setattr(curr.config, key, K)
-        step()
     # Region 2 — the same `steps` steps again with HIP events around the launch groups (recorded inside libbhg on the
     # launch stream) for the roofline objects.  Kept out of region 1 because every event record costs the stream a
     # ~4 us bubble (measured: 210 vs 192 steps/s with 4 records per CG iteration); its throughput is reported as
@@ -526,18 +561,10 @@ def main():
             if cnt.value:
                 spans[name] = (1e3 * tot.value / cnt.value, cnt.value)   # (average us, launches)
         be.lib.bhg_timing_enable(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None and elapsed_timed is not None:
+        t = torch.tensor([elapsed_timed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        if elapsed_timed is not None:
-            t = torch.tensor([elapsed_timed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_timed = float(t.item())
-        if elapsed_half is not None:
-            t = torch.tensor([elapsed_half], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_half = float(t.item())
+        elapsed_timed = float(t.item())
     be.check_health()
 
     finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
@@ -563,7 +590,7 @@ def main():
                      "fabric-side bandwidth on cache-resident data, quoted against the 8 TB/s HBM peak as north_star asks; "
                      "cache-defeated figures: profiles/r02_bench_kernels_N10M_cache_defeated.json" % ((3 * 4 * N + 4 * N + 8e6) / 1e6))
         # event-free iteration time (region 1 vs region 1b): the span every fused roofline figure below is quoted on
-        iter_us = 1e6 * (elapsed - elapsed_half) / (args.steps * (K - K // 2)) if elapsed_half is not None else None
+        iter_us = med(pair_iter_us) if pair_iter_us else None   # median over the (full, half) pairs
         if fused and args.algo in ("cg", "neumann") and (iter_us is not None or ("cg_iter" if args.algo == "cg" else "hvp") in spans):
             ev_us, ev_n = spans.get("cg_iter" if args.algo == "cg" else "hvp", (None, 0))
             us = iter_us if iter_us is not None else ev_us
@@ -584,9 +611,16 @@ def main():
                     "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "algorithmic_bytes_per_launch": alg,
                     "avg_launch_us": us,
-                    "avg_launch_us_source": ("event-free: (t(K) - t(K/2)) / (K/2) over two timed regions of %d steps, the headline's own clock"
-                                             % args.steps) if iter_us is not None else "HIP events around the iteration (bhg_timing)",
+                    "avg_launch_us_source": ("event-free: (t(K) - t(K/2)) / (K/2) per interleaved pair of timed regions of %d steps (the "
+                                             "headline's own clock), median of %d pairs" % (args.steps, len(pair_iter_us)))
+                    if iter_us is not None else "HIP events around the iteration (bhg_timing)",
+                    "avg_launch_us_pairs": pair_iter_us or None,
+                    "avg_launch_us_min_max": [min(pair_iter_us), max(pair_iter_us)] if pair_iter_us else None,
                     "avg_launch_us_hip_events": ev_us, "launches_timed": ev_n,
+                    "hip_events_note": "the event figure brackets every iteration with FOUR hipEventRecord calls on the launch stream (iteration "
+                                       "span + HVP span); each record is a ~3-4 us bubble in a chain of dependent 6-14 us launches, so it reads "
+                                       "~12 us above the event-free slope by construction — it is kept as the live HIP-event cross-check, the "
+                                       "slope (no events, no profiler) is the figure that agrees with rocprofv3's per-kernel sums (profiles/)",
                     "traffic": traffic, "traffic_source": traffic_src,
                     "achieved_on_traffic_GBps": (traffic / (us * 1e-6) / 1e9) if traffic else None,
                     "own": None,
@@ -679,6 +713,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "regions": {"reps": reps, "steps_each": args.steps, "statistic": "median region (value, ms_per_step); every region is bracketed by "
+                        "barrier + synchronize and is the max over ranks",
+                        "ms_per_step_each": [1e3 * t / args.steps for t in t_full],
+                        "ms_per_step_min_max": [1e3 * min(t_full) / args.steps, 1e3 * max(t_full) / args.steps],
+                        "half_K_ms_per_step_each": [1e3 * t / args.steps for t in t_half] or None},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -694,6 +733,8 @@ def main():
                                                                    ", K HVPs captured once per solve and replayed as a HIP graph (opt-in)" if args.hvp_graph == "solve" else
                                                                    ", loss / gradient-with-graph and HVP captured ONCE for the run and replayed as two HIP graphs (opt-in)")),
                 "blas_of_the_opaque_hvp": ("PyTorch TunableOp (tuned during the warm-up)" if args.tunableop else "PyTorch default") if args.hvp == "autograd" else None,
+                "upper": ("meta-weight-net in closed form (bhg_mwn_forward / bhg_mwn_backward: one launch each way)" if args.upper == "closed-form"
+                          else "meta-weight-net through PyTorch autograd") if args.hvp == "analytic" else "PyTorch autograd",
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "solver_form": solver_form,
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else

@@ -134,6 +134,12 @@ SYMBOLS = {
          c_float, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "bhg_mwn_max_hidden": (c_int, []),
+    "bhg_mwn_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "bhg_mwn_backward": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "bhg_mlp_neumann_solve": (
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_float, c_float, c_void_p, c_size_t, POINTER(c_int), c_void_p],

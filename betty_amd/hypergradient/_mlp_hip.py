@@ -132,9 +132,22 @@ class HipMLPState:
             ce = buf.ce[:B]
         else:
             ce = self._aten_forward(Ws, bs, y)
-        # sample weights from the upper problem's module (keeps the graph to prev's parameters)
-        self.sample_weight = spec.weight_fn(ce.detach().clone())
-        buf.sd[:B].copy_(self.sample_weight.detach().reshape(-1).to(torch.float32) / B)
+        # sample weights: the declared closed form of the meta-weight-net (one launch, writes s / B where bhg_mlp_backward reads it),
+        # else the upper problem's module through autograd (keeps the graph to prev's parameters)
+        self.native_upper, self.sample_weight = False, None
+        wn = getattr(spec, "weight_net", None)
+        if wn is not None and buf.native_prepare:
+            self._upper_slots = wn.slots(list(spec.prev.trainable_parameters()))
+            ts = [t.detach() for t in wn.tensors()]
+            self.native_upper = (self._upper_slots is not None and ts[0].shape[0] <= int(lib.bhg_mwn_max_hidden()) and
+                                 all(t.is_cuda and t.device == x.device and t.dtype == torch.float32 and t.is_contiguous() for t in ts))
+        if self.native_upper:
+            self._wn = ts
+            _native.check(lib.bhg_mwn_forward(buf.ce.data_ptr(), B, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(),
+                                              ts[0].shape[0], None, buf.sd.data_ptr(), _stream()), "bhg_mwn_forward")
+        else:
+            self.sample_weight = spec.weight_fn(ce.detach().clone())
+            buf.sd[:B].copy_(self.sample_weight.detach().reshape(-1).to(torch.float32) / B)
         if buf.native_prepare:
             _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
         else:
@@ -149,6 +162,29 @@ class HipMLPState:
             buf.out_tab, buf.out_keep = _native.ptr_array([t.data_ptr() for t in buf.out])
         self.out = buf.out
         self._out_tab = buf.out_tab
+
+    def upper_vjp(self, coeff, upper, scale: float = 1.0, retain_graph: bool = False, with_flat: bool = False):
+        """d(sum_i coeff_i s_i)/d(upper parameters), aligned with ``upper``: closed form (views of ONE fresh flat buffer in
+        ``upper``'s order, times ``scale``) when the weight net is declared, else autograd through ``sample_weight``'s graph."""
+        if not self.native_upper:
+            sw = self.sample_weight
+            out = list(torch.autograd.grad(sw, upper, grad_outputs=coeff.reshape(sw.shape), retain_graph=retain_graph))
+            return (out, None) if with_flat else out
+        ts, B = self._wn, self.B
+        H = ts[0].shape[0]
+        sizes = [p.numel() for p in upper]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=ts[0].device)   # fresh: .grad may keep its views
+        views, off = [], 0
+        for p, n in zip(upper, sizes):
+            views.append(flat[off: off + n].view(p.shape))
+            off += n
+        g = [views[i] for i in self._upper_slots]   # (w1, b1, w2, b2) -> their slots in `upper`
+        coeff = coeff if (coeff.dtype == torch.float32 and coeff.is_contiguous()) else coeff.to(torch.float32).contiguous()
+        _native.check(
+            self.lib.bhg_mwn_backward(self.buf.ce.data_ptr(), coeff.data_ptr(), B, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(),
+                                      ts[3].data_ptr(), H, float(scale), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                      g[3].data_ptr(), _stream()), "bhg_mwn_backward")
+        return (views, flat) if with_flat else views
 
     # ---- ATen path of the once-per-step passes for wide output layers ------------------------------------------
     def _aten_forward(self, Ws, bs, y):
@@ -297,14 +333,14 @@ class HipMLPState:
                                                          buf.fws.numel(), _stream()),
                     "bhg_mlp_neumann_mixed_coeff",
                 )
-                return buf.coeff[:B].clone()
+                return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
             if solve.kind == "cg":
                 _native.check(
                     self.lib.bhg_mlp_cg_mixed_coeff(ctypes.byref(self.desc), buf.labels.data_ptr(), buf.coeff.data_ptr(), solve.alpha,
                                                     buf.fws.data_ptr(), buf.fws.numel(), _stream()),
                     "bhg_mlp_cg_mixed_coeff",
                 )
-                return buf.coeff[:B].clone()
+                return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
             # a materialised Neumann accumulator: read it like any direction (below)
         if buf.native_prepare:
             tab, _keep = self._dir_table(dir_views)
@@ -312,7 +348,7 @@ class HipMLPState:
                 self.lib.bhg_mlp_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(), _stream()),
                 "bhg_mlp_mixed_coeff",
             )
-            return buf.coeff[:B].clone()
+            return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
         Vs, cs = dir_views[0::2], dir_views[1::2]
         Rh = None
         for l in range(self.L):

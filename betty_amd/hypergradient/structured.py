@@ -51,6 +51,51 @@ def structured_hvp_for(curr, prev):
     return hook(prev)
 
 
+class SigmoidMLPWeightNet:
+    """Declared structure of the sample-weight function of :class:`WeightedCEMLP`: the meta-weight-net of data reweighting
+    (examples/learning_to_reweight/model.py:98-111, ``MLP(hidden_size, num_layers=1)``; called at main.py:123-125)::
+
+        s = sigmoid(out(relu(hidden(ce.reshape(-1, 1)))))          hidden: nn.Linear(1, H), out: nn.Linear(H, 1)
+
+    With it the HIP implementation evaluates the weights and their VJP to (hidden, out)'s parameters in closed form
+    (csrc/bhg_mwn.hip: one launch each way) instead of ~15 ATen launches through autograd per step — five rocBLAS GEMMs for a
+    100 x 100 problem.  It is a promise like the inner structure and is checked the same way (the first prepare() compares the
+    mixed second derivative with autograd through the problem's real ``training_step``).  ``weight_fn`` stays the definition:
+    it is what runs whenever the closed form does not apply (``impl="torch"``, a CPU tensor, H > 2048, upper parameters
+    that are not exactly these four tensors).
+
+    ``average_over``: the reference's ``sync=True`` hop accumulates through autograd so that a DistributedDataParallel wrapper
+    of the upper module all-reduces (mean) the hypergradient (betty/problems/problem.py:220-224, cg.py:58-63).  The closed form
+    does not pass through that wrapper, so a data-parallel caller says so here: ``True`` (the default process group) or a process
+    group -> the M-sized flat result is all-reduced (RCCL) and averaged before it is accumulated into ``.grad``; ``None`` (the
+    default) -> no collective, as for an un-wrapped module in the reference.
+    """
+
+    def __init__(self, hidden: torch.nn.Linear, out: torch.nn.Linear, average_over=None):
+        if hidden.in_features != 1 or out.out_features != 1 or hidden.out_features != out.in_features:
+            raise ValueError("SigmoidMLPWeightNet: hidden must be Linear(1, H) and out Linear(H, 1)")
+        if hidden.bias is None or out.bias is None:
+            raise ValueError("SigmoidMLPWeightNet: both layers carry a bias in the reference's meta-weight-net")
+        self.hidden, self.out, self.average_over = hidden, out, average_over
+
+    def tensors(self):
+        return [self.hidden.weight, self.hidden.bias, self.out.weight, self.out.bias]
+
+    def slots(self, upper_params):
+        """Index of (w1, b1, w2, b2) inside ``upper_params``, or None when the upper problem's trainable parameters are not
+        exactly these four tensors (then the closed form does not describe d/d(upper) and autograd keeps the job)."""
+        mine = self.tensors()
+        if len(upper_params) != 4:
+            return None
+        idx = []
+        for t in mine:
+            hit = [i for i, p in enumerate(upper_params) if p is t]
+            if len(hit) != 1:
+                return None
+            idx.append(hit[0])
+        return idx if sorted(idx) == [0, 1, 2, 3] else None
+
+
 class WeightedCEMLP:
     """ReLU-MLP with per-sample-weighted cross-entropy (+ optional ridge):
 
@@ -86,8 +131,11 @@ class WeightedCEMLP:
     """
 
     def __init__(self, curr, prev, layers: Sequence[torch.nn.Linear], weight_fn: Callable, ridge: float = 0.0,
-                 batch=None, impl: Optional[str] = None, fused: bool = True, keep_solution: bool = False, verify: bool = True):
+                 batch=None, impl: Optional[str] = None, fused: bool = True, keep_solution: bool = False, verify: bool = True,
+                 weight_net: Optional["SigmoidMLPWeightNet"] = None):
         self.curr, self.prev = curr, prev
+        # optional declared structure of weight_fn itself (closed-form sample weights and upper VJP on the HIP path)
+        self.weight_net = weight_net
         self.verify = bool(verify)
         self.layers = list(layers)
         self.weight_fn = weight_fn
@@ -146,8 +194,7 @@ class WeightedCEMLP:
         hv_auto, mixed_auto = second[:len(params)], second[len(params):]
         hv = [h.detach().clone() + self.hvp_shift * d for h, d in zip(self._state.hvp(direction), direction)]
         coeff = self._state.mixed_coeff(direction)   # (the graph of the sample weights is kept: the real mixed_vjp comes later)
-        mixed = torch.autograd.grad(self._state.sample_weight, upper, grad_outputs=coeff.reshape(self._state.sample_weight.shape),
-                                    retain_graph=True)
+        mixed = self._state.upper_vjp(coeff, upper, retain_graph=True)   # closed-form weight net: its kernels are what is checked
 
         def rel(got, want):
             num = sum(float(((a.double() - (b.double() if b is not None else 0.0)) ** 2).sum()) for a, b in zip(got, want)) ** 0.5
@@ -220,6 +267,25 @@ class WeightedCEMLP:
         st = self._state
         coeff = st.mixed_coeff(neg_x_views, solve) if solve is not None else st.mixed_coeff(neg_x_views)  # [B]: d(g.(-x))/d s_i
         upper = self.prev.trainable_parameters()
+        if getattr(st, "native_upper", False):
+            # closed-form weight net (csrc/bhg_mwn.hip): the M-sized result lands in ONE fresh flat buffer; sync=True accumulates it
+            # into .grad like Problem.set_grads (problem.py:583-597) after the data-parallel mean the declaration asks for
+            wn = self.weight_net
+            world, group = 1, None
+            if sync and wn.average_over is not None:
+                import torch.distributed as dist  # noqa: PLC0415
+
+                if dist.is_available() and dist.is_initialized():
+                    group = None if wn.average_over is True else wn.average_over
+                    world = dist.get_world_size(group)
+            grads, flat = st.upper_vjp(coeff, upper, scale=1.0 / world, with_flat=True)
+            if world > 1:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)   # pre-scaled by 1 / world: the mean (DDP's reduction)
+            if sync:
+                for p_, g_ in zip(upper, grads):
+                    p_.grad = g_ if p_.grad is None else p_.grad + g_
+                return None
+            return grads
         if sync:
             torch.autograd.backward(st.sample_weight, grad_tensors=coeff.reshape(st.sample_weight.shape), inputs=upper)
             return None
@@ -257,6 +323,12 @@ class _TorchMLPState:
         for l in range(len(Ws) - 1, 0, -1):
             deltas[l - 1] = masks[l - 1] * (deltas[l] @ Ws[l])
         self.Ws, self.hs, self.masks, self.p, self.sd, self.deltas, self.B = Ws, hs, masks, p, sd, deltas, B
+
+    native_upper = False
+
+    def upper_vjp(self, coeff, upper, retain_graph=False):
+        return list(torch.autograd.grad(self.sample_weight, upper, grad_outputs=coeff.reshape(self.sample_weight.shape),
+                                        retain_graph=retain_graph))
 
     def _r_forward(self, Vs, cs):
         Rh, Rhs = None, [None]

@@ -340,6 +340,21 @@ int64_t bhg_mlp_proj_iterations(void);
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff,
                                 float alpha, int K, int projected, void* fws, size_t fws_bytes, void* stream);
 
+/* ---- closed-form meta-weight-net (round 5; csrc/bhg_mwn.hip) --------------------------------------------------------------------
+ * The UPPER problem of data reweighting (examples/learning_to_reweight/model.py:98-111 `MLP(hidden_size, num_layers = 1)`, called at
+ * main.py:123-125):  s_i = sigmoid(w2 . relu(w1 * ce_i + b1) + b2),  ce: [B] detached per-sample losses, w1, b1, w2: [H], b2: [1].
+ * On the reference's path autograd evaluates it when the inner loss is rebuilt (cg.py:27-32 / neumann.py:31-36) and differentiates it in
+ * the final mixed VJP (cg.py:58-68 / neumann.py:44-54): ~15 ATen launches for 301 parameters.  Here one launch each way; all pointers
+ * are device pointers, fp32, the launches are asynchronous on `stream`.
+ *   bhg_mwn_forward   s[i] (may be NULL) and sd[i] = s[i] / B (may be NULL; what bhg_mlp_backward reads through bhg_mlp.sd)
+ *   bhg_mwn_backward  gw1, gb1, gw2 [H], gb2 [1]  =  scale * d( sum_i coeff[i] * s_i ) / d(w1, b1, w2, b2)    (overwritten, not added)
+ * Deterministic (one workgroup, fixed summation order).  1 <= H <= bhg_mwn_max_hidden().                                          */
+int bhg_mwn_max_hidden(void);
+int bhg_mwn_forward(const float* ce, int B, const float* w1, const float* b1, const float* w2, const float* b2, int H, float* s,
+                    float* sd, void* stream);
+int bhg_mwn_backward(const float* ce, const float* coeff, int B, const float* w1, const float* b1, const float* w2, const float* b2,
+                     int H, float scale, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,6 +496,115 @@ def test_structured_hip_path_matches_reference(name, sync, be):
     assert rel <= 1e-4 and mx <= 1e-3, (rel, mx)  # north_star tolerance
 
 
+# ------------------------------------------------------------------------------------------------
+# round 5: the meta-weight-net in closed form (csrc/bhg_mwn.hip; SigmoidMLPWeightNet) — the upper problem of
+# examples/learning_to_reweight/model.py:98-111, evaluated and differentiated in one launch each way
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H", [(100, 100), (37, 500), (1500, 64), (5, 2048), (1, 1), (2500, 300)])
+def test_mwn_kernels_match_autograd(B, H, be):
+    """bhg_mwn_forward / bhg_mwn_backward through the C ABI against the module itself under autograd (fp32 on the same GPU)."""
+    import ctypes
+
+    torch.manual_seed(B * 7 + H)
+    net = zoo.MWN(H).to(DEV)
+    ce = (2.5 * torch.rand(B, device=DEV)).contiguous()
+    coeff = torch.randn(B, device=DEV).contiguous()
+    s_ref = net(ce.reshape(-1, 1)).reshape(-1)
+    g_ref = torch.autograd.grad(s_ref, list(net.parameters()), grad_outputs=coeff)
+    lib = be.lib
+    s, sd = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    w1, b1, w2, b2 = [t.detach().contiguous() for t in (net.l1.weight, net.l1.bias, net.l2.weight, net.l2.bias)]
+    st = int(torch.cuda.current_stream().cuda_stream)
+    _native.check(lib.bhg_mwn_forward(ce.data_ptr(), B, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), H, s.data_ptr(),
+                                      sd.data_ptr(), st), "bhg_mwn_forward")
+    np.testing.assert_allclose(s.cpu().numpy(), s_ref.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(sd.cpu().numpy(), (s_ref.detach() / B).cpu().numpy(), rtol=2e-6, atol=2e-7 / B)
+    outs = [torch.full_like(t, float("nan")) for t in (w1, b1, w2, b2)]
+    for scale in (1.0, 0.25):
+        _native.check(lib.bhg_mwn_backward(ce.data_ptr(), coeff.data_ptr(), B, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), H,
+                                           ctypes.c_float(scale), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                                           st), "bhg_mwn_backward")
+        rel, mx = rel_err(_np(outs), [scale * g.detach().cpu().numpy().astype(np.float64) for g in g_ref])
+        assert rel <= 2e-6 and mx <= 2e-5, (B, H, scale, rel, mx)
+    again = [o.clone() for o in outs]
+    _native.check(lib.bhg_mwn_backward(ce.data_ptr(), coeff.data_ptr(), B, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), H,
+                                       ctypes.c_float(0.25), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), st),
+                  "bhg_mwn_backward")
+    for a, b in zip(again, outs):
+        assert torch.equal(a, b), "fixed summation order: bitwise run-to-run"
+    assert lib.bhg_mwn_forward(ce.data_ptr(), B, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 4096, s.data_ptr(), None, st) != 0
+
+
+@pytest.mark.parametrize("name", ["reweight_cg20", "reweight_neumann10", "deep_cg6", "deep_neumann6"])
+@pytest.mark.parametrize("sync", [False, True])
+def test_closed_form_weight_net_matches_reference(name, sync, be):
+    """The structured path with the upper module DECLARED (closed-form sample weights and upper VJP) against the reference's goldens,
+    and against the same path with the upper module under autograd; sync=True accumulates into .grad like Problem.set_grads."""
+    case = zoo.CASE_BY_NAME[name]
+    inputs, outputs = load_golden(case.family)
+    res = {}
+    for declared in (True, False):
+        curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+        zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=declared)
+        if sync:
+            for p in prev.trainable_parameters():
+                p.grad = torch.full_like(p, 0.25)
+        out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, sync)
+        if sync:
+            assert out is None
+            out = [p.grad - 0.25 for p in prev.trainable_parameters()]
+        res[declared] = _np(out)
+        if declared:
+            from betty_amd.hypergradient import structured
+
+            prov = structured.structured_hvp_for(curr, prev)
+            prov.prepare()
+            assert prov._state.native_upper, "the closed form was declared but did not run"
+    want = golden_list(outputs, case.name, "fp32")
+    wmax = max(np.abs(np.concatenate([w.ravel() for w in want])).max(), 1e-30)
+    scale = max(1.0, 0.25 / wmax) if sync else 1.0   # the 0.25 offset costs fp32 digits when the result is tiny
+    rel, mx = rel_err(res[True], want)
+    assert rel <= (1e-4 + 2e-7) * scale and mx <= 1e-3 * scale, (rel, mx)
+    rel2, _ = rel_err(res[True], res[False])
+    assert rel2 <= 2e-5 * scale, rel2
+
+
+def test_closed_form_weight_net_declines_what_it_does_not_describe(be):
+    """Upper parameters that are not exactly the four tensors of the declared net: autograd keeps the job (no wrong gradient)."""
+    case = zoo.CASE_BY_NAME["reweight_cg20"]
+    inputs, outputs = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=True)
+    only = list(prev.module.parameters())[:2]
+    prev.trainable_parameters = lambda: only          # e.g. a frozen output layer
+    from betty_amd.hypergradient import structured
+
+    prov = structured.structured_hvp_for(curr, prev)
+    prov.verify = False
+    prov.prepare()
+    assert not prov._state.native_upper
+    out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, False)
+    rel, _ = rel_err(_np(out), golden_list(outputs, case.name, "fp32")[:2])
+    assert rel <= 1e-4, rel
+
+
+def test_a_wrong_weight_net_declaration_is_rejected(be):
+    """A meta-weight-net with another activation than the declared one: the first prepare() raises StructureMismatchError."""
+    from betty_amd.hypergradient import structured
+
+    case = zoo.CASE_BY_NAME["reweight_cg20"]
+    inputs, _ = load_golden(case.family)
+    curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+    fwd = prev.module.forward
+    prev.module.forward = lambda x: torch.sigmoid(prev.module.l2(torch.tanh(prev.module.l1(x))))   # tanh, not relu
+    try:
+        zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=True)
+        with pytest.raises(structured.StructureMismatchError):
+            hg.jvp_fn_mapping[case.algo](vector, curr, prev, False)
+    finally:
+        prev.module.forward = fwd
+
+
 @pytest.mark.parametrize("name", ["reweight_cg20", "reweight_neumann10", "deep_cg6", "deep_neumann6"])
 def test_structured_goldens_with_and_without_fusion(name, be):
     """Both arms of the structured path against the reference's goldens: fused (the product default: recurrence

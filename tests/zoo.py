@@ -14,6 +14,7 @@ bit-identical numbers.
 from __future__ import annotations
 
 import dataclasses
+import os
 from typing import Callable, Dict, List
 
 import numpy as np
@@ -489,14 +490,16 @@ def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cp
 RIDGE = {"reweight": 0.5, "deep": 0.5}
 
 
-def attach_mlp_structure(curr, family, impl=None, fused=True):
-    """Opt the inner problem into the analytic HVP (betty_amd.hypergradient.structured)."""
-    from betty_amd.hypergradient.structured import WeightedCEMLP
+def attach_mlp_structure(curr, family, impl=None, fused=True, weight_net=False, average_over=None):
+    """Opt the inner problem into the analytic HVP (betty_amd.hypergradient.structured).  weight_net=True also declares the upper
+    module (zoo.MWN) as the closed-form meta-weight-net (SigmoidMLPWeightNet)."""
+    from betty_amd.hypergradient.structured import SigmoidMLPWeightNet, WeightedCEMLP
 
     def structure(prev):
         return WeightedCEMLP(
             curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)),
             ridge=RIDGE[family], impl=impl, fused=fused,
+            weight_net=SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=average_over) if weight_net else None,
         )
 
     curr.hypergradient_structure = structure
@@ -520,3 +523,71 @@ def attach_prox_structure(curr):
     curr.hypergradient_structure = structure
     return curr
 
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json cfg 5 AS NAMED: the reference's own DARTS supernet `Network(16, 10, 8)` (1,930,618 parameters in 1,399 tensors) and
+# `Architecture(4)` (2 x 14 x 8 = 224) — examples/neural_architecture_search/model_search.py:129-234,302-317 — on the example's batch
+# 64 x 3 x 32 x 32 (train_search.py:24), Neumann K = 20.  The model files are the reference's own: read from the checkout in the build
+# container (tests/golden/make_cfg5_golden.py) or from the staged, git-ignored, test-only copy oracle/_ref/examples_nas on the GPU box.
+# ------------------------------------------------------------------------------------------------------------------------------------
+NAS_DIRS = (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "examples_nas"),
+            "/root/reference/examples/neural_architecture_search")
+CFG5_SEED, CFG5_K, CFG5_ALPHA, CFG5_BATCH = 5, 20, 0.01, 64
+
+
+def nas_dir():
+    for d in NAS_DIRS:
+        if os.path.isfile(os.path.join(d, "model_search.py")):
+            return d
+    return None
+
+
+def reference_nas_modules():
+    import importlib
+    import sys
+    import types
+
+    if "utils" not in sys.modules or not hasattr(sys.modules["utils"], "accuracy"):
+        # model_search.py does `from utils import accuracy`; the example's utils.py needs torchvision (absent here) for its data
+        # pipeline only — a stand-in module carries the one function the model file names (it is never called by `loss`)
+        stub = types.ModuleType("utils")
+        stub.accuracy = lambda output, target, topk=(1,): [torch.zeros(()) for _ in topk]
+        sys.modules["utils"] = stub
+    d = nas_dir()
+    sys.path.insert(0, d)
+    try:
+        return importlib.import_module("model_search")
+    finally:
+        sys.path.remove(d)
+
+
+def cfg5_as_named_case(Config, device, dtype=torch.float32, K=CFG5_K):
+    """(curr, prev, vector): every tensor is drawn by the CPU generator in fp32 and then moved / cast, so the build container (CPU,
+    fp32 and fp64) and the GPU box see the same numbers."""
+    ms = reference_nas_modules()
+    g = torch.Generator().manual_seed(CFG5_SEED)
+    torch.manual_seed(CFG5_SEED)
+    inner = ms.Network(16, 10, 8, torch.nn.CrossEntropyLoss()).to(device=device, dtype=dtype)
+    upper = ms.Architecture(4).to(device=device, dtype=dtype)
+    x = torch.randn(CFG5_BATCH, 3, 32, 32, generator=g).to(device=device, dtype=dtype)
+    y = torch.randint(0, 10, (CFG5_BATCH,), generator=g).to(device)
+    vector = [(1e-2 * torch.randn(p.shape, generator=g)).to(device=device, dtype=dtype) for p in inner.parameters()]
+    prev = StubProblem("arch", upper, config=Config())
+
+    def loss_fn(self, batch):   # train_search.py:124-129 (Classifier.training_step)
+        xb, tb = batch
+        return self.module.loss(xb, prev.module(), tb)
+
+    curr = StubProblem("classifier", inner, config=Config(type="neumann", neumann_iterations=K, neumann_alpha=CFG5_ALPHA),
+                       loss_fn=loss_fn, batch=(x, y))
+    return curr, prev, vector
+
+
+def cfg5_checksums(curr, prev, vector):
+    """fp64 sums (and absolute sums) of every input tensor: the GPU box proves it rebuilt the very problem the golden was made from."""
+    import numpy as np
+
+    x, y = curr.cur_batch
+    ts = list(curr.parameters()) + list(prev.parameters()) + [x, y.double()] + list(vector)
+    return np.array([t.detach().double().sum().item() for t in ts] + [t.detach().double().abs().sum().item() for t in ts])
