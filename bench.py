@@ -149,7 +149,7 @@ def lib_sha256():
 
     from betty_amd import _native
 
-    with open(_native.LIB_PATH, "rb") as f:
+    with open(_native.current_lib_path(), "rb") as f:   # the library this process actually calls (product, or libbhg_ab.so under --debug)
         return hashlib.sha256(f.read()).hexdigest()
 
 
@@ -385,11 +385,17 @@ def main():
                     help="--hvp autograd only: let PyTorch's TunableOp pick the GEMM kernel of every shape of the double backward "
                          "during the warm-up (the GEMMs of the opaque path are PyTorch's, not libbhg's)")
     ap.add_argument("--no-slope", action="store_true", help="skip the K/2 regions (event-free per-iteration time)")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="after the --warmup steps, keep stepping (untimed) until this much wall-clock has passed: clocks at their "
+                         "sustained state before the first timed region (0 = off)")
     ap.add_argument("--reps", type=int, default=5,
                     help="timed regions of `--steps` steps each (full and, interleaved, K/2): the line reports the MEDIAN region and the spread")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the in-run check of the timed solver against the committed reference-CPU goldens (A/B sweeps)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
+    ap.add_argument("--ab-lib", action="store_true",
+                    help="run on the measurement build libbhg_ab.so with every arm at its default (what --debug implies): the A/B partner "
+                         "of a --debug line, and the check that the two builds run the same default form")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=INT",
                     help="select a measurement arm of libbhg through bhg_debug_set (the library reads no environment variable); "
                          "repeatable, e.g. --debug packed_chain=0 --debug mlp_proj=0.  Echoed in config.debug_arms")
@@ -429,6 +435,8 @@ def main():
     from betty_amd.backend import get_backend
 
     be = get_backend()
+    if args.debug or args.ab_lib:   # measurement arms live in the measurement build (libbhg_ab.so: same sources, -DBHG_AB)
+        _native.use_ab(True)
     for kv in args.debug:
         key, _, val = kv.partition("=")
         _native.debug_set(key, int(val))
@@ -489,6 +497,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Settle (untimed, reported as `settle_steps`): W = 5 warm-up steps are 7 ms of GPU work — the first timed region of a 20-step run
+    # then still sees the clocks ramp (round 5, two boxes: its first (full, half) pair read -74 and +75 us per iteration next to
+    # 60.0-60.7 for the other four).  Steps are run until --settle-ms of wall-clock have passed (default 300; 0 = off).
+    settle_steps = 0
+    if args.settle_ms > 0:
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 1e-3 * args.settle_ms:
+            step()
+            settle_steps += 1
+            if settle_steps % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
     # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream, bracketed by barrier +
     # synchronize on both sides.  Repeated `--reps` times (default 5): `value` / `ms_per_step` are the MEDIAN region, every region
     # and the min-max spread are in the line (`regions`).  One region of 20 steps is 30 ms: a single sample of it moves by
@@ -712,6 +733,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "regions": {"reps": reps, "steps_each": args.steps, "statistic": "median region (value, ms_per_step); every region is bracketed by "
                         "barrier + synchronize and is the max over ranks",
@@ -747,6 +769,7 @@ def main():
                 if args.mode == "global" else ("replicas + DDP all-reduce of the M-sized hypergradient" if world > 1 else "single GPU"),
                 "finite": finite,
                 "debug_arms": args.debug or None,
+                "lib": "libbhg_ab.so (measurement build: A/B table compiled in)" if _native.is_ab() else "libbhg.so (product: no measurement arm in the code object)",
                 "lib_sha256": lib_sha256()[:16],
             },
             "parity": parity,

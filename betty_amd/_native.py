@@ -12,7 +12,9 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BHG_LIB") or os.path.join(_HERE, "csrc", "libbhg.so")  # BHG_LIB: A/B builds of the same ABI
+LIB_PATH = os.environ.get("BHG_LIB") or os.path.join(_HERE, "csrc", "libbhg.so")  # BHG_LIB: another build of the same ABI
+# the measurement build (the same sources with the A/B table compiled in, -DBHG_AB): what `bhg_debug_set` needs; see use_ab()
+AB_LIB_PATH = os.environ.get("BHG_AB_LIB") or os.path.join(_HERE, "csrc", "libbhg_ab.so")
 
 BHG_CHUNK_ELEMS = 4096
 BHG_FLAT_ALIGN = 64
@@ -57,6 +59,7 @@ class Mlp(ctypes.Structure):
         ("partial", c_void_p),
         ("partial_floats", c_size_t),
         ("ridge2", c_float),
+        ("prepacked", c_int32),
     ]
 
 
@@ -79,6 +82,7 @@ SYMBOLS = {
         [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p],
     ),
     "bhg_cg_init": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bhg_cg_init_masked": (c_int, [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_uint64, c_void_p, c_void_p]),
     "bhg_cg_step": (
         c_int,
         [_PP, c_int, _CH, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_int, c_void_p, c_void_p],
@@ -106,6 +110,7 @@ SYMBOLS = {
     "bhg_debug_reset": (None, []),
     "bhg_debug_key_count": (c_int, []),
     "bhg_debug_key_name": (c_char_p, [c_int]),
+    "bhg_is_ab_build": (c_int, []),
     "bhg_timing_enable": (c_int, [c_int]),
     "bhg_timing_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
     "bhg_logreg_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -128,12 +133,22 @@ SYMBOLS = {
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_float, c_float, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
+    "bhg_mlp_cg_state_mask": (ctypes.c_uint64, [POINTER(Mlp), c_int]),
+    "bhg_mlp_cg_solve_rhs": (
+        c_int,
+        [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_float, c_float, c_void_p,
+         c_void_p, c_size_t, _PP, c_void_p],
+    ),
     "bhg_mlp_cg_global_phase": (
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
          c_float, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "bhg_mlp_timeout_flag_dev": (c_void_p, [POINTER(Mlp), c_void_p]),
+    "bhg_mlp_supports_packed_prepare": (c_int, [POINTER(Mlp)]),
+    "bhg_mlp_forward_packed": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bhg_mlp_backward_packed": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_size_t, c_void_p]),
     "bhg_mwn_max_hidden": (c_int, []),
     "bhg_mwn_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "bhg_mwn_backward": (
@@ -150,30 +165,55 @@ SYMBOLS = {
     "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
-_lib = None
+_libs = {}          # path -> bound CDLL
+_current = [None]   # path of the library load() returns: LIB_PATH (the product) unless use_ab() switched
 
 
-def load() -> ctypes.CDLL:
-    """Load libbhg.so once; raise loudly when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _bind(path: str) -> ctypes.CDLL:
+    lib = _libs.get(path)
+    if lib is not None:
+        return lib
+    if not os.path.exists(path):
         raise NativeLibraryError(
-            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            f"{path} not found: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C betty_amd/csrc`. "
             "betty_amd has no CPU fallback."
         )
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:  # pragma: no cover - build/ABI mismatch
-            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
+            raise NativeLibraryError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
+    _libs[path] = lib
     return lib
+
+
+def load() -> ctypes.CDLL:
+    """The library every call goes through: libbhg.so (the product: one form per solver, no measurement arm in its code object)
+    unless use_ab() switched this process to libbhg_ab.so.  Loaded once; raises loudly when it has not been built."""
+    return _bind(_current[0] or LIB_PATH)
+
+
+def current_lib_path() -> str:
+    return _current[0] or LIB_PATH
+
+
+def is_ab() -> bool:
+    return bool(load().bhg_is_ab_build())
+
+
+def use_ab(on: bool = True) -> None:
+    """Route every subsequent call of this process through the measurement build libbhg_ab.so (on) or back through the product
+    (off).  Both can be loaded side by side (separate shared objects, separate state: launch counters, side streams, debug table);
+    device buffers are plain memory and serve either.  Used by the `bhg_debug` pytest fixture and `bench.py --debug`."""
+    if on:
+        _bind(AB_LIB_PATH)
+        _current[0] = AB_LIB_PATH
+    else:
+        _current[0] = None
 
 
 def check(rc: int, what: str) -> None:
@@ -194,6 +234,9 @@ def debug_set(key: str, value) -> None:
     """Select a measurement / test arm of libbhg (include/bhg.h: bhg_debug_set).  value None = back to the shipped behaviour.
     The library itself reads no environment variable."""
     lib = load()
+    if value is not None and not lib.bhg_is_ab_build():
+        raise NativeLibraryError(f"bhg_debug_set({key}): the product libbhg.so carries no measurement arm — call "
+                                 "betty_amd._native.use_ab() first (libbhg_ab.so; the `bhg_debug` fixture and `bench.py --debug` do)")
     if value is None:
         check(lib.bhg_debug_unset(_debug_key(key)), f"bhg_debug_unset({key})")
     else:

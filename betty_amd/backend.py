@@ -29,7 +29,7 @@ class HipBackend:
     name = "hip"
 
     def __init__(self):
-        self.lib = _native.load()
+        _native.load()   # fail loudly now if the extension has not been built
         if not torch.cuda.is_available():
             raise _native.NativeLibraryError(
                 "betty_amd needs a visible MI355X (torch.cuda.is_available() is False); "
@@ -41,6 +41,7 @@ class HipBackend:
         # hold some (the barrier would spin until the collective ends, or time out)
         self.collectives_in_flight = 0
         self._health = []  # (event, pinned flag copy): non-blocking time-out checks of finished resident solves
+        self._fused_flags = weakref.WeakValueDictionary()   # id -> 1-element int32 view of a fused workspace's time-out word
 
     # -- helpers ---------------------------------------------------------------------------
     def layout(self, tensors: Sequence[torch.Tensor]) -> FlatLayout:
@@ -115,14 +116,19 @@ class HipBackend:
         )
 
     # -- CG ------------------------------------------------------------------------------------------
-    def cg_init(self, layout, vector, x, r, p) -> None:
+    def cg_init(self, layout, vector, x, r, p, keep_mask: Optional[int] = None):
+        """x = 0 (x None: not materialised), r = p = vector, r.r partials (cg.py:34-36).  keep_mask (bhg_cg_init_masked): only the
+        tensors whose bit is set have their slices of r / p written — for a solver that reads the others from the right-hand side's
+        own tensors.  Returns the tensors the kernel read (the caller's, or fp32 / contiguous copies of them)."""
         ts = self._prep(vector, layout)
         tab, _keep = self._table(ts)
+        mask = (1 << 64) - 1 if keep_mask is None else int(keep_mask) & ((1 << 64) - 1)
         _native.check(
-            self.lib.bhg_cg_init(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, None if x is None else x.data_ptr(),
-                                 r.data_ptr(), p.data_ptr(), layout.workspace.data_ptr(), _stream_ptr()),
-            "bhg_cg_init",
+            self.lib.bhg_cg_init_masked(tab, layout.T, layout.chunks_dev.data_ptr(), layout.n_chunks, None if x is None else x.data_ptr(),
+                                        r.data_ptr(), p.data_ptr(), mask, layout.workspace.data_ptr(), _stream_ptr()),
+            "bhg_cg_init_masked",
         )
+        return ts
 
     def _cached_table(self, tensors, layout):
         """Pointer table of an HVP tensor list; a provider that hands back the SAME output tensors every
@@ -198,8 +204,27 @@ class HipBackend:
         ev.record()
         self._health.append((ev, host))
 
+    @property
+    def lib(self):
+        """The library of the moment: the product, or the measurement build while _native.use_ab() is on."""
+        return _native.load()
+
+    def watch_fused_workspace(self, flag_view: torch.Tensor) -> None:
+        """Register the time-out word of a fused MLP solver's workspace (bhg_mlp_timeout_flag_dev): read — and cleared — by
+        check_health(block=True).  No per-step cost: the pollers poison the result with NaN themselves, this is the diagnosis."""
+        self._fused_flags[id(flag_view)] = flag_view
+
     def check_health(self, block: bool = True) -> None:
-        """Raise if a resident-CG grid barrier timed out in a solve that has finished (block=True: wait for all)."""
+        """Raise if a resident-CG grid barrier timed out in a solve that has finished (block=True: wait for all), or — block=True
+        only, it synchronises — if the in-launch beta exchange of a fused MLP solve gave up (csrc/mlp/wskp.inc poll_beta)."""
+        if block:
+            for flag in list(self._fused_flags.values()):
+                if int(flag.item()) != 0:
+                    flag.zero_()
+                    raise _native.NativeLibraryError(
+                        "bhg_mlp_cg_solve: workgroups of the first chain launch waited ~1 s for the step's beta, which another "
+                        "workgroup of the same launch publishes, and gave up; the hypergradient of that call is NaN.  The launch "
+                        "was built without its publisher (a library bug) or the device could not keep the launch resident.")
         keep = []
         for ev, host in self._health:
             if block:

@@ -43,7 +43,7 @@ enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 
   X(mlp_hoist) X(hoist_wgs) X(proj_step_alone) X(mlp_no_side) X(mlp_no_fuse) X(mlp_no_outer_all) X(neumann_side)             \
   X(hoist_staged_mink) X(proj_alpha_alone) X(proj_small_alone) X(outer_order_by_work) X(outer_no_pre) X(outer_stagger)       \
   X(mlp_no_fused_solve) X(cg_eager_p) X(cg_x_every_iter) X(neumann_p_every_iter) X(head_no_prefetch) X(cg_spin_limit)        \
-  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(alpha_in_hoist) X(graw_v2) X(wskp_ragged) X(pstep_v2) X(pstep_unroll) X(rnew_in_graw) X(graw_cols) X(lin_first) X(lin_prio) X(lin_nub) X(lin_order) X(lin_update_next)
+  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(alpha_in_hoist) X(graw_v2) X(wskp_ragged) X(pstep_v2) X(pstep_unroll) X(rnew_in_graw) X(graw_cols) X(lin_first) X(lin_prio) X(lin_nub) X(lin_order) X(lin_update_next) X(lin_withhold_beta) X(neumann_vnew) X(cg_rhs_direct) X(packed_prepare)
 enum DbgKey : int {
 #define BHG_DBG_ENUM(n) DBG_##n,
   BHG_DBG_KEYS(BHG_DBG_ENUM)
@@ -51,9 +51,18 @@ enum DbgKey : int {
   DBG_COUNT
 };
 constexpr int kDbgUnset = INT32_MIN;
+#ifdef BHG_AB
+// measurement build (make ab -> libbhg_ab.so): the table is live; every-arm tests and `bench.py --debug` load THIS library
 extern int g_dbg[DBG_COUNT];
 inline bool dbg_is_set(DbgKey k) { return g_dbg[k] != kDbgUnset; }
 inline int dbg(DbgKey k, int dflt) { return g_dbg[k] == kDbgUnset ? dflt : g_dbg[k]; }
+#else
+// PRODUCT build (libbhg.so, round 5): no table, no switch — every dbg(key, dflt) is the constant `dflt`, the arms behind the other
+// values are dead code the compiler drops (kernels nobody launches leave the code object), bhg_debug_set() fails and
+// bhg_debug_key_count() is 0.  One form per solver ships; the arms are measured and tested on libbhg_ab.so, built from the same sources.
+constexpr bool dbg_is_set(DbgKey) { return false; }
+constexpr int dbg(DbgKey, int dflt) { return dflt; }
+#endif
 
 // ---- in-kernel time stamps (measurement builds only: make stamps -> libbhg_stamps.so, -DBHG_STAMPS) ------------------------------
 // BHG_STAMP(kernel_id, slot): thread 0 of the workgroup stores s_memrealtime (100 MHz, one clock for the whole chip) at

@@ -18,11 +18,13 @@ void set_error(const char* fmt, ...) {
 
 static inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+#ifdef BHG_AB
 int g_dbg[DBG_COUNT] = {
 #define BHG_DBG_INIT(n) kDbgUnset,
     BHG_DBG_KEYS(BHG_DBG_INIT)
 #undef BHG_DBG_INIT
 };
+#endif
 static const char* const kDbgNames[DBG_COUNT] = {
 #define BHG_DBG_NAME(n) #n,
     BHG_DBG_KEYS(BHG_DBG_NAME)
@@ -47,6 +49,7 @@ const char* bhg_last_error(void) { return g_err; }
 
 size_t bhg_workspace_bytes(int T) { return ws_bytes(T); }
 
+#ifdef BHG_AB
 int bhg_debug_set(const char* key, int value) {
   const int i = dbg_find(key);
   BHG_REQUIRE(i >= 0, "unknown debug key");
@@ -65,6 +68,22 @@ void bhg_debug_reset(void) {
 }
 int bhg_debug_key_count(void) { return DBG_COUNT; }
 const char* bhg_debug_key_name(int i) { return (i >= 0 && i < DBG_COUNT) ? kDbgNames[i] : nullptr; }
+int bhg_is_ab_build(void) { return 1; }
+#else
+// the product carries no measurement arm (bhg_common.hpp): the calls exist so that one binding serves both builds, and say so
+int bhg_debug_set(const char* key, int) {
+  (void)dbg_find(key);
+  BHG_REQUIRE(false, "this is the product build of libbhg: measurement / test arms live in libbhg_ab.so (make -C betty_amd/csrc ab)");
+}
+int bhg_debug_unset(const char* key) {
+  (void)key;
+  return BHG_OK;   // (nothing is ever set)
+}
+void bhg_debug_reset(void) {}
+int bhg_debug_key_count(void) { return 0; }
+const char* bhg_debug_key_name(int) { return nullptr; }
+int bhg_is_ab_build(void) { return 0; }
+#endif
 
 int64_t bhg_layout_flat_size(const int64_t* numel, int T) {
   if (T < 0 || (T > 0 && !numel)) return -1;

@@ -100,6 +100,7 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wsk<LB, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
+#ifdef BHG_AB   // (arm-only instances are not in the product's code object: bhg_common.hpp)
     const int wsl_depth = dbg(DBG_wsl_depth, 2);   // A/B: register stages of the staged form
     if (wsl_depth == 3) {
       static bool attr3 = false;
@@ -108,9 +109,10 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
         attr3 = true;
       }
       hipLaunchKernelGGL((k_gemm_wsk<LB, false, 3, true>), grid, block, lds, st, a);
-    } else {
-      hipLaunchKernelGGL((k_gemm_wsk<LB, false, 2, true>), grid, block, lds, st, a);
+      return;
     }
+#endif
+    hipLaunchKernelGGL((k_gemm_wsk<LB, false, 2, true>), grid, block, lds, st, a);
     return;
   }
 #define BHG_WSK(BFV, DV) hipLaunchKernelGGL((k_gemm_wsk<LB, BFV, DV>), grid, block, 0, st, a)
@@ -118,7 +120,10 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
     // (N-contiguous B with the lazy direction holds 48 registers per stage: three stages would spill)
     if (d == 2 || LB == LAYOUT_RC) BHG_WSK(true, 2); else BHG_WSK(true, LB == LAYOUT_RC ? 2 : 3);
   } else {
-    if (d == 2) BHG_WSK(false, 2); else BHG_WSK(false, 3);
+#ifdef BHG_AB
+    if (d == 2) BHG_WSK(false, 2); else
+#endif
+    BHG_WSK(false, 3);
   }
 #undef BHG_WSK
 }
@@ -128,12 +133,16 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef BHG_AB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsk_group<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#endif
     attr_done = true;
   }
+#ifdef BHG_AB
   const int wsl_depth = dbg(DBG_wsl_depth, 2);
-  if (wsl_depth == 3) hipLaunchKernelGGL(k_wsk_group<3>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
-  else hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
+  if (wsl_depth == 3) { hipLaunchKernelGGL(k_wsk_group<3>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g); return; }
+#endif
+  hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
 
 // Grouped launch on packed operands (wskp.inc).  Block tables are rounded up to multiples of 8 so that a problem's tile t keeps
@@ -201,10 +210,17 @@ struct WskpBuilder {
       c.na = g.n >= 2 ? g.blk0[1] : blk;
       if (g.n >= 2) { c.r0 = {g.p[1].Ap, g.p[1].Bq, g.p[1].out, g.p[1].outp, g.p[1].K, 0}; c.nr0 = (g.n == 3 ? g.blk0[2] : blk) - g.blk0[1]; }
       if (g.n == 3) c.r1 = {g.p[2].Ap, g.p[2].Bq, g.p[2].out, g.p[2].outp, g.p[2].K, 0};
-      if (d == 2) hipLaunchKernelGGL(k_wskpc<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c);
-      else hipLaunchKernelGGL(k_wskpc<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c);
-    } else if (d == 2) hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
-    else hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
+#ifdef BHG_AB
+      if (d != 2) hipLaunchKernelGGL(k_wskpc<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c); else
+#endif
+      hipLaunchKernelGGL(k_wskpc<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, c);
+    } else {
+#ifdef BHG_AB
+      if (d != 2) hipLaunchKernelGGL(k_wskp<3>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g); else
+#endif
+      hipLaunchKernelGGL(k_wskp<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, g);
+    }
+    (void)d;
     g = WskpArgs{};
     blk = 0;
   }
@@ -234,10 +250,13 @@ void launch_gemm(const GemmArgs& a_in, int tn, hipStream_t st) {
   const bool no_fast = dbg(DBG_mlp_no_fast, 0) != 0;   // A/B switch (debug)
   if (no_fast) fast = false;
 #define BHG_GEMM(TNV, F, BFV) hipLaunchKernelGGL((k_gemm<LA, LB, TNV, F, BFV>), grid, dim3(256), 0, st, a)
+#ifdef BHG_AB   // (debug key mlp_tn = 64)
   if (tn == 64) {
     if (bf) { if (fast) BHG_GEMM(64, true, true); else BHG_GEMM(64, false, true); }
     else    { if (fast) BHG_GEMM(64, true, false); else BHG_GEMM(64, false, false); }
-  } else {
+  } else
+#endif
+  {
     if (bf) { if (fast) BHG_GEMM(32, true, true); else BHG_GEMM(32, false, true); }
     else    { if (fast) BHG_GEMM(32, true, false); else BHG_GEMM(32, false, false); }
   }
@@ -249,17 +268,18 @@ inline int skinny_tile_n() {
 }
 
 void launch_reduce_mask(hipStream_t st, const float* part, int splits, int slab, const float* bias,
-                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr) {
+                        const float* mask, float* out, int rows, int N, int B, float* relu_mask_out = nullptr,
+                        float* outp = nullptr) {
   if ((N & 3) == 0) {
     int blocks = (slab / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<4>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out);
+                       relu_mask_out, outp);
   } else {
     int blocks = (slab + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_reduce_mask<1>, dim3(blocks), dim3(256), 0, st, part, splits, slab, bias, mask, out, rows, N, B,
-                       relu_mask_out);
+                       relu_mask_out, (float*)nullptr);
   }
 }
 
@@ -332,8 +352,10 @@ int side_state(SideState** out) {
     BHG_OUTER_LDS(true, FUSE_CG); BHG_OUTER_LDS(false, FUSE_CG);
     BHG_OUTER_LDS(true, FUSE_NEUMANN); BHG_OUTER_LDS(false, FUSE_NEUMANN);
 #undef BHG_OUTER_LDS
+#ifdef BHG_AB   // (debug key outer_no_pre)
     BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+#endif
     BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     BHG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_outer_all<FUSE_NEUMANN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   }
@@ -391,6 +413,7 @@ struct HoistPlan {
   // the chain's first product by linearity (k_wskpl; L >= 4 and the projected forms only): Z(p) = Rh_0(p) W_1^T in two slots by
   // iteration parity, packed Rh_0(r'), the second slot of Gf_1(p) (slot 0 is g_off[gf[1]]), a copy of r|b0
   size_t z1_off[2], rh0rp_off, gp1alt_off, rb0c_off; bool lin_ok;
+  size_t rh0alt_off;   // projected Neumann with the update inside k_graw: the second slot of the ROW-MAJOR Rh_0 (slot 0 is m->Rh[0])
   bool proj_ok;                                                          // the projected solvers pay off and fit (cost model below)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
@@ -500,6 +523,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->gp1alt_off = off; off += (size_t)Bp * m->dims[2];
     hp->rb0c_off = off; off += (size_t)((m->dims[1] + 63) & ~63);
   }
+  if (hp->proj_ok) { hp->rh0alt_off = off; off += (size_t)Bp * m->dims[1]; }
   hp->graw_tiles = 0;
   for (int i = 0; i < n; ++i) hp->graw_tiles += (Bp / 64) * (hp->N[i] / 32);
   hp->blk0[n] = blk;
@@ -610,7 +634,9 @@ void carve_fused_ws(const bhg_mlp* m, void* base, FusedWs* w) {
 // Packed copies of the constants of a solve (wskp.inc): the chain's weights in both orientations, h_l and delta_l for the Gram
 // products.  One launch, once per solve: 3 x 15 M floats moved at cfg 2, ~1 % of a CG-20 solve.
 bool packed_chain_on(const FusedWs& w) { return w.Wf[1] != nullptr && dbg(DBG_packed_chain, 1) != 0; }
-int pack_operands(const bhg_mlp* m, const FusedWs& w, hipStream_t st) {
+// weights_only: the chain's weights and the input batch h_0 — what bhg_mlp_forward_packed packs before the net's own forward pass,
+// whose epilogues leave h_l and delta_l packed themselves
+int pack_operands(const bhg_mlp* m, const FusedWs& w, hipStream_t st, bool weights_only = false) {
   PackArgs g{};
   int blk = 0;
   auto add = [&](const float* X, float* Xp, int R, int K, int kind) {
@@ -624,9 +650,9 @@ int pack_operands(const bhg_mlp* m, const FusedWs& w, hipStream_t st) {
   const int L = m->L, Bp = m->Bp;
   bool ok = true;
   for (int l = 0; l + 1 < L && ok; ++l) {
-    ok = ok && add(m->h[l], w.hpk[l], Bp, m->dims[l], 0);
+    if (!weights_only || l == 0) ok = ok && add(m->h[l], w.hpk[l], Bp, m->dims[l], 0);
     if (l >= 1) {
-      ok = ok && add(m->delta[l], w.dpk[l], Bp, m->dims[l + 1], 0);
+      if (!weights_only) ok = ok && add(m->delta[l], w.dpk[l], Bp, m->dims[l + 1], 0);
       ok = ok && add(m->W[l], w.Wf[l], m->dims[l + 1], m->dims[l], 0);
       ok = ok && add(m->W[l], w.Wb[l], m->dims[l], m->dims[l + 1], 1);
     }
@@ -670,6 +696,8 @@ struct ChainMode {
   int gphase; double* php; double inv_world;
   int second;                   // fully projected CG: iteration 1 (the scalars k_proj_step completes are those of the FIRST iteration)
   int lin;                      // fully projected CG: the chain's first product by linearity, update launch inside it (k_wskpl; cg_ctx_init decides)
+  int nk;                       // projected Neumann: iteration index (the row-major Rh_0 lives in two slots by its parity, see vnew)
+  const void* const* rhs;       // fully projected CG, first iteration: the right-hand side's own tensors (bhg_mlp_cg_solve_rhs) or NULL
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -747,6 +775,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   // are told (G(r) is up to date, there is no G(raw)); the conditions are those of the step length computed inside k_graw
   const bool rnew = graw_single && cg && cm.proj >= 2 && cm.gphase == 0 && dbg(DBG_proj_small_alone, 0) == 0 &&
                     dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0;
+  // vnew (round 5): the projected Neumann solver's k_graw applies v' = v - alpha (raw + shift v) to G(v) itself and leaves Rh_0(v') packed
+  // and row-major — neumann.py:63 has no scalars to wait for — so the update launch at the top of the next iteration (k_proj_update) is
+  // gone: SIX launches per iteration instead of seven.  Like rnew a property of the whole solve.  The row-major Rh_0 alternates between
+  // m->Rh[0] and a second slot (iteration parity): the Gb_1 tiles of the launch that writes Rh_0(v') still read Rh_0(v).
+  const bool vnew = cm.mode == FUSE_NEUMANN && hp && cm.proj && graw_single && L >= 3 && dbg(DBG_neumann_vnew, 1) != 0;
+  auto rh0_slot = [&](int k) { return (k & 1) ? cm.ws->hoist + hp->rh0alt_off : m->Rh[0]; };   // Rh_0(v_k), row-major
   // lin: the chain's first product by linearity with the update launch riding in it (k_wskpl, wskpl.inc) — like rnew a property of
   // the whole solve: every iteration's first product, every k_graw (Rh_0(r') for the next one) and cg_iteration (the second bias's
   // direction in slots) follow it
@@ -770,7 +804,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       HoistProb& q = ha.p[i];
       q.A = hp->bwd[i] ? m->delta[l] : m->h[l];
       // CG: the RESIDUAL's slice — G(p) = G(r) + beta G(p_old) (k_hoist_reduce); Neumann: the direction itself
-      q.Bm = cg ? cm.fa + cm.starts[2 * l] : static_cast<const float*>(dir[2 * l]);
+      q.Bm = cg ? ((cm.first && cm.rhs) ? static_cast<const float*>(cm.rhs[2 * l]) : cm.fa + cm.starts[2 * l]) : static_cast<const float*>(dir[2 * l]);
       q.slabs = hbase + hp->slab_off[i];
       q.K = hp->K[i]; q.N = hp->N[i]; q.splits = hp->splits[i]; q.rc = hp->bwd[i];
       q.lda = hp->K[i]; q.ldb = hp->bwd[i] ? hp->N[i] : hp->K[i];
@@ -799,6 +833,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       hipLaunchKernelGGL(k_hoist_reduce, dim3(rblk), dim3(256), 0, st, ra);
       // (projected forms: the iteration-invariant Gram matrices S_l = h_l h_l^T, D_l = delta_l delta_l^T are formed once per
       //  solve — in the FIRST iteration's Gram launch, below, beside T_l and E_l: nothing needs them before its G(raw) products)
+    } else if (vnew) {         // the last iteration's k_graw applied the update and left Rh_0(v'): nothing to launch
+      ++g_proj_iterations;
     } else {                   // projected CG: G(r), G(p) from their batch-sized recurrences — nothing N-sized is read
       ProjArgs pa{};
       for (int i = 0; i < hp->n; ++i) {
@@ -865,6 +901,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
             h.gran = cm.ws->gran;
             h.rb0_copy = hbase + hp->rb0c_off;
             h.prio = dbg(DBG_lin_prio, 0);
+            h.withhold = dbg(DBG_lin_withhold_beta, 0);   // (tests: the pollers' bounded wait, see poll_beta)
             // launched update blocks (debug key lin_nub; 0 = one per virtual block): few, fat blocks leave most CUs to the tiles
             // (1 = as many as leave the launch ONE workgroup per CU with the ragged row tiling: that instance needs 288 registers)
             int nub = dbg(DBG_lin_nub, 0);
@@ -880,9 +917,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           }
           for (int t = 0; t < sa.snt; ++t) { ps.t.slen[t] = sa.slen[t]; ps.t.soff[t] = sa.soff[t]; }
           if (lin) { lin_ps = ps; lin_nu = (h.nub > 0 ? h.nub : rblk) + sgrid; lin_U = U; }
-          else if (U == 4) hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+#ifdef BHG_AB   // (debug key pstep_unroll)
           else if (U == 2) hipLaunchKernelGGL(k_pstep<2>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
-          else hipLaunchKernelGGL(k_pstep<1>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+          else if (U == 1) hipLaunchKernelGGL(k_pstep<1>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
+#endif
+          else hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
         } else
         hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
       } else {
@@ -945,8 +984,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         const int grid = (upd_next ? la.ns : la.nu) + na + rider_blocks;
         lin_update_pending = upd_next;
         BHG_REQUIRE(cm.first || lin_U == 4, "the update blocks inside k_wskpl are built for four float4 per thread");
-        if (la.ps.h.nub > 0) hipLaunchKernelGGL((k_wskpl<2, 4, true>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
-        else hipLaunchKernelGGL((k_wskpl<2, 4, false>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
+#ifdef BHG_AB   // (debug key lin_nub)
+        if (la.ps.h.nub > 0) hipLaunchKernelGGL((k_wskpl<2, 4, true>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la); else
+#endif
+        hipLaunchKernelGGL((k_wskpl<2, 4, false>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
         if (cm.first)   // r|b0 as k_graw's tiles will read it (its bias blocks update the slice in the same launch)
           BHG_HIP_CHECK(hipMemcpyAsync(hbase + hp->rb0c_off, cm.fa + cm.starts[1], sizeof(float) * (size_t)m->dims[1],
                                        hipMemcpyDeviceToDevice, st));
@@ -1342,9 +1383,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
             if (l >= 1) { q.A2 = hbase + hp->tslabp_off[l] + ((lin && l == 1) ? (size_t)cm.kpar * Bp * Bp : 0); q.B2 = m->delta[l]; }
           } else {             // Gb_l(raw) = E_l h_l + D_l Rh_{l-1}
             q.A1 = hbase + hp->eslabp_off[l]; q.B1 = m->h[l];
-            q.A2 = hbase + hp->dp_off[l]; q.B2 = m->Rh[l - 1];
+            q.A2 = hbase + hp->dp_off[l]; q.B2 = (vnew && l == 1) ? rh0_slot(cm.nk) : m->Rh[l - 1];
           }
           q.Gr = q.Gp = q.B1;   // (always loadable)
+          if (vnew) q.Gr = q.Gp = hbase + hp->g_off[i];   // G(v): updated in place by the tile that owns the element
           if (full) {           // the inner products' partner: Rd_l (= B1) forward, Rh_{l-1} (= B2) backward
             q.Gr = hbase + hp->gr_off[i]; q.Gp = (lin && i == hp->gf[1]) ? gp1(cm.kpar) : hbase + hp->g_off[i];
             q.dots = hp->bwd[i] ? 2 : 1;
@@ -1363,15 +1405,23 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (!small_first) gb += small_blocks;
         if (alpha_in_hoist) { ka.do_alpha = 1; ka.alpha = aa; }
         BHG_REQUIRE(!rnew || (alpha_in_hoist && full), "k_graw was to apply the residual step but has no step length");
-        ka.rnew = rnew ? 1 : 0;
+        ka.rnew = (rnew || vnew) ? 1 : 0;
+        if (vnew) {   // Rh_0(v') for the next iteration's first product (packed) and for its k_graw (row-major, the other slot)
+          ka.nalpha = cm.alpha; ka.nshift = cm.shift;
+          ka.rh0p = cm.ws->Rhp[0]; ka.rh0 = rh0_slot(cm.nk + 1); ka.mask0 = m->mask[0];
+          ka.rb0 = ka.pb0s = static_cast<const float*>(dir[1]); ka.rh0_prod = hp->gf[0];
+        }
         if (lin) {   // Rh_0(r') for the next iteration's first product; beta's granules cleared for its publication
           ka.rh0p = hbase + hp->rh0rp_off; ka.mask0 = m->mask[0]; ka.rb0 = hbase + hp->rb0c_off;
           ka.pb0s = static_cast<const float*>(dir[1]); ka.gran = cm.ws->gran; ka.rh0_prod = hp->gf[0];
         }
+#ifdef BHG_AB   // (debug key graw_cols = 64)
         if (ct == 64) {
           if (cg) hipLaunchKernelGGL(k_graw64<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
           else hipLaunchKernelGGL(k_graw64<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
-        } else if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        } else
+#endif
+        if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
         else hipLaunchKernelGGL(k_graw<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
       }
       HoistArgs ga{};
@@ -1457,12 +1507,16 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const int total = blk + oa.head_blocks + bias_blk;
       if (lds_max < (size_t)kTM * kCPad * sizeof(float)) lds_max = (size_t)kTM * kCPad * sizeof(float);
       const bool no_pre = dbg(DBG_outer_no_pre, 0) != 0;   // A/B runs
+      (void)no_pre;
       const int stagger = dbg(DBG_outer_stagger, 1);
       oa.stagger = stagger;
+#ifdef BHG_AB
       if (no_pre) {
         if (cg) hipLaunchKernelGGL((k_outer_all<FUSE_CG, false>), dim3(total), dim3(256), lds_max, st, oa, ba);
         else hipLaunchKernelGGL((k_outer_all<FUSE_NEUMANN, false>), dim3(total), dim3(256), lds_max, st, oa, ba);
-      } else {
+      } else
+#endif
+      {
         if (cg) hipLaunchKernelGGL((k_outer_all<FUSE_CG, true>), dim3(total), dim3(256), lds_max, st, oa, ba);
         else hipLaunchKernelGGL((k_outer_all<FUSE_NEUMANN, true>), dim3(total), dim3(256), lds_max, st, oa, ba);
       }
@@ -1588,6 +1642,14 @@ int bhg_mlp_supports_fused_solve(const bhg_mlp* m) {
   return !off && m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && use_head(m);
 }
 
+// The time-out word of the in-launch beta exchange (poll_beta, wskp.inc): non-zero after a solve whose pollers gave up.
+void* bhg_mlp_timeout_flag_dev(const bhg_mlp* m, void* fws) {
+  if (!m || !fws || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS || m->Bp <= 0) return nullptr;
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  return w.gran + 1;
+}
+
 size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m) {
   if (!m || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS || m->Bp <= 0) return 0;
   FusedWs w;
@@ -1611,6 +1673,7 @@ struct CgCtx {
   float cg_alpha, shift;
   FusedWs w; double* scal; const double* partR0; int n_init, pgrid, bgrid;
   bool lazy, hoist, lin; int proj_level;
+  const void* const* rhs;
   BetaArgs ba; HoistPlan hplan;
   const void* dir[2 * BHG_MLP_MAX_LAYERS];
 };
@@ -1618,7 +1681,7 @@ struct CgCtx {
 static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
                         int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws, void* fws, bool global) {
   c->m = m; c->x = x; c->r = r; c->p = p; c->starts = starts; c->chunks_dev = chunks_dev; c->n_chunks = n_chunks; c->K = K;
-  c->cg_alpha = cg_alpha; c->shift = hvp_shift;
+  c->cg_alpha = cg_alpha; c->shift = hvp_shift; c->rhs = nullptr;
   carve_fused_ws(m, fws, &c->w);
   char* wsb = static_cast<char*>(ws);
   c->scal = reinterpret_cast<double*>(wsb + kWsScal);
@@ -1703,6 +1766,7 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
     c->dir[1] = k == 0 ? static_cast<const void*>(c->p + c->starts[1]) : static_cast<const void*>(w.pb0[k & 1]);
   if (c->lin) c->dir[3] = k == 0 ? static_cast<const void*>(c->p + c->starts[3]) : static_cast<const void*>(w.pb1[k & 1]);
   cm.lin = c->lin ? 1 : 0;
+  cm.rhs = c->rhs;
   if (int rc = run_chain(m, c->dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
@@ -1715,6 +1779,26 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
 int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
                      const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
                      void* fws, size_t fws_bytes, void* stream) {
+  return bhg_mlp_cg_solve_rhs(m, x, r, p, starts, chunks_dev, n_chunks, K, cg_alpha, hvp_shift, ws, fws, fws_bytes, nullptr, stream);
+}
+
+unsigned long long bhg_mlp_cg_state_mask(const bhg_mlp* m, int has_x) {
+  if (!m || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS || 2 * m->L > 64 || has_x || !bhg_mlp_supports_fused_solve(m)) return ~0ull;
+  // cg_ctx_init's decision with x == NULL (nothing in it depends on the state pointers)
+  HoistPlan hp;
+  hp.ok = false;
+  if (dbg(DBG_cg_eager_p, 0) == 0 && hoist_mode() != 0) hoist_plan(m, &hp);
+  const bool level2 = hp.ok && hp.proj_ok && proj_mode() != 0 && proj_mode() != 9;
+  if (!level2 || dbg(DBG_cg_rhs_direct, 1) == 0) return ~0ull;
+  unsigned long long mask = 0ull;
+  for (int l = 0; l < m->L; ++l) mask |= 1ull << (2 * l + 1);   // biases
+  mask |= 1ull << (2 * (m->L - 1));                              // the narrow head weight (use_head holds: the fused solve needs it)
+  return mask;
+}
+
+int bhg_mlp_cg_solve_rhs(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts,
+                         const bhg_chunk* chunks_dev, int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws,
+                         void* fws, size_t fws_bytes, const void* const* rhs, void* stream) {
   if (int rc = solve_common_checks(m, starts, fws, fws_bytes)) return rc;
   // x == NULL: the N-sized solution vector is not materialised.  For this structure the mixed second derivative only
   // needs Rz(x) = sum_k alpha_k Rz(p_k), which k_cg_alpha accumulates from the batch-sized Rz of every direction
@@ -1726,7 +1810,11 @@ int bhg_mlp_cg_solve(const bhg_mlp* m, float* x, float* r, float* p, const int64
   hipStream_t st = static_cast<hipStream_t>(stream);
   CgCtx c;
   cg_ctx_init(&c, m, x, r, p, starts, chunks_dev, n_chunks, K, cg_alpha, hvp_shift, ws, fws, false);
-  if (c.hoist && packed_chain_on(c.w))
+  BHG_REQUIRE(!rhs || c.proj_level == 2, "rhs names the right-hand side for the FULLY PROJECTED solver only (see bhg_mlp_cg_state_mask)");
+  if (rhs)
+    for (int l = 0; l + 1 < m->L; ++l) BHG_REQUIRE(rhs[2 * l] && ((uintptr_t)rhs[2 * l] & 15) == 0, "rhs tensors must be 16-byte aligned device pointers");
+  c.rhs = rhs;
+  if (c.hoist && packed_chain_on(c.w) && !m->prepacked)   // (prepacked: bhg_mlp_forward_packed / _backward_packed left the packed operands)
     if (int rc = pack_operands(m, c.w, st)) return rc;
   for (int k = 0; k < K; ++k)
     if (int rc = cg_iteration(&c, k, 0, nullptr, 1.0, st)) return rc;
@@ -1768,7 +1856,7 @@ int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, cons
     BHG_HIP_CHECK(hipGetLastError());
     return BHG_OK;
   }
-  if (k == 0 && phase == BHG_CG_GLOBAL_CHAIN && c.hoist && packed_chain_on(c.w))
+  if (k == 0 && phase == BHG_CG_GLOBAL_CHAIN && c.hoist && packed_chain_on(c.w) && !m->prepacked)
     if (int rc = pack_operands(m, c.w, st)) return rc;
   if (int rc = cg_iteration(&c, k, phase == BHG_CG_GLOBAL_CHAIN ? 1 : 2, php, 1.0 / (double)world, st)) return rc;
   BHG_HIP_CHECK(hipGetLastError());
@@ -1802,7 +1890,7 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
   if (hoist_mode() == 2 || want_proj) hoist_plan(m, &hplan);
   const bool proj = want_proj && hplan.ok && hplan.proj_ok && use_head(m);
   if (projected_out) *projected_out = proj ? 1 : 0;   // the caller hands it to bhg_mlp_neumann_mixed_coeff (no hidden per-workspace state)
-  if (hplan.ok && K > 0 && packed_chain_on(w))
+  if (hplan.ok && K > 0 && packed_chain_on(w) && !m->prepacked)
     if (int rc = pack_operands(m, w, st)) return rc;
   for (int k = 0; k < K; ++k) {
     float* vin = (k & 1) ? v1 : v0;
@@ -1825,6 +1913,7 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     cm.ws = &w;
     cm.hoist = hplan.ok ? &hplan : nullptr;   // every direction product in one grouped launch (k_hoist), as in the CG solver
     cm.proj = proj ? 1 : 0;
+    cm.nk = k;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
     if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
   }
@@ -1837,7 +1926,7 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
     cm.fa = (K & 1) ? v0 : v1; cm.fb = nullptr; cm.fd = vin; cm.starts = starts;
     cm.alpha = alpha; cm.shift = hvp_shift;
     cm.x_mode = 1; cm.rzx_acc = w.rzx; cm.first = 0;
-    cm.ws = &w; cm.hoist = &hplan; cm.proj = 1; cm.stop_after_head = 1;
+    cm.ws = &w; cm.hoist = &hplan; cm.proj = 1; cm.stop_after_head = 1; cm.nk = K;
     if (int rc = run_chain(m, dir, cm, st)) return rc;
   }
   return BHG_OK;
@@ -1931,6 +2020,93 @@ int bhg_mlp_backward(const bhg_mlp* m, const int64_t* labels, void* stream) {
     launch_gemm<LAYOUT_KC, LAYOUT_RC>(a, tn, st);
     launch_reduce_mask(st, m->partial, a.splits, Bp * N, nullptr, m->mask[l - 1], const_cast<float*>(m->delta[l - 1]), Bp,
                        N, B);
+  }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// ---- round 5: the once-per-step passes on the chain's own packed form -------------------------------------------------------------
+// bhg_mlp_forward / bhg_mlp_backward run every hidden layer as a split-K GEMM + a reduce launch (5 pairs, 100 us of a 1.4 ms step at
+// cfg 2).  The solvers' chain needs the weights packed anyway (k_pack, once per solve): packed FIRST, the hidden layers behind the
+// first run as ONE k_wskpf / k_wskpc launch each, and their epilogues leave h_l / delta_l packed for the Gram products and the chain —
+// so k_pack no longer reads them.  The first layer keeps its split-K form (its weight is not an operand of the chain: packing it
+// would cost more than it saves); its reduce launch stores the packed copy of h_1.
+int bhg_mlp_supports_packed_prepare(const bhg_mlp* m) {
+  if (!bhg_mlp_supports_native_prepare(m) || !bhg_mlp_supports_fused_solve(m) || dbg(DBG_packed_prepare, 1) == 0) return 0;
+  HoistPlan hp;
+  hoist_plan(m, &hp);
+  return hp.ok && dbg(DBG_packed_chain, 1) != 0 ? 1 : 0;
+}
+
+int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* fws, size_t fws_bytes,
+                           void* stream) {
+  if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(bias && labels && ce && fws, "NULL argument");
+  BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
+  BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  if (int rc = pack_operands(m, w, st, true)) return rc;
+  {   // first layer: split-K GEMM + reduce (bias, ReLU mask, h_1 row-major and packed)
+    const int K = m->dims[0], N = m->dims[1];
+    GemmArgs a{};
+    a.pr[0] = {m->h[0], m->W[0], K, K};
+    a.pairs = 1;
+    a.M = Bp; a.N = N; a.K = K;
+    const int tn = skinny_tile_n();
+    a.splits = pick_splits((N + tn - 1) / tn, K, 1);
+    a.out = m->partial; a.ldo = N; a.out_rows = Bp;
+    launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    launch_reduce_mask(st, m->partial, a.splits, Bp * N, static_cast<const float*>(bias[0]), nullptr, const_cast<float*>(m->h[1]), Bp, N, B,
+                       const_cast<float*>(m->mask[0]), w.hpk[1]);
+  }
+  for (int l = 1; l + 1 < L; ++l) {   // hidden layers behind the first: one launch on packed operands
+    WskpfArgs f{};
+    WskpProb& q = f.a;
+    q.Ap = w.hpk[l]; q.Bq = w.Wf[l]; q.RA = Bp; q.RB = m->dims[l + 1]; q.K = m->dims[l]; q.B = B; q.nsplit = 1;
+    q.bias = static_cast<const float*>(bias[l]);
+    q.out = const_cast<float*>(m->h[l + 1]);
+    q.outp = l + 2 < L ? w.hpk[l + 1] : nullptr;   // (the head reads h_{L-1} row-major)
+    f.relu_mask = const_cast<float*>(m->mask[l]);
+    wskp_tiling(&q, false);
+    const int blk = q.nfull * (q.RB / 32) + q.nstrip;
+    hipLaunchKernelGGL(k_wskpf<2>, dim3(blk), dim3(64 * kWskpWaves), 0, st, f);
+  }
+  launch_head_forward(st, Bp, nullptr, m->h[L - 1], m->W[L - 1] /* unused: no Rh */, m->W[L - 1], static_cast<const float*>(bias[L - 1]),
+                      nullptr, nullptr, const_cast<float*>(m->prob), m->dims[L - 1], m->dims[L], B, HEAD_LOGITS, labels, ce, nullptr,
+                      nullptr, nullptr);
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+int bhg_mlp_backward_packed(const bhg_mlp* m, const int64_t* labels, void* fws, size_t fws_bytes, void* stream) {
+  if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(labels && fws, "NULL argument");
+  BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
+  BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = m->L, Bp = m->Bp, B = m->B;
+  const int C = m->dims[L];
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  hipLaunchKernelGGL(k_delta_top, dim3((Bp * C + 255) / 256), dim3(256), 0, st, m->prob, m->sd, labels,
+                     const_cast<float*>(m->delta[L - 1]), Bp, C, B);
+  {   // through the head: delta_{L-2}, row-major and packed
+    const int l = L - 1, K = m->dims[l + 1], N = m->dims[l];
+    const int blocks = (Bp * (N / 4) + 255) / 256;
+    hipLaunchKernelGGL(k_head_backward, dim3(blocks), dim3(256), 0, st, (const float*)nullptr, m->delta[l], m->W[l],
+                       (const float*)nullptr, m->mask[l - 1], const_cast<float*>(m->delta[l - 1]), N, K, B, Bp, w.dpk[l - 1]);
+  }
+  for (int l = L - 2; l >= 1; --l) {   // delta_{l-1} = mask_{l-1} * (delta_l W_l): one launch on packed operands
+    WskpBuilder wb;
+    WskpProb q{};
+    q.Ap = w.dpk[l]; q.Bq = w.Wb[l]; q.RA = Bp; q.RB = m->dims[l]; q.K = m->dims[l + 1]; q.B = B; q.nsplit = 1;
+    q.mask = m->mask[l - 1]; q.out = const_cast<float*>(m->delta[l - 1]);
+    q.outp = l >= 2 ? w.dpk[l - 1] : nullptr;
+    wb.add(q);
+    wb.launch(st);
   }
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;

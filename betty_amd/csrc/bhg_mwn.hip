@@ -57,18 +57,31 @@ __global__ __launch_bounds__(kThreads) void k_mwn_backward(const float* __restri
 #pragma unroll
   for (int u = 0; u < kPer; ++u) a_w1[u] = a_b1[u] = a_w2[u] = 0.f;
   float a_b2 = 0.f;   // (thread 0 .. : partial of sum_i dz2_i over the samples this thread owns in phase a)
+  // the first chunk's samples are requested together with the parameters (one round trip to memory, not two: the launch is latency, not work)
+  constexpr int kSPer = kMwnChunk / kThreads;
+  float c_pre[kSPer], k_pre[kSPer];
+#pragma unroll
+  for (int u = 0; u < kSPer; ++u) {
+    const int t = threadIdx.x + kThreads * u;
+    c_pre[u] = ce[t < B ? t : 0];
+    k_pre[u] = coeff[t < B ? t : 0];
+  }
   __syncthreads();
   for (int i0 = 0; i0 < B; i0 += kMwnChunk) {
     const int n = B - i0 < kMwnChunk ? B - i0 : kMwnChunk;
-    for (int t = threadIdx.x; t < n; t += kThreads) {
-      const float c = ce[i0 + t];
+#pragma unroll
+    for (int u = 0; u < kSPer; ++u) {
+      const int t = threadIdx.x + kThreads * u;
+      if (t >= n) continue;
+      const float c = i0 == 0 ? c_pre[u] : ce[i0 + t];
+      const float kc = i0 == 0 ? k_pre[u] : coeff[i0 + t];
       float z = bias2;
       for (int j = 0; j < H; ++j) {
         const float a = fmaf(sp[j], c, sp[H + j]);
         z = fmaf(sp[2 * H + j], a > 0.f ? a : 0.f, z);
       }
       const float v = mwn_sigmoid(z);
-      const float dz = coeff[i0 + t] * (v * (1.f - v));
+      const float dz = kc * (v * (1.f - v));
       sdz[t] = dz;
       sce[t] = c;
       a_b2 += dz;

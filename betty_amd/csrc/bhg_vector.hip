@@ -163,13 +163,16 @@ __global__ __launch_bounds__(kThreads) void k_cg_init(PtrTab tab, const bhg_chun
                                                       float* __restrict__ r, float* __restrict__ p,
                                                       double* __restrict__ partR0,
                                                       unsigned* __restrict__ barrier_words,
-                                                      double* __restrict__ scal) {
+                                                      double* __restrict__ scal, unsigned long long keep_mask) {
+  // keep_mask (bhg_cg_init_masked): bit t clear -> tensor t's slices of r and p are NOT written (only its share of r.r is taken):
+  // a solver that reads those slices of the right-hand side from the caller's tensors and never touches the direction's
   __shared__ double red[kWaves];
   double acc = 0.0;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const bhg_chunk ck = chunks[c];
     const float* src = tab_ptr(tab, ck.tensor) + ck.src_off;
+    const bool keep = ck.tensor >= 64 || ((keep_mask >> ck.tensor) & 1ull) != 0ull;   // (workgroup-uniform)
     float4 t[kVecPerThread];
 #pragma unroll
     for (int i = 0; i < kVecPerThread; ++i) t[i] = ld4(src, 4 * (threadIdx.x + kThreads * i), ck.len);
@@ -177,8 +180,10 @@ __global__ __launch_bounds__(kThreads) void k_cg_init(PtrTab tab, const bhg_chun
     for (int i = 0; i < kVecPerThread; ++i) {
       const int e = 4 * (threadIdx.x + kThreads * i);
       if (x) st4(x + ck.flat_off, e, ck.len, zero);   // x == NULL: the caller does not materialise the solution vector
-      st4(r + ck.flat_off, e, ck.len, t[i]);
-      st4(p + ck.flat_off, e, ck.len, t[i]);
+      if (keep) {
+        st4(r + ck.flat_off, e, ck.len, t[i]);
+        st4(p + ck.flat_off, e, ck.len, t[i]);
+      }
       acc += (double)t[i].x * t[i].x + (double)t[i].y * t[i].y + (double)t[i].z * t[i].z +
              (double)t[i].w * t[i].w;
     }
@@ -908,6 +913,11 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
 
 int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
                 float* p, void* ws, void* stream) {
+  return bhg_cg_init_masked(vec, T, chunks_dev, n_chunks, x, r, p, ~0ull, ws, stream);
+}
+
+int bhg_cg_init_masked(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks, float* x, float* r,
+                       float* p, unsigned long long keep_mask, void* ws, void* stream) {
   BHG_COMMON_CHECKS(vec);
   BHG_REQUIRE(ws, "workspace is NULL");
   if (n_chunks == 0) return BHG_OK;
@@ -918,7 +928,7 @@ int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int 
   char* w = static_cast<char*>(ws);
   hipLaunchKernelGGL(k_cg_init, dim3(grid_for(n_chunks)), dim3(kThreads), 0, st, tab, chunks_dev, n_chunks, x,
                      r, p, reinterpret_cast<double*>(w + kWsPartR),
-                     reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal));
+                     reinterpret_cast<unsigned*>(w + kWsBarrier), reinterpret_cast<double*>(w + kWsScal), keep_mask);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

@@ -31,6 +31,104 @@ class AutogradHVP:
         return torch.autograd.grad(self.in_grad, self.params, grad_outputs=direction_views, retain_graph=True)
 
 
+# ---- forward-over-reverse Hessian-vector product (opt-in, round 5) ------------------------------------------------------------
+# H v = d/d eps [ grad_w L(w + eps v) ]: forward-mode tangents (torch.autograd.forward_ad) carried through ONE evaluation of the
+# loss and its ordinary backward — the same quantity as the double backward of cg.py:39-41 / neumann.py:62, to rounding.  Why it
+# exists: ATen's `_convolution_double_backward` handles a GROUPED convolution by a Python-visible loop over the groups — 16 to 64
+# tiny convolutions per depthwise layer and term — so the double backward of a DARTS supernet (BASELINE cfg 5: the reference's
+# `Network(16, 10, 8)`, eight cells x 14 edges x 4 separable / dilated ops) is ~300 k launches enqueued by the host:
+# 18.4 s per product on the MI355X box against 1.9 s for the whole forward-over-reverse pass, whose derivative formulas are
+# whole-tensor convolutions (profiles/r05_cfg5_hvp_conv_modes.txt).  K + 1 passes per solve: K products and the mixed second
+# derivative d/d eps grad_lambda L(w + eps (-alpha x)); no `in_grad` graph is built at all.
+# OPT-IN: `inner_problem.hypergradient_hvp = "forward_over_reverse"`.  The problem promises that
+#   * its trainable parameters are exactly parameters of `problem.module` (they are swapped for dual tensors by name);
+#   * training_step is a deterministic function of (parameters, batch) given the RNG state: the state at the start of the solve is
+#     restored before every pass, so dropout draws the same masks K + 1 times (the reference's ONE graph has one set of masks);
+#   * module buffers (batch-norm running statistics) may be updated in place: the first pass updates the real ones — once, as the
+#     reference's single training_step call does — the others work on clones.
+# Operators without a forward-mode formula raise NotImplementedError on the first pass: the caller falls back to the double backward.
+def forward_over_reverse_wanted(curr) -> bool:
+    return getattr(curr, "hypergradient_hvp", None) == "forward_over_reverse"
+
+
+class ForwardOverReverseHVP:
+    def __init__(self, curr, prev):
+        import torch.autograd.forward_ad as fwAD  # noqa: PLC0415
+        from torch.nn.utils import stateless  # noqa: PLC0415
+
+        self.fwAD, self._swap = fwAD, stateless._reparametrize_module
+        self.curr, self.prev = curr, prev
+        self.module = curr.module
+        self.params = list(curr.trainable_parameters())
+        by_id = {id(p): n for n, p in self.module.named_parameters()}
+        missing = [i for i, p in enumerate(self.params) if id(p) not in by_id]
+        if missing:
+            raise ValueError("hypergradient_hvp = 'forward_over_reverse': trainable parameters must be parameters of problem.module")
+        self.names = [by_id[id(p)] for p in self.params]
+        dev = self.params[0].device
+        self._cuda = dev.type == "cuda"
+        self._rng_cpu = torch.get_rng_state()
+        self._rng_dev = torch.cuda.get_rng_state(dev) if self._cuda else None
+        self._dev = dev
+        self.passes = 0
+        self.fallback = self.in_grad = None
+
+    def _pass(self, tangents, wrt_upper: bool):
+        fwAD = self.fwAD
+        if self.passes > 0:   # the same random draws as the first pass
+            torch.set_rng_state(self._rng_cpu)
+            if self._cuda:
+                torch.cuda.set_rng_state(self._rng_dev, self._dev)
+        swap = {}
+        if self.passes > 0:   # running statistics were updated by the first pass: later passes must not move them again
+            swap.update({n: b.detach().clone() for n, b in self.module.named_buffers()})
+        self.passes += 1
+        with fwAD.dual_level():
+            duals = [fwAD.make_dual(p.detach().requires_grad_(True), t.detach().reshape(p.shape)) for p, t in zip(self.params, tangents)]
+            swap.update(dict(zip(self.names, duals)))
+            with self._swap(self.module, swap):
+                loss = self.curr.training_step_exec(self.curr.cur_batch)
+            wrt = list(self.prev.trainable_parameters()) if wrt_upper else duals
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                grads = torch.autograd.grad(loss, wrt, allow_unused=wrt_upper)
+            out = []
+            for g, w in zip(grads, wrt):
+                t = None if g is None else fwAD.unpack_dual(g).tangent
+                out.append(torch.zeros_like(w) if t is None else t.detach())
+        return out
+
+    def __call__(self, direction_views: Sequence[torch.Tensor]):
+        if self.fallback is not None:
+            return self.fallback(direction_views)
+        try:
+            return self._pass(direction_views, wrt_upper=False)
+        except (NotImplementedError, RuntimeError) as exc:
+            if self.passes > 1:
+                raise
+            # an operator of this training_step has no forward-mode formula: the reference's double backward takes over for the solve
+            warnings.warn(f"betty_amd: forward-over-reverse HVP not available for this training_step ({type(exc).__name__}: {exc}); "
+                          "using the double backward", RuntimeWarning)
+            torch.set_rng_state(self._rng_cpu)
+            if self._cuda:
+                torch.cuda.set_rng_state(self._rng_dev, self._dev)
+            self.in_grad = inner_gradient(self.curr)
+            self.fallback = AutogradHVP(self.in_grad, self.params)
+            return self.fallback(direction_views)
+
+    def mixed(self, neg_x_views, sync: bool):
+        """cg.py:58-68 / neumann.py:44-54: d(g . neg_x)/d lambda = tangent of grad_lambda L in direction neg_x on the inner weights."""
+        if self.fallback is not None:
+            return mixed_vjp(self.in_grad, self.prev, neg_x_views, sync)
+        grads = self._pass(neg_x_views, wrt_upper=True)
+        upper = list(self.prev.trainable_parameters())
+        if sync:
+            # accumulate THROUGH autograd (AccumulateGrad nodes), like the reference's backward(..., inputs=upper): hooks fire
+            torch.autograd.backward(upper, grad_tensors=grads)
+            return None
+        return grads
+
+
 # ---- hipGraph replay of an opaque Hessian-vector product ----------------------------------------------------------------
 # The double backward of a user's training_step is hundreds to thousands of small ATen launches (cfg 2's MLP: ~1.1 ms per
 # HVP, launch-bound): the K HVPs of one solve run the SAME launch sequence on the SAME addresses — the autograd graph of

@@ -125,7 +125,18 @@ class HipMLPState:
         buf.h[0][:B].copy_(x.detach().to(torch.float32).reshape(B, -1))
         buf.labels[:B].copy_(y.reshape(-1))
 
-        if buf.native_prepare:
+        # the once-per-step passes on the chain's packed operands when the network takes that form (include/bhg.h: the weights are
+        # packed first, the hidden layers behind the first run as one launch each) — decided per call: an A/B key may switch it
+        d.prepacked = 0
+        # (fused or not: every arm of a problem shares ONE set of activations, masks and deltas)
+        self.packed_prepare = bool(buf.native_prepare and lib.bhg_mlp_supports_packed_prepare(ctypes.byref(d)))
+        if self.packed_prepare:
+            fws = self._fused_ws(x.device)
+            bias_tab, self._bias_keep = _native.ptr_array([b.data_ptr() for b in bs])
+            _native.check(lib.bhg_mlp_forward_packed(ctypes.byref(d), bias_tab, buf.labels.data_ptr(), buf.ce.data_ptr(), fws.data_ptr(),
+                                                     fws.numel(), _stream()), "bhg_mlp_forward_packed")
+            ce = buf.ce[:B]
+        elif buf.native_prepare:
             bias_tab, self._bias_keep = _native.ptr_array([b.data_ptr() for b in bs])
             _native.check(lib.bhg_mlp_forward(ctypes.byref(d), bias_tab, buf.labels.data_ptr(), buf.ce.data_ptr(), _stream()),
                           "bhg_mlp_forward")
@@ -148,7 +159,11 @@ class HipMLPState:
         else:
             self.sample_weight = spec.weight_fn(ce.detach().clone())
             buf.sd[:B].copy_(self.sample_weight.detach().reshape(-1).to(torch.float32) / B)
-        if buf.native_prepare:
+        if self.packed_prepare:
+            _native.check(lib.bhg_mlp_backward_packed(ctypes.byref(d), buf.labels.data_ptr(), buf.fws.data_ptr(), buf.fws.numel(), _stream()),
+                          "bhg_mlp_backward_packed")
+            d.prepacked = 1   # the solves of this step find h_l, delta_l and the chain's weights packed
+        elif buf.native_prepare:
             _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
         else:
             self._aten_backward(Ws, y)
@@ -168,7 +183,7 @@ class HipMLPState:
         ``upper``'s order, times ``scale``) when the weight net is declared, else autograd through ``sample_weight``'s graph."""
         if not self.native_upper:
             sw = self.sample_weight
-            out = list(torch.autograd.grad(sw, upper, grad_outputs=coeff.reshape(sw.shape), retain_graph=retain_graph))
+            out = list(torch.autograd.grad(sw, upper, grad_outputs=coeff.reshape(sw.shape), retain_graph=retain_graph, allow_unused=retain_graph))
             return (out, None) if with_flat else out
         ts, B = self._wn, self.B
         H = ts[0].shape[0]
@@ -251,25 +266,46 @@ class HipMLPState:
             want += [W.numel(), W.shape[0]]
         return tuple(want) == tuple(layout.numels) and str(layout.device) == str(self.Ws[0].device)
 
-    def _fused_args(self, layout):
+    def _fused_ws(self, device):
         buf = self.buf
         if getattr(buf, "fws", None) is None:
             n = int(self.lib.bhg_mlp_fused_ws_bytes(ctypes.byref(self.desc)))
-            buf.fws = torch.zeros(max(n, 256), dtype=torch.uint8, device=layout.device)
-        starts = (ctypes.c_int64 * len(layout.starts))(*layout.starts)
-        return buf.fws, starts
+            buf.fws = torch.zeros(max(n, 256), dtype=torch.uint8, device=device)
+            # the solver's time-out word (bounded in-launch beta exchange): diagnosed by HipBackend.check_health
+            addr = self.lib.bhg_mlp_timeout_flag_dev(ctypes.byref(self.desc), buf.fws.data_ptr())
+            if addr:
+                off = int(addr) - buf.fws.data_ptr()
+                buf.fws_flag = buf.fws[off: off + 4].view(torch.int32)
+                from ..backend import get_backend  # noqa: PLC0415
 
-    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True) -> FusedSolve:
+                get_backend().watch_fused_workspace(buf.fws_flag)
+        return buf.fws
+
+    def _fused_args(self, layout):
+        fws = self._fused_ws(layout.device)
+        starts = (ctypes.c_int64 * len(layout.starts))(*layout.starts)
+        return fws, starts
+
+    def cg_state_mask(self):
+        """Which tensors' slices of r / p the coming solve (without a solution vector) reads or writes: None = all of them, else the
+        bit mask of bhg_mlp_cg_state_mask — the fully projected solver keeps only the biases and the head weight N-sized."""
+        mask = int(self.lib.bhg_mlp_cg_state_mask(ctypes.byref(self.desc), 0))
+        return None if mask == (1 << 64) - 1 else mask
+
+    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True, rhs=None) -> FusedSolve:
         """cg.py:38-56 for this structure: K x (HVP chain with fused r/x update + direction update).
         keep_x=False: the library gets x = NULL and never reads or writes the solution vector.  Returns the token that
-        lets mixed_coeff() work from the Rz(x) the solver accumulated."""
+        lets mixed_coeff() work from the Rz(x) the solver accumulated.  rhs: the right-hand side's own tensors (what cg_init read),
+        for a solve whose r / p were initialised through cg_state_mask()."""
         fws, starts = self._fused_args(layout)
+        rhs_tab, _rhs_keep = (None, None) if rhs is None else _native.ptr_array([t.data_ptr() for t in rhs])
         _native.check(
-            self.lib.bhg_mlp_cg_solve(ctypes.byref(self.desc), x.data_ptr() if keep_x else None, r.data_ptr(), p.data_ptr(), starts,
-                                      layout.chunks_dev.data_ptr(), layout.n_chunks, int(K), float(cg_alpha), float(shift),
-                                      layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), _stream()),
-            "bhg_mlp_cg_solve",
+            self.lib.bhg_mlp_cg_solve_rhs(ctypes.byref(self.desc), x.data_ptr() if keep_x else None, r.data_ptr(), p.data_ptr(), starts,
+                                          layout.chunks_dev.data_ptr(), layout.n_chunks, int(K), float(cg_alpha), float(shift),
+                                          layout.workspace.data_ptr(), fws.data_ptr(), fws.numel(), rhs_tab, _stream()),
+            "bhg_mlp_cg_solve_rhs",
         )
+        self._rhs_keep = (rhs, _rhs_keep)   # the solve is asynchronous: its first iteration reads these tensors
         # the solver accumulated Rz(x) on its way: mixed_coeff(solve=token) of exactly this solution needs no R-forward pass
         self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=keep_x)
         return self._solve

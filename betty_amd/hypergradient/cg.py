@@ -11,7 +11,8 @@ streaming kernels (40*N bytes) instead of ~10*T ATen launches moving ~140*N byte
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, persistent_graphs_for, solve_stream
+from ._common import (AutogradHVP, ForwardOverReverseHVP, GraphedHVP, forward_over_reverse_wanted, hvp_graph_wanted, inner_gradient,
+                      mixed_vjp, persistent_graphs_for, solve_stream)
 from .structured import structured_hvp_for
 
 
@@ -36,17 +37,20 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
     be = get_backend()
     layout = be.layout(vector)
     x, r, p = layout.state(3)
-    keep_graph = False
+    keep_graph = for_hvp = False
     if provider is None:
         if persist is not None:
             in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.parameters()), layout.views(p, vector), prev)
+        elif forward_over_reverse_wanted(curr):
+            # opt-in: H p by forward-over-reverse passes (no double-backward graph; _common.ForwardOverReverseHVP)
+            in_grad, hvp_fn, for_hvp = None, ForwardOverReverseHVP(curr, prev), True
         else:
             in_grad = inner_gradient(curr)
             hvp_fn = AutogradHVP(in_grad, curr.parameters())
     else:
         in_grad = None
         hvp_fn = provider.prepare()
-    if graphed and persist is None:
+    if graphed and persist is None and not for_hvp:
         hvp_fn = GraphedHVP(hvp_fn)
 
     alpha = float(config.cg_alpha)
@@ -55,12 +59,23 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
     # WeightedCEMLP.keep_solution): then x is not even zeroed
     skips = getattr(provider, "fused_cg_skips_solution", None)
     skip_x = bool(fused is not None and alpha != 0.0 and skips is not None and skips(layout, K))
-    be.cg_init(layout, vector, None if skip_x else x, r, p)  # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
+    # ... and a fused solver that works from batch-sized projections reads the N-sized right-hand side once, in its first iteration:
+    # it says which tensors' slices of r / p it needs at all (fused_cg_state_mask) and reads the others from `vector` itself
+    state_mask = getattr(provider, "fused_cg_state_mask", None)
+    keep_mask = state_mask(layout, K) if (skip_x and state_mask is not None) else None
+    # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
+    rhs = be.cg_init(layout, vector, None if skip_x else x, r, p, keep_mask=keep_mask) if keep_mask is not None else \
+        be.cg_init(layout, vector, None if skip_x else x, r, p)
     p_views = layout.views(p, vector)
 
     # a structured provider may leave a diagonal part of the Hessian (ridge) to the recurrence kernel
     shift = float(getattr(provider, "hvp_shift", 0.0)) if provider is not None else 0.0
-    solve = fused(layout, x, r, p, K, alpha) if (fused is not None and alpha != 0.0) else False
+    if fused is not None and alpha != 0.0:
+        solve = fused(layout, x, r, p, K, alpha, rhs=rhs) if keep_mask is not None else fused(layout, x, r, p, K, alpha)
+        if keep_mask is not None and not solve:   # (r / p were initialised for THAT solver only: the generic loop below must not run on them)
+            raise RuntimeError("a provider that announced a state mask must run its fused solver")
+    else:
+        solve = False
     if solve:
         pass  # the provider's own kernels ran all K iterations (HVP outputs consumed on chip, no N-sized H p)
     else:
@@ -79,6 +94,8 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_x, sync, solve=solve)
         return provider.mixed_vjp(neg_x, sync)
+    if for_hvp:   # the mixed second derivative is one more forward-over-reverse pass (or the fallback's double backward)
+        return hvp_fn.mixed(neg_x, sync)
     if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
         return persist.mixed(prev, neg_x, sync)
     return mixed_vjp(in_grad, prev, neg_x, sync)

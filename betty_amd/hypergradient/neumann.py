@@ -8,7 +8,8 @@ ATen launches; the final ``alpha*p`` and the negation are folded into the last i
 from __future__ import annotations
 
 from ..backend import get_backend
-from ._common import AutogradHVP, GraphedHVP, hvp_graph_wanted, inner_gradient, mixed_vjp, persistent_graphs_for, solve_stream
+from ._common import (AutogradHVP, ForwardOverReverseHVP, GraphedHVP, forward_over_reverse_wanted, hvp_graph_wanted, inner_gradient,
+                      mixed_vjp, persistent_graphs_for, solve_stream)
 from .structured import structured_hvp_for
 
 
@@ -29,18 +30,21 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
     be = get_backend()
     layout = be.layout(vector)
     v, p = layout.state(2)
-    keep_graph = False
+    keep_graph = for_hvp = False
     if provider is None:
         # neumann.py:39 differentiates w.r.t. trainable_parameters() (cg uses parameters())
         if persist is not None:
             in_grad, hvp_fn, keep_graph = persist.begin_step(curr, list(curr.trainable_parameters()), layout.views(v, vector), prev)
+        elif forward_over_reverse_wanted(curr):
+            # opt-in: H v by forward-over-reverse passes (no double-backward graph; _common.ForwardOverReverseHVP)
+            in_grad, hvp_fn, for_hvp = None, ForwardOverReverseHVP(curr, prev), True
         else:
             in_grad = inner_gradient(curr)
             hvp_fn = AutogradHVP(in_grad, curr.trainable_parameters())
     else:
         in_grad = None
         hvp_fn = provider.prepare()
-    if graphed and persist is None:
+    if graphed and persist is None and not for_hvp:
         hvp_fn = GraphedHVP(hvp_fn)
 
     alpha = float(config.neumann_alpha)
@@ -68,6 +72,8 @@ def _neumann(vector, curr, prev, sync, provider, K, graphed, persist=None):
         if solve and solve is not True:   # a token: the provider is told WHICH solve these views name (see structured.py)
             return provider.mixed_vjp(neg_p, sync, solve=solve)
         return provider.mixed_vjp(neg_p, sync)
+    if for_hvp:   # the mixed second derivative is one more forward-over-reverse pass (or the fallback's double backward)
+        return hvp_fn.mixed(neg_p, sync)
     if keep_graph:   # the captured autograd graph of `in_grad` outlives the step (see PersistentOpaqueGraphs.saved_versions)
         return persist.mixed(prev, neg_p, sync)
     return mixed_vjp(in_grad, prev, neg_p, sync)

@@ -111,6 +111,12 @@ int bhg_neumann_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev,
                                launch (40 bytes per streamed element), up to bhg_cg_resident_capacity_chunks() */
 int bhg_cg_init(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, void* ws, void* stream);
+/* The same with a per-tensor write mask (round 5): bit t of keep_mask clear (t < 64) -> tensor t's slices of r and p are left
+ * untouched; its share of r.r is still taken.  For a solver that reads those slices of the right-hand side from the caller's own
+ * tensors and never reads the direction's (bhg_mlp_cg_solve_rhs with the mask bhg_mlp_cg_state_mask returns): at the metric
+ * workload 80 MB of writes per hypergradient step that nothing ever read.  keep_mask = ~0: bhg_cg_init.                        */
+int bhg_cg_init_masked(const void* const* vec, int T, const bhg_chunk* chunks_dev, int n_chunks,
+                       float* x, float* r, float* p, unsigned long long keep_mask, void* ws, void* stream);
 int bhg_cg_step(const void* const* hvp, int T, const bhg_chunk* chunks_dev, int n_chunks,
                 float* x, float* r, float* p, float cg_alpha, int iter, float out_scale,
                 float hvp_shift /* operator = HVP + hvp_shift*I, see bhg_neumann_step */, int variant,
@@ -181,6 +187,10 @@ int bhg_debug_unset(const char* key);
 void bhg_debug_reset(void);                       /* every key back to unset        */
 int bhg_debug_key_count(void);
 const char* bhg_debug_key_name(int i);            /* NULL past the end              */
+/* Round 5: the table lives in the MEASUREMENT build only (libbhg_ab.so, `make -C betty_amd/csrc ab`, -DBHG_AB; same sources, same
+ * ABI).  In the product libbhg.so every key is compiled to its default — the arms are not in the code object — bhg_debug_set()
+ * returns BHG_ERR_ARG, bhg_debug_key_count() is 0 and bhg_is_ab_build() is 0.                                                      */
+int bhg_is_ab_build(void);
 
 /* ---- optional kernel timing (measurement only) ----------------------------------
  * When enabled, every bhg_cg_step / bhg_neumann_step launch group carries start/stop
@@ -230,6 +240,9 @@ typedef struct bhg_mlp {
   float* partial;                         /* split-K scratch, >= bhg_mlp_partial_floats() floats    */
   size_t partial_floats;
   float ridge2;                           /* 2 * ridge                                              */
+  int32_t prepacked;                      /* round 5: 1 = bhg_mlp_forward_packed + bhg_mlp_backward_packed filled the packed operands
+                                             inside the fused workspace for THESE weights and THIS batch (the solvers then skip their
+                                             packing launch); 0 otherwise                              */
 } bhg_mlp;
 size_t bhg_mlp_partial_floats(const bhg_mlp* m);
 /* dir / out: host arrays of 2L device pointers [V_0, c_0, V_1, c_1, ...] / [H(W_0), H(b_0), ...]
@@ -304,6 +317,17 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
 int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
                             int n_chunks, int k, int K, int phase, int world, double* php, float cg_alpha, float hvp_shift,
                             void* ws, void* fws, size_t fws_bytes, void* stream);
+/* bhg_mlp_cg_solve with the right-hand side's tensors named (round 5).  rhs: 2L device pointers [W_0-shaped, b_0-shaped, ...] — the
+ * tensors bhg_cg_init(_masked) was given — or NULL (= bhg_mlp_cg_solve).  The fully projected solver reads the N-sized residual
+ * exactly once, in iteration 0, where r = the right-hand side: with rhs it reads the MFMA layers' slices THERE, so the caller may
+ * skip writing them (and the direction's, which it never reads) in bhg_cg_init_masked.
+ * bhg_mlp_cg_state_mask: bit t set -> the solve reads / writes tensor t's slice of r, p (t = 2l: W_l, 2l + 1: b_l); all ones unless the
+ * solve will run fully projected (has_x = 0, the plan's cost model, no A/B key against it) — then only the biases and the head
+ * weight.  Evaluate it right before bhg_cg_init_masked; a non-trivial mask obliges the caller to pass rhs.                         */
+unsigned long long bhg_mlp_cg_state_mask(const bhg_mlp* m, int has_x);
+int bhg_mlp_cg_solve_rhs(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
+                         int n_chunks, int K, float cg_alpha, float hvp_shift, void* ws, void* fws, size_t fws_bytes,
+                         const void* const* rhs, void* stream);
 /* Mixed-derivative coefficient (see bhg_mlp_mixed_coeff) of the solution of the LAST bhg_mlp_cg_solve on `fws`,
  * without another R-forward pass: x is a linear combination of the CG directions, and the solver accumulated
  * Rz(x) = sum_k alpha_k Rz(p_k) from the Rz every iteration's head kernel computes anyway.                          */
@@ -339,6 +363,25 @@ int64_t bhg_mlp_proj_iterations(void);
  * the workspace address; the library holds no per-workspace state any more.) */
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff,
                                 float alpha, int K, int projected, void* fws, size_t fws_bytes, void* stream);
+
+/* ---- the once-per-step passes on packed operands (round 5) -----------------------------------------------------------------------
+ * bhg_mlp_forward / bhg_mlp_backward with the hidden layers behind the first as ONE launch each on the chain's packed form
+ * (csrc/mlp/wskp.inc) instead of a split-K GEMM + reduce pair.  They need the fused workspace: the weights are packed into it first
+ * (the launch the solvers would otherwise do), and the products' epilogues leave h_l / delta_l packed there as well.  After BOTH calls
+ * the caller sets m->prepacked = 1 for the solves of this step (same weights, same batch, same fws).  Same results as the split-K
+ * pair up to the summation order of the dot products.  bhg_mlp_supports_packed_prepare: 1 when the network takes this form (the
+ * hoisted plan applies: >= 3 layers, hidden widths % 32 == 0, narrow head).                                                        */
+int bhg_mlp_supports_packed_prepare(const bhg_mlp* m);
+int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* fws, size_t fws_bytes,
+                           void* stream);
+int bhg_mlp_backward_packed(const bhg_mlp* m, const int64_t* labels, void* fws, size_t fws_bytes, void* stream);
+
+/* Device address of the fused solvers' time-out word inside `fws` (4 bytes, zero in a freshly zeroed workspace): workgroups of the
+ * fully projected CG solver's first chain launch receive beta from ANOTHER workgroup of the same launch (published in 64 replicated
+ * granules, csrc/mlp/wskp.inc poll_beta).  That wait is bounded: a poller that gives up (~1 s) sets this word to 1 and continues with
+ * NaN, so the solve ends with a poisoned result instead of hanging the GPU — the same contract as the resident CG kernel's grid
+ * barrier (bhg_cg_timeout_flag_dev).  The caller reads and clears it (HipBackend.check_health).  NULL on a bad descriptor.          */
+void* bhg_mlp_timeout_flag_dev(const bhg_mlp* m, void* fws);
 
 /* ---- closed-form meta-weight-net (round 5; csrc/bhg_mwn.hip) --------------------------------------------------------------------
  * The UPPER problem of data reweighting (examples/learning_to_reweight/model.py:98-111 `MLP(hidden_size, num_layers = 1)`, called at

@@ -9,6 +9,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 algo = sys.argv[2] if len(sys.argv) > 2 else "cg"
 fused = (sys.argv[3] if len(sys.argv) > 3 else "fused") == "fused"
 from betty_amd import _native
+if sys.argv[4:]:
+    _native.use_ab(True)   # measurement arms live in libbhg_ab.so
 for kv in sys.argv[4:]:   # measurement arms: key=int (bhg_debug_set)
     k, _, v = kv.partition("=")
     _native.debug_set(k, int(v))

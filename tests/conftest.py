@@ -63,11 +63,17 @@ class _DebugArms:
 
 @pytest.fixture
 def bhg_debug():
+    """Measurement / test arms live in libbhg_ab.so (the same sources, -DBHG_AB): a test that takes this fixture runs on THAT library
+    — its default arm is the product's only form — and the process goes back to the product libbhg.so afterwards."""
     from betty_amd import _native
 
+    _native.use_ab(True)
     _native.debug_reset()
-    yield _DebugArms()
-    _native.debug_reset()
+    try:
+        yield _DebugArms()
+    finally:
+        _native.debug_reset()
+        _native.use_ab(False)
 
 
 _GOLDEN_CACHE = {}

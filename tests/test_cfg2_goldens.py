@@ -89,7 +89,7 @@ def _arms(algo):
                  ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
                  ("fused-gram-256", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KCHUNK": "256"})),
                  # round 4: the chain on row-major operands through the LDS-staged form (round 3's product), the Gram products in a
-                 # launch of their own, and the packed K loop with two / four register stages (default: three)
+                 # launch of their own, and the packed K loop with two (the default) / three register stages
                  ("fused-unpacked", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_CHAIN": "0"})),
                  ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
                  ("fused-graw-v1", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAW_V2": "0"})),
@@ -99,8 +99,11 @@ def _arms(algo):
                  ("fused-upd-in-first", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_UPDATE_NEXT": "0"})),
                  ("fused-kpstep-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_FIRST": "0"})),
                  ("fused-graw-stores-raw", dict(hvp="hip", fused=True, wsk=None, env={"BHG_RNEW_IN_GRAW": "0"})),
-                 ("fused-packed-d2", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "2"})),
-                 ("fused-packed-d4", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "4"}))]
+                 # WskpBuilder::launch builds depths 2 (the default) and 3 only — any other value runs depth 3 — and the
+                 # key reaches k_wskp / k_wskpc, not the hard-wired <2, ...> instances k_wskpl / k_wskpu
+                 ("fused-packed-d2-default", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "2"})),
+                 ("fused-packed-d3", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_DEPTH": "3"})),
+                 ("fused-upper-autograd", dict(hvp="hip", fused=True, wsk=None, upper="autograd"))]
         arms += [("unfused-stream", dict(hvp="hip", fused=False, wsk=None, variant="stream")),
                  ("autograd-resident", dict(hvp="autograd", variant="resident")), ("autograd-stream", dict(hvp="autograd", variant="stream"))]
     else:
@@ -110,6 +113,11 @@ def _arms(algo):
                  ("fused-gram-nosplit", dict(hvp="hip", fused=True, wsk=None, env={"BHG_GRAM_KSPLIT": "0"})),
                  ("fused-unpacked", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_CHAIN": "0"})),
                  ("fused-gram-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_PACKED_GRAM": "0"})),
+                 # round 5: the default's k_graw applies v' = v - alpha (raw + shift v) itself (six launches); the arm keeps the
+                 # update launch at the top of the iteration (round 4's seven)
+                 ("fused-update-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_NEUMANN_VNEW": "0"})),
+                 # the meta-weight-net through autograd (round 4's path) instead of its closed form
+                 ("fused-upper-autograd", dict(hvp="hip", fused=True, wsk=None, upper="autograd")),
                  ("autograd", dict(hvp="autograd"))]
     return arms
 
@@ -134,7 +142,7 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
     else:
         bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
     for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH", "BHG_GRAW_V2",
-                "BHG_ALPHA_IN_HOIST", "BHG_LIN_UPDATE_NEXT", "BHG_LIN_FIRST", "BHG_RNEW_IN_GRAW"):
+                "BHG_ALPHA_IN_HOIST", "BHG_LIN_UPDATE_NEXT", "BHG_LIN_FIRST", "BHG_RNEW_IN_GRAW", "BHG_NEUMANN_VNEW"):
         bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         bhg_debug.setenv(key, val)
@@ -143,7 +151,8 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
     try:
         curr, prev, vector = bench.build(torch.device("cuda:0"), seed, K=K, algo=algo, ridge=ridge)
         if arm["hvp"] == "hip":
-            bench.declare_structure(curr, "hip", fused=arm["fused"], keep_solution=arm.get("keep", False))
+            bench.declare_structure(curr, "hip", fused=arm["fused"], keep_solution=arm.get("keep", False),
+                                    native_upper=arm.get("upper") != "autograd")
         out = hg.jvp_fn_mapping[algo](vector, curr, prev, False)
         return [t.detach().cpu().numpy() for t in out]
     finally:

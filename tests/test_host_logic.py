@@ -435,22 +435,130 @@ def test_structure_guard_rejects_a_training_step_the_closed_form_does_not_descri
 def test_cfg5_named_network_is_the_references_own():
     """BASELINE cfg 5 names `Network(16, 10, 8)` + `Architecture` of examples/neural_architecture_search/model_search.py:129-234,
     302-317.  The GPU test builds exactly that model from the reference's files (staged test-only by `make -C oracle ref`): here,
-    without a GPU, its size is pinned — 1,930,618 parameters in 1,399 tensors, 2 x 14 x 8 = 224 architecture parameters."""
-    import importlib
-    import types
-
-    nas = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "examples_nas")
-    if not os.path.isfile(os.path.join(nas, "model_search.py")):
+    without a GPU, its size is pinned — 1,930,618 parameters in 1,399 tensors, 2 x 14 x 8 = 224 architecture parameters — and the
+    seeded problem zoo.cfg5_as_named_case builds is the one the committed reference-CPU golden was generated from (checksums)."""
+    if zoo.nas_dir() is None:
         pytest.skip("reference NAS example not staged (make -C oracle ref)")
-    if "utils" not in sys.modules or not hasattr(sys.modules["utils"], "accuracy"):
-        stub = types.ModuleType("utils")
-        stub.accuracy = lambda output, target, topk=(1,): [torch.zeros(()) for _ in topk]
-        sys.modules["utils"] = stub
-    sys.path.insert(0, nas)
-    try:
-        ms = importlib.import_module("model_search")
-    finally:
-        sys.path.remove(nas)
-    net, arch = ms.Network(16, 10, 8, torch.nn.CrossEntropyLoss()), ms.Architecture(4)
-    assert (sum(p.numel() for p in net.parameters()), len(list(net.parameters()))) == (1_930_618, 1_399)
-    assert sum(p.numel() for p in arch.parameters()) == 224
+    curr, prev, vector = zoo.cfg5_as_named_case(Config, torch.device("cpu"))
+    assert (sum(p.numel() for p in curr.parameters()), len(list(curr.parameters()))) == (1_930_618, 1_399)
+    assert sum(p.numel() for p in prev.parameters()) == 224
+    assert curr.config.type == "neumann" and curr.config.neumann_iterations == 20
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg5_as_named.npz")
+    if os.path.isfile(gold_path):
+        gold = np.load(gold_path)
+        np.testing.assert_array_equal(zoo.cfg5_checksums(curr, prev, vector), gold["checksum"])
+        assert gold["neumann20/fp32"].shape == (224,) and np.isfinite(gold["neumann20/fp32"]).all()
+        # the reference's own fp32 run is the reference's own fp64 run to its stated spread
+        spread = np.linalg.norm(gold["neumann20/fp32"] - gold["neumann20/fp64"]) / np.linalg.norm(gold["neumann20/fp64"])
+        assert abs(spread - float(gold["neumann20/ref_spread"])) <= 1e-12 + 1e-6 * spread
+
+
+# ---- round 5: forward-over-reverse Hessian-vector products (opt-in: inner_problem.hypergradient_hvp) ------------------------------
+class _ConvBNDrop(torch.nn.Module):
+    """Depthwise + pointwise convolution, batch norm with running statistics, dropout: the operators whose double backward the
+    forward-over-reverse pass replaces, and the two kinds of state a repeated training_step could disturb."""
+
+    def __init__(self):
+        super().__init__()
+        self.dw = torch.nn.Conv2d(4, 4, 3, padding=1, groups=4, bias=False)
+        self.pw = torch.nn.Conv2d(4, 6, 1, bias=False)
+        self.bn = torch.nn.BatchNorm2d(6, affine=False)
+        self.drop = torch.nn.Dropout(0.25)
+        self.fc = torch.nn.Linear(6, 3)
+
+    def forward(self, x, gate):
+        h = torch.tanh(self.bn(self.pw(self.dw(x)))) * gate.reshape(1, -1, 1, 1)
+        return self.fc(self.drop(h.mean((2, 3))))
+
+
+class _Gate(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.g = torch.nn.Parameter(torch.linspace(0.5, 1.5, 6))
+
+    def forward(self):
+        return torch.sigmoid(self.g)
+
+
+def _convbn_case(algo, K, seed=3):
+    torch.manual_seed(seed)
+    inner, upper = _ConvBNDrop(), _Gate()
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.randn(8, 4, 6, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+    vector = [0.1 * torch.randn(p.shape, generator=g) for p in inner.parameters()]
+    prev = zoo.StubProblem("upper", upper, config=Config())
+    cfg = Config(type="cg", cg_iterations=K, cg_alpha=1.0) if algo == "cg" else Config(type="neumann", neumann_iterations=K, neumann_alpha=0.05)
+
+    def loss_fn(self, batch):
+        xb, yb = batch
+        out = self.module(xb, prev.module())
+        return torch.nn.functional.cross_entropy(out, yb) + 0.5 * sum((p * p).sum() for p in self.module.parameters())
+
+    curr = zoo.StubProblem("inner", inner, config=cfg, loss_fn=loss_fn, batch=(x, y))
+    return curr, prev, vector
+
+
+@pytest.mark.parametrize("algo,K", [("cg", 4), ("neumann", 5)])
+@pytest.mark.parametrize("sync", [False, True])
+def test_forward_over_reverse_hvp_matches_the_double_backward(algo, K, sync, checker):
+    """Same solve twice on the same seeded problem — the reference's double backward (default) and the opt-in forward-over-reverse
+    passes — through the host path: same hypergradient to rounding, same RNG state afterwards (dropout drew ONE set of masks, as in the
+    reference's single graph), batch-norm running statistics advanced exactly once in both."""
+    res = {}
+    for mode in (None, "forward_over_reverse"):
+        curr, prev, vector = _convbn_case(algo, K)
+        if mode:
+            curr.hypergradient_hvp = mode
+        torch.manual_seed(11)
+        out = hg.jvp_fn_mapping[algo](vector, curr, prev, sync)
+        if sync:
+            assert out is None
+            out = [p.grad for p in prev.trainable_parameters()]
+        res[mode] = ([o.detach().numpy().astype(np.float64) for o in out], torch.get_rng_state().clone(),
+                     curr.module.bn.running_mean.clone(), int(curr.module.bn.num_batches_tracked))
+    rel, _ = rel_err(res["forward_over_reverse"][0], res[None][0])
+    assert rel <= 2e-5, rel
+    assert torch.equal(res["forward_over_reverse"][1], res[None][1]), "the K + 1 passes must leave the RNG where ONE training_step leaves it"
+    assert res["forward_over_reverse"][3] == res[None][3] == 1
+    torch.testing.assert_close(res["forward_over_reverse"][2], res[None][2], rtol=1e-6, atol=1e-7)
+
+
+def test_forward_over_reverse_falls_back_when_an_operator_has_no_forward_formula(checker):
+    """A training_step through a custom autograd.Function without a jvp: the first pass raises, the solve continues on the double
+    backward (with a warning) and gives the default's answer."""
+
+    class Square(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.save_for_backward(x)
+            return x * x
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            return 2.0 * x * g
+
+    res = {}
+    for mode in (None, "forward_over_reverse"):
+        torch.manual_seed(5)
+        inner = torch.nn.Linear(5, 1, bias=False)
+        upper = _Gate()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(16, 5, generator=g)
+        prev = zoo.StubProblem("upper", upper, config=Config())
+
+        def loss_fn(self, batch, prev=prev):
+            return Square.apply(self.module(batch)).mean() * prev.module().sum() + (self.module.weight ** 2).sum()
+
+        curr = zoo.StubProblem("inner", inner, config=Config(type="neumann", neumann_iterations=3, neumann_alpha=0.05), loss_fn=loss_fn, batch=x)
+        if mode:
+            curr.hypergradient_hvp = mode
+        vector = [0.1 * torch.randn(p.shape, generator=g) for p in inner.parameters()]
+        if mode:
+            with pytest.warns(RuntimeWarning, match="forward-over-reverse HVP not available"):
+                out = hg.neumann(vector, curr, prev, False)
+        else:
+            out = hg.neumann(vector, curr, prev, False)
+        res[mode] = [o.detach().numpy().astype(np.float64) for o in out]
+    rel, _ = rel_err(res["forward_over_reverse"], res[None])
+    assert rel <= 1e-6, rel

@@ -33,10 +33,38 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_libs", {})
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libbhg.so"))
     with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
         _native.load()
+
+
+def test_the_product_has_no_measurement_arm_and_the_measurement_build_has_them_all():
+    """Round 5: libbhg.so is built WITHOUT the A/B table (every dbg(key, dflt) is the constant dflt, the arm-only kernel instances are
+    not in its code object); libbhg_ab.so — the same sources with -DBHG_AB — carries the table for the every-arm tests and the
+    same-box A/B measurements.  Same ABI: one binding serves both."""
+    try:
+        _native.use_ab(False)
+        lib = _native.load()
+        assert not _native.is_ab() and lib.bhg_debug_key_count() == 0 and lib.bhg_debug_key_name(0) is None
+        assert lib.bhg_debug_set(b"mlp_proj", 0) != 0 and b"product build" in lib.bhg_last_error()
+        with pytest.raises(_native.NativeLibraryError, match="use_ab"):
+            _native.debug_set("mlp_proj", 0)
+        _native.debug_set("mlp_proj", None)   # un-setting is a no-op everywhere
+        _native.use_ab(True)
+        ab = _native.load()
+        assert ab is not lib and _native.is_ab() and ab.bhg_debug_key_count() >= 50
+        keys = _native.debug_keys()
+        for k in ("mlp_proj", "packed_chain", "lin_withhold_beta", "neumann_vnew", "cg_rhs_direct", "packed_prepare"):
+            assert k in keys
+        _native.debug_set("mlp_proj", 0)
+        _native.debug_reset()
+        for name in _declared_symbols():
+            assert hasattr(ab, name), name
+        # the arms are code: the product's shared object is smaller by the kernels only they launch
+        assert os.path.getsize(_native.LIB_PATH) < 0.9 * os.path.getsize(_native.AB_LIB_PATH)
+    finally:
+        _native.use_ab(False)
 
 
 def test_product_backend_refuses_cpu():
