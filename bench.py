@@ -153,7 +153,7 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
 def pmc_traffic(key, N):

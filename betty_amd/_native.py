@@ -162,6 +162,7 @@ SYMBOLS = {
     "bhg_mlp_wsk_launches": (c_int64, []),
     "bhg_mlp_hoist_launches": (c_int64, []),
     "bhg_mlp_proj_iterations": (c_int64, []),
+    "bhg_mlp_lin_launches": (c_int64, []),
     "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
@@ -169,10 +170,30 @@ _libs = {}          # path -> bound CDLL
 _current = [None]   # path of the library load() returns: LIB_PATH (the product) unless use_ab() switched
 
 
+_PY_ENV = {"BHG_LIB", "BHG_AB_LIB", "BHG_HVP_GRAPH", "BHG_ALL_RANKS_ON_GPU0"}   # what the PYTHON side reads; the library reads nothing
+_warned_env = [False]
+
+
+def _warn_legacy_env() -> None:
+    """Rounds 1-3 selected measurement arms through BHG_* environment variables; since round 4 the library reads none, and scripts
+    that still export them would silently measure the default arm under an A/B label.  Say so, once."""
+    if _warned_env[0]:
+        return
+    _warned_env[0] = True
+    stale = sorted(k for k in os.environ if k.startswith("BHG_") and k not in _PY_ENV)
+    if stale:
+        import warnings
+
+        warnings.warn("betty_amd: environment variable(s) " + ", ".join(stale) + " are IGNORED — libbhg reads no environment variable. "
+                      "Measurement arms are selected with betty_amd._native.use_ab() + debug_set(key, int) (bench.py --debug KEY=INT) "
+                      "on the measurement build libbhg_ab.so.", RuntimeWarning, stacklevel=3)
+
+
 def _bind(path: str) -> ctypes.CDLL:
     lib = _libs.get(path)
     if lib is not None:
         return lib
+    _warn_legacy_env()
     if not os.path.exists(path):
         raise NativeLibraryError(
             f"{path} not found: the HIP extension has not been built. Run "

@@ -78,6 +78,7 @@ inline bool wsk_eligible(const WskArgs& a) {
 int64_t g_wsk_launches = 0;   // bhg_mlp_wsk_launches()
 int64_t g_hoist_launches = 0; // bhg_mlp_hoist_launches()
 int64_t g_proj_iterations = 0; // bhg_mlp_proj_iterations()
+int64_t g_lin_launches = 0;    // bhg_mlp_lin_launches()
 template <int LB>
 void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
   WskArgs a = a_in;
@@ -513,10 +514,11 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
       hp->eslabp_off[l] = off; off += (size_t)2 * Bp * Bp;
     }
   }
-  // L == 4 exactly: the update blocks then ride in the pre-head launch (k_wskpu) and find beta published.  In a deeper net they stay in
-  // k_wskpl AHEAD of the block that publishes beta and spin for it: correct while they all fit on the chip at once (the 5- and 6-layer
-  // nets of the test suite), a deadlock for a wide one (more update blocks than resident slots) — so deeper nets keep the k_pstep launch.
-  hp->lin_ok = hp->proj_ok && L == 4;
+  // L == 4: the update blocks ride in the pre-head launch (k_wskpu) and find beta published.  In a deeper net the launch after the
+  // first product reads what they write, so they stay in k_wskpl — dispatched BEHIND the small blocks, the first of which publishes
+  // beta (round 5: WskplArgs.upd_first; round 4 had them ahead of the publisher, a deadlock for a wide net, and kept the k_pstep
+  // launch for L > 4 instead).  The pollers' wait is bounded either way (poll_beta).
+  hp->lin_ok = hp->proj_ok && L >= 4 && (L == 4 || dbg(DBG_lin_deep, 1) != 0);
   if (hp->lin_ok) {
     for (int i = 0; i < 2; ++i) { hp->z1_off[i] = off; off += (size_t)Bp * m->dims[2]; }
     hp->rh0rp_off = off; off += (size_t)Bp * m->dims[1];
@@ -975,6 +977,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (upd_next) {   // only the small slices' blocks (the first publishes beta) ride here, ahead of the tiles
           la.ns = lin_nu - lin_ps.h.update_blocks;
           la.nt = na + rider_blocks;
+        } else if (!cm.first && L > 4 && lin_ps.h.nub == 0) {   // deeper nets: [small blocks][update blocks][tiles] — publisher first
+          la.ns = lin_nu - lin_ps.h.update_blocks;
+          la.nt = na + rider_blocks;
+          la.upd_first = 1;
         } else
         if (!cm.first && dbg(DBG_lin_order, 0) != 0) {
           la.ns = lin_nu - (lin_ps.h.nub > 0 ? lin_ps.h.nub : lin_ps.h.update_blocks);
@@ -988,6 +994,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         if (la.ps.h.nub > 0) hipLaunchKernelGGL((k_wskpl<2, 4, true>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la); else
 #endif
         hipLaunchKernelGGL((k_wskpl<2, 4, false>), dim3(grid), dim3(64 * kWskpWaves), 0, st, la);
+        ++g_lin_launches;
         if (cm.first)   // r|b0 as k_graw's tiles will read it (its bias blocks update the slice in the same launch)
           BHG_HIP_CHECK(hipMemcpyAsync(hbase + hp->rb0c_off, cm.fa + cm.starts[1], sizeof(float) * (size_t)m->dims[1],
                                        hipMemcpyDeviceToDevice, st));
@@ -1619,6 +1626,7 @@ int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out,
 int64_t bhg_mlp_wsk_launches(void) { return bhg::g_wsk_launches; }
 int64_t bhg_mlp_hoist_launches(void) { return bhg::g_hoist_launches; }
 int64_t bhg_mlp_proj_iterations(void) { return bhg::g_proj_iterations; }
+int64_t bhg_mlp_lin_launches(void) { return bhg::g_lin_launches; }
 
 int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, const int64_t* labels, float* coeff, float alpha,
                                 int K, int projected, void* fws, size_t fws_bytes, void* stream) {

@@ -350,6 +350,9 @@ int64_t bhg_mlp_hoist_launches(void);
  * G(raw_k) from B x B Gram matrices times batch-sized arrays (raw_k = the weight-shaped outputs of H p_k are outer products of
  * batch-sized factors), G(p_{k+1}) = G(r_{k+1}) + beta_k G(p_k) — no N-sized operand is read after the first iteration. */
 int64_t bhg_mlp_proj_iterations(void);
+/* Test / measurement hook: launches of k_wskpl — iterations of the fully projected CG solver in its SIX-launch form (the chain's first
+ * product by linearity on Rh_0(r'), beta published inside the launch; nets of >= 4 layers, padded batch 128).                      */
+int64_t bhg_mlp_lin_launches(void);
 /* bhg_mlp_neumann_solve (and bhg_neumann_init) accept p == NULL: the N-sized accumulator of neumann.py:64 is then never
  * written; the head kernel sums Rz(v_k), k < K, into `fws` instead, and this call turns that sum plus one R-forward pass
  * in direction v_K (`v_last`: the 2L slices of the direction buffer that holds v_K — v0 for even K, v1 for odd K) into the

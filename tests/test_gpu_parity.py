@@ -1096,6 +1096,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         # pre-head launch (k_wskpu) — the arms: update blocks inside k_wskpl; the k_pstep launch; k_graw storing G(raw) instead of
         # applying the residual step (on other nets the three arms run the default's launches)
         arms["full-updfirst"] = dict(arms["full"], BHG_LIN_UPDATE_NEXT="0")
+        arms["full-deep-kpstep"] = dict(arms["full"], BHG_LIN_DEEP="0")   # nets deeper than four layers with round 4's k_pstep launch
         arms["full-kpstep"] = dict(arms["full"], BHG_LIN_FIRST="0")
         arms["full-grawraw"] = dict(arms["full"], BHG_RNEW_IN_GRAW="0")
     out = {}
@@ -1110,9 +1111,14 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         # test_projection_is_gated_by_batch_size) must not pick the arm here — the eight-layer net is 32-96 wide
         bhg_debug.setenv("BHG_PROJ_MAX_RATIO", "100000000")
         keep = env.get("keep", "1") == "1"
-        h0, p0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations()
+        h0, p0, l0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations(), lib.bhg_mlp_lin_launches()
         out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
         dh, dp = lib.bhg_mlp_hoist_launches() - h0, lib.bhg_mlp_proj_iterations() - p0
+        if algo == "cg" and name == "full":
+            # round 5: every net of >= 4 layers with a batch of <= 128 takes the SIX-launch form (k_wskpl once per iteration) — the
+            # deeper ones with their update blocks behind the publisher inside that launch; 3-layer nets and larger batches do not
+            want_lin = K if (len(dims) - 1 >= 4 and B <= 128) else 0
+            assert lib.bhg_mlp_lin_launches() - l0 == want_lin, (dims, B, lib.bhg_mlp_lin_launches() - l0, want_lin)
         want = {"classic": (0, 0), "hoisted": (K, 0), "projected": (1, K - 1), "full": (1, K - 1 if algo == "cg" else K)}[name.split("-")[0]]
         assert (dh, dp) == want, (name, dh, dp, want)
         again = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
