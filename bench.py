@@ -627,7 +627,11 @@ def main():
                                "slices' outputs, step length)" if (args.algo == "cg" and solver_form and solver_form.startswith("fully")) else
                                "bhg_mlp_cg_solve: one whole fused CG-HVP iteration (R-chain + k_cg_alpha + k_outer_all, whose "
                                "epilogue carries the r/p update)" if args.algo == "cg" else
-                               "bhg_mlp_neumann_solve: one whole Neumann-HVP iteration (" + ("projected form" if (solver_form or "").startswith("projected") else "classic chain") + ")"),
+                               "bhg_mlp_neumann_solve: one whole Neumann-HVP iteration (" + (
+                                   "projected form, SIX dependent launches since round 5: the R-chain through the constant weights on packed "
+                                   "operands (k_wskpc x2 forward with the Gram rider, k_head_forward, k_wskpc x2 backward), then k_graw — G(raw) products, "
+                                   "the update G(v') = G(v) - alpha (G(raw) + shift G(v)) and Rh_0(v') in its epilogue, small slices' outputs; no update launch"
+                                   if (solver_form or "").startswith("projected") else "classic chain") + ")"),
                     "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "algorithmic_bytes_per_launch": alg,
@@ -757,6 +761,9 @@ def main():
                 "blas_of_the_opaque_hvp": ("PyTorch TunableOp (tuned during the warm-up)" if args.tunableop else "PyTorch default") if args.hvp == "autograd" else None,
                 "upper": ("meta-weight-net in closed form (bhg_mwn_forward / bhg_mwn_backward: one launch each way)" if args.upper == "closed-form"
                           else "meta-weight-net through PyTorch autograd") if args.hvp == "analytic" else "PyTorch autograd",
+                "once_per_step_passes": ("hidden layers behind the first as one launch each on the chain's packed operands (bhg_mlp_forward_packed / "
+                                         "_backward_packed); right-hand side read in place (bhg_cg_init_masked + bhg_mlp_cg_solve_rhs)")
+                if (fused and not args.debug) else None,
                 "cg_variant": "fused-solver" if fused else ("resident" if resident else "stream"),
                 "solver_form": solver_form,
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else

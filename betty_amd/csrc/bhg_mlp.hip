@@ -987,6 +987,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           la.nt = na + rider_blocks;
         }
         la.ps = lin_ps;
+        // (measurement arm lin_update_next = 0 on a four-layer net: the update blocks are dispatched AHEAD of the block that publishes
+        //  beta and poll for it — they must all fit on the chip beside it; the wait is bounded either way, this keeps the arm honest)
+        BHG_REQUIRE(cm.first || la.ns > 0 || lin_ps.h.update_blocks <= 2 * chip_cus(),
+                    "update blocks ahead of the publisher would not all be resident: use the default order");
         const int grid = (upd_next ? la.ns : la.nu) + na + rider_blocks;
         lin_update_pending = upd_next;
         BHG_REQUIRE(cm.first || lin_U == 4, "the update blocks inside k_wskpl are built for four float4 per thread");
