@@ -146,6 +146,7 @@ SYMBOLS = {
     ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_timeout_flag_dev": (c_void_p, [POINTER(Mlp), c_void_p]),
+    "bhg_mlp_stage_batch": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_void_p, c_void_p]),
     "bhg_mlp_supports_packed_prepare": (c_int, [POINTER(Mlp)]),
     "bhg_mlp_forward_packed": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_backward_packed": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -419,6 +419,7 @@ struct HoistPlan {
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
 };
+inline bool graw_batch_ok(int Bp) { return Bp == 128 || (Bp % 128 == 0 && dbg(DBG_graw_kloop, 1) != 0); }
 inline bool graw_split() {   // G(raw) products with two operand pairs: one workgroup per pair (A/B: BHG_PROJ_GRAW_SPLIT=0)
   return dbg(DBG_proj_graw_split, 1) != 0;
 }
@@ -538,14 +539,14 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
 // column tile of k_graw: 32, or 64 (debug key graw_cols = 64; every product's width must allow it).  Same-box A/B at cfg 2, twice:
 // 667.4 / 668.0 steps/s with 32 columns, 660.3 / 661.6 with 64 — the 64-column workgroup has its CU to itself and its phases
 // (operands 4.6 us, MFMAs 4.1 us, epilogue 2.9 us; stamps) no longer overlap with another workgroup's.
-int graw_cols(const HoistPlan* hp) {
-  if (dbg(DBG_graw_cols, 32) != 64) return 32;
+int graw_cols(const HoistPlan* hp, int Bp = 128) {
+  if (dbg(DBG_graw_cols, 32) != 64 || Bp != 128) return 32;
   for (int i = 0; i < hp->n; ++i)
     if (hp->N[i] % 64) return 32;
   return 64;
 }
 int graw_tile_count(const HoistPlan* hp, int Bp) {
-  const int ct = graw_cols(hp);
+  const int ct = graw_cols(hp, Bp);
   int t = 0;
   for (int i = 0; i < hp->n; ++i) t += (Bp / 64) * (hp->N[i] / ct);
   return t;
@@ -771,7 +772,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   bool sd_in_chain = false;   // first iteration: S_l, D_l rode in the first chain launch as well
   // k_graw (graw.inc) closes the iteration when the Gram matrices arrive packed; its loaders sum two K-split slabs at most.
   // graw_single: what the NEXT iteration's recurrences are told about the layout of G(raw) (one slab per product, not one per pair)
-  const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 && Bp == 128;   // (k_graw: K = 128)
+  // (k_graw: K = the padded batch = 128 in registers; round 5: larger padded batches through the K-looped instance k_grawk)
+  const bool graw_single = packed && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 && graw_batch_ok(Bp);
   const bool graw2 = gram_in_chain && graw_single;
   // rnew: k_graw applies r' = r - alpha Hp to G(r) itself (GrawArgs.rnew) — like graw_single, what the NEXT iteration's recurrences
   // are told (G(r) is up to date, there is no G(raw)); the conditions are those of the step length computed inside k_graw
@@ -1381,7 +1383,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
       if (graw2) {   // round 4: packed Gram matrices -> k_graw (64 x 32 tiles, inner products in the tile epilogue, one slab per product)
         GrawArgs ka{};
-        const int ct = graw_cols(hp);
+        const int ct = graw_cols(hp, Bp);
         // CT = 32: the small slices' blocks lead the grid; CT = 64: the tiles do (one CU each), the small blocks fill second slots
         const bool small_first = ct == 32;
         int gb = small_first ? (small_blocks + 15) & ~15 : 0;   // (every table entry a multiple of 16)
@@ -1405,7 +1407,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
           q.pb0 = real_tiles;
           real_tiles += (Bp / 64) * (hp->N[i] / ct);
-          ka.blk0[i] = gb; gb += (((Bp / 64) * (hp->N[i] / ct)) + 15) & ~15;
+          // every column tile with all its Bp / 64 row groups: groups of one tile 8 blocks apart (one XCD), column tiles padded to 8
+          ka.blk0[i] = gb; gb += (Bp / 64) * (((hp->N[i] / ct) + 7) & ~7);
         }
         ka.blk0[hp->n] = gb; ka.tile_end = gb;
         BHG_REQUIRE(real_tiles == graw_tile_count(hp, Bp) && real_tiles <= hp->graw_tiles, "tile count of k_graw and of the plan disagree");
@@ -1432,7 +1435,10 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           else hipLaunchKernelGGL(k_graw64<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
         } else
 #endif
-        if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        if (Bp != 128) {   // the K-looped instance (32-column tiles)
+          if (cg) hipLaunchKernelGGL(k_grawk<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+          else hipLaunchKernelGGL(k_grawk<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
+        } else if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
         else hipLaunchKernelGGL(k_graw<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
       }
       HoistArgs ga{};
@@ -1728,7 +1734,7 @@ static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p
   // the chain's first product by linearity (k_wskpl): fully projected CG closing with k_graw that applies the residual step (the
   // conditions of run_chain's graw_single and rnew), a net with a product between the first and the pre-head one, few small tensors
   c->lin = c->proj_level == 2 && c->hplan.lin_ok && packed_chain_on(c->w) && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 &&
-           m->Bp == 128 && dbg(DBG_proj_small_alone, 0) == 0 && dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0 &&
+           graw_batch_ok(m->Bp) && dbg(DBG_proj_small_alone, 0) == 0 && dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0 &&
            c->ba.nt <= 16 && proj_step_merged() && dbg(DBG_pstep_v2, 1) != 0 && dbg(DBG_lin_first, 1) != 0;
 }
 // gphase 0: the whole iteration (one rank) | 1: up to this rank's p.H_data p | 2: from the step length on (see ChainMode)
@@ -2120,6 +2126,28 @@ int bhg_mlp_backward_packed(const bhg_mlp* m, const int64_t* labels, void* fws, 
     wb.add(q);
     wb.launch(st);
   }
+  BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// The step's batch into the padded buffers the passes read: h_0[:B] = x (fp32 [B][d_0]), labels[:B] = y — ONE launch instead of two
+// device-to-device copies (8.5 + 1.7 us through the copy engine's blit path for 1.2 MB + 800 B at cfg 2; round 5).
+__global__ __launch_bounds__(256) void k_stage_batch(const float* __restrict__ x, const int64_t* __restrict__ y, float* __restrict__ h0,
+                                                     int64_t* __restrict__ labels, int64_t n4, int B) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<float4*>(h0)[i] = reinterpret_cast<const float4*>(x)[i];
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b < B; b += 256) labels[b] = y[b];
+}
+int bhg_mlp_stage_batch(const bhg_mlp* m, const float* x, const int64_t* y, int64_t* labels, void* stream) {
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(x && y && labels && m->h[0], "NULL argument");
+  BHG_REQUIRE((m->dims[0] & 3) == 0 && ((uintptr_t)x & 15) == 0, "the input batch must be 16-byte aligned with a width that is a multiple of 4");
+  const int64_t n4 = (int64_t)m->B * m->dims[0] / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_stage_batch, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, const_cast<float*>(m->h[0]), labels, n4, m->B);
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
 }

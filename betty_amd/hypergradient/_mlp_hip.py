@@ -122,8 +122,14 @@ class HipMLPState:
         if getattr(buf, "last_B", B) > B:  # a smaller batch than last time: clear the now-unused rows
             buf.h[0][B:].zero_()
         buf.last_B = B
-        buf.h[0][:B].copy_(x.detach().to(torch.float32).reshape(B, -1))
-        buf.labels[:B].copy_(y.reshape(-1))
+        xs, ys = x.detach().reshape(B, -1), y.detach().reshape(-1)
+        if (xs.dtype == torch.float32 and xs.is_contiguous() and xs.data_ptr() % 16 == 0 and dims[0] % 4 == 0 and ys.dtype == torch.int64
+                and ys.is_contiguous() and ys.device == xs.device):
+            _native.check(lib.bhg_mlp_stage_batch(ctypes.byref(d), xs.data_ptr(), ys.data_ptr(), buf.labels.data_ptr(), _stream()),
+                          "bhg_mlp_stage_batch")   # one launch for both
+        else:
+            buf.h[0][:B].copy_(xs.to(torch.float32))
+            buf.labels[:B].copy_(ys)
 
         # the once-per-step passes on the chain's packed operands when the network takes that form (include/bhg.h: the weights are
         # packed first, the hidden layers behind the first run as one launch each) — decided per call: an A/B key may switch it

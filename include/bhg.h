@@ -374,6 +374,9 @@ int bhg_mlp_neumann_mixed_coeff(const bhg_mlp* m, const void* const* v_last, con
  * the caller sets m->prepacked = 1 for the solves of this step (same weights, same batch, same fws).  Same results as the split-K
  * pair up to the summation order of the dot products.  bhg_mlp_supports_packed_prepare: 1 when the network takes this form (the
  * hoisted plan applies: >= 3 layers, hidden widths % 32 == 0, narrow head).                                                        */
+/* The step's batch into the padded buffers: m->h[0][:B] = x (fp32 [B][dims[0]], 16-byte aligned, dims[0] % 4 == 0), labels[:B] = y.
+ * One launch in place of two device-to-device copies.  Rows >= B of h[0] are the caller's to keep zero.                                */
+int bhg_mlp_stage_batch(const bhg_mlp* m, const float* x, const int64_t* y, int64_t* labels, void* stream);
 int bhg_mlp_supports_packed_prepare(const bhg_mlp* m);
 int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* fws, size_t fws_bytes,
                            void* stream);

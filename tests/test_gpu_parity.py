@@ -1051,6 +1051,7 @@ def test_withheld_beta_times_out_poisons_the_result_and_is_diagnosed(be, bhg_deb
     "dims,B,K",
     [([256, 384, 128, 10], 100, 5), ([512, 256, 256, 64, 10], 128, 4), ([256, 256, 256, 256, 128, 10], 100, 6), ([512, 1024, 64, 10], 200, 3),
      ([64, 96, 64, 32, 64, 96, 32, 64, 10], 50, 4),   # eight layers: the deepest net the hoisted / projected forms take
+     ([512, 256, 256, 64, 10], 200, 4), ([256, 256, 128, 64, 10], 256, 5), ([256, 192, 128, 64, 32, 10], 300, 3),   # round 5: batches > 128
      ([3072, 2048, 1536, 384, 10], 100, 20)],
     ids=lambda v: str(v),
 )
@@ -1099,6 +1100,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         arms["full-deep-kpstep"] = dict(arms["full"], BHG_LIN_DEEP="0")   # nets deeper than four layers with round 4's k_pstep launch
         arms["full-kpstep"] = dict(arms["full"], BHG_LIN_FIRST="0")
         arms["full-grawraw"] = dict(arms["full"], BHG_RNEW_IN_GRAW="0")
+    arms["full-no-kloop"] = dict(arms["full"], BHG_GRAW_KLOOP="0")      # batches beyond 128 with round 3's closing launches
     out = {}
     for name, env in arms.items():
         bhg_debug.reset()
@@ -1115,9 +1117,9 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         out[name] = _run_solver(algo, dims, B, ridge, K, sum(dims) + B, True, keep=keep)
         dh, dp = lib.bhg_mlp_hoist_launches() - h0, lib.bhg_mlp_proj_iterations() - p0
         if algo == "cg" and name == "full":
-            # round 5: every net of >= 4 layers with a batch of <= 128 takes the SIX-launch form (k_wskpl once per iteration) — the
-            # deeper ones with their update blocks behind the publisher inside that launch; 3-layer nets and larger batches do not
-            want_lin = K if (len(dims) - 1 >= 4 and B <= 128) else 0
+            # round 5: every net of >= 4 layers takes the SIX-launch form (k_wskpl once per iteration) — the deeper ones with their update
+            # blocks behind the publisher inside that launch, batches beyond 128 with the K-looped closing launch; 3-layer nets do not
+            want_lin = K if len(dims) - 1 >= 4 else 0   # (any batch: k_graw's K-looped instance takes padded batches beyond 128)
             assert lib.bhg_mlp_lin_launches() - l0 == want_lin, (dims, B, lib.bhg_mlp_lin_launches() - l0, want_lin)
         want = {"classic": (0, 0), "hoisted": (K, 0), "projected": (1, K - 1), "full": (1, K - 1 if algo == "cg" else K)}[name.split("-")[0]]
         assert (dh, dp) == want, (name, dh, dp, want)
