@@ -7,7 +7,7 @@
 set -u
 O=gpurun_out/r5f; mkdir -p $O gpurun_out/pmc; export TMPDIR=/tmp
 sha256sum betty_amd/csrc/libbhg.so betty_amd/csrc/libbhg_ab.so | tee $O/lib.sha
-timeout 1500 python -m pytest tests -m gpu -q -rP -rs --durations=8 > $O/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest_gpu_full.log | tail -2
+timeout 1500 python -m pytest tests -m gpu -q -rPs --durations=8 > $O/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest_gpu_full.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log
 line() { python - "$1" "$2" <<'PY'
 import json, sys
