@@ -233,3 +233,67 @@ def test_two_processes_share_one_gpu_over_gloo():
         assert rel <= 1e-4, (rank, rel)
         assert same
         assert (solves, n_scalar, n_resid) == (1, K, K - 1)
+
+
+# ---- round 5: the closed-form upper net under data parallelism (SigmoidMLPWeightNet.average_over) ---------------------------------
+def _average_over_worker(rank, world, port, q):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zoo
+        from betty_amd import Config
+
+        torch.cuda.set_device(0)
+        case = zoo.CASE_BY_NAME["reweight_cg20"]
+        inputs = zoo.seed_family_inputs(case.family, seed=rank)      # the ranks' own batches / directions, ...
+        shared = zoo.seed_family_inputs(case.family, seed=0)
+        for k in inputs:                                                # ... the same inner and upper weights (replicas)
+            if not k.startswith(("batch", "vec")):
+                inputs[k] = shared[k]
+        res = {}
+        for sync in (False, True):
+            curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+            zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=True, average_over=True)
+            for p in prev.trainable_parameters():
+                p.grad = torch.zeros_like(p)          # (accumulated into, not replaced: problem.py:592-597)
+            out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, sync)
+            res[sync] = torch.cat([p.grad.reshape(-1) for p in prev.trainable_parameters()]) if sync else \
+                torch.cat([t.reshape(-1) for t in out])
+        local = res[False].cpu()
+        every = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        mean = sum(every) / world
+        differ = float((every[0] - every[-1]).norm() / every[0].norm())
+        rel = float((res[True].cpu() - mean).norm() / mean.norm())
+        q.put((rank, rel, differ))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_closed_form_upper_net_averages_over_ranks():
+    """sync=True with the upper module declared in closed form and average_over=True: what lands in .grad is the MEAN over the ranks of
+    their local hypergradients (sync=False does no collective) — the reduction DistributedDataParallel's reducer performs for the
+    reference's backward (problem.py:220-224, cg.py:58-63) — between two processes on the one GPU over gloo."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_average_over_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, differ in sorted(q.get(timeout=5) for _ in range(world)):
+        assert differ > 1e-3, "the ranks must hold different local results for the test to mean anything"
+        assert rel <= 1e-5, (rank, rel)
