@@ -13,8 +13,16 @@ MWN 1-100-1 (M = 301), batch 100 x 3072, synthetic seeded data already resident 
 
 Multi-GPU (``--gpus N`` under torch.distributed.run): the path shards by replica exactly as the
 reference's DDP mode does — every rank solves on its local batch with no collective inside the CG
-loop; the M-sized hypergradient is all-reduced (mean) by the DDP reducer over RCCL when the
-``sync=True`` backward fires.  Weak scaling: value = N * steps / max-over-ranks time.
+loop; the M-sized hypergradient is averaged over the ranks when the ``sync=True`` hop completes: by
+ONE flat all-reduce of the M floats over RCCL issued by the hop itself (the upper module is declared in
+closed form, SigmoidMLPWeightNet(average_over=True): csrc/bhg_mwn.hip), or — ``--upper autograd`` — by
+the DDP reducer when the backward through the wrapped module fires, as in the reference.  Weak scaling:
+value = N * steps / max-over-ranks time.
+
+Timing: W warm-up steps, an untimed settle phase (--settle-ms), then --reps pairs of timed regions of
+--steps steps (full K, then K / 2, interleaved), each bracketed by barrier + synchronize; the line
+reports the MEDIAN full region (value, ms_per_step) and every region, and the per-iteration time as the
+median of (t(K) - t(K/2)) / (K/2) over the pairs.
 
 Prints ONE JSON line (rank 0).
 """
@@ -499,17 +507,29 @@ def main():
         step()
     # Settle (untimed, reported as `settle_steps`): W = 5 warm-up steps are 7 ms of GPU work — the first timed region of a 20-step run
     # then still sees the clocks ramp (round 5, two boxes: its first (full, half) pair read -74 and +75 us per iteration next to
-    # 60.0-60.7 for the other four).  Steps are run until --settle-ms of wall-clock have passed (default 300; 0 = off).
+    # 60.0-60.7 for the other four).  Steps are run for about --settle-ms of wall-clock (default 300; 0 = off).
+    # The COUNT is what every rank must agree on (a step of a multi-rank run contains a collective): eight probe steps are timed,
+    # the number of further steps follows from that time, and the ranks take the maximum of their counts.
     settle_steps = 0
     if args.settle_ms > 0:
+        probe = 8
         torch.cuda.synchronize()
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 1e-3 * args.settle_ms:
+        for _ in range(probe):
             step()
-            settle_steps += 1
-            if settle_steps % 8 == 0:
+        torch.cuda.synchronize()
+        per_step = max((time.perf_counter() - t_settle) / probe, 1e-6)
+        more = max(0, min(4096, int(1e-3 * args.settle_ms / per_step + 0.999) - probe))
+        if dist is not None:
+            t = torch.tensor([more], device=device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = int(t.item())
+        for i in range(more):
+            step()
+            if i % 8 == 7:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
+        settle_steps = probe + more
     # Region 1 — the headline: exactly `steps` steps, nothing but the product path on the stream, bracketed by barrier +
     # synchronize on both sides.  Repeated `--reps` times (default 5): `value` / `ms_per_step` are the MEDIAN region, every region
     # and the min-max spread are in the line (`regions`).  One region of 20 steps is 30 ms: a single sample of it moves by
