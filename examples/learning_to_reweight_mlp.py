@@ -20,7 +20,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from betty_amd import Config  # noqa: E402
 from betty_amd.engine import Engine, EngineConfig  # noqa: E402
-from betty_amd.hypergradient.structured import WeightedCEMLP  # noqa: E402
+from betty_amd.hypergradient.structured import SigmoidMLPWeightNet, WeightedCEMLP  # noqa: E402
 from betty_amd.problems import ImplicitProblem  # noqa: E402
 
 
@@ -63,8 +63,12 @@ class Classifier(ImplicitProblem):  # inner
         return torch.mean(w * ce) + RIDGE * sum((p * p).sum() for p in self.module.parameters())
 
     def hypergradient_structure(self, prev):
+        # the inner MLP and — optionally — the meta-weight-net are DECLARED: the K Hessian-vector products run on the matrix-core kernels,
+        # the sample weights and their VJP to the MWN's parameters in closed form (csrc/bhg_mwn.hip); both declarations are checked against
+        # autograd on first use.  (Under a data-parallel strategy add average_over=True: the mean DDP's reducer would have taken.)
         return WeightedCEMLP(self, prev, layers=list(self.module.layers),
-                             weight_fn=lambda ce: prev(ce.reshape(-1, 1)), ridge=RIDGE)
+                             weight_fn=lambda ce: prev(ce.reshape(-1, 1)), ridge=RIDGE,
+                             weight_net=SigmoidMLPWeightNet(prev.module.l1, prev.module.l2))
 
 
 def main():

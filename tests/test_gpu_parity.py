@@ -1828,3 +1828,19 @@ def test_projection_is_gated_by_batch_size(algo):
     rel, _ = rel_err(got, want)
     print(f"{algo} {dims} B={B}: projection gated off (hoist launches {dh}), vs un-fused {rel:.2e}")
     assert rel <= 5e-5, rel
+
+
+def test_example_learning_to_reweight_runs_with_both_structures_declared():
+    """examples/learning_to_reweight_mlp.py end to end on the GPU (own Engine shim, Adam on the meta-weight-net, SGD on the classifier):
+    the inner MLP and the meta-weight-net are both declared, so every hypergradient of the run goes through the fused solver AND the
+    closed-form upper kernels — with the first-use checks of both declarations against autograd on the way."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for algo in ("cg", "neumann"):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "learning_to_reweight_mlp.py"), "--algo", algo, "--k", "4",
+                            "--iters", "30", "--sizes", "256,128,64,10"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith(f"algo={algo}")]
+        assert line and "upper steps" in line[0], r.stdout[-500:]
+        print(line[0])
