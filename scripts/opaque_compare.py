@@ -5,8 +5,8 @@ backward; no declared structure): what this backend buys where only the recurren
   cfg 2, opaque   MLP 3072-2048-1536-384-10 (N = 10,034,826, 8 tensors), CG K = 20          bench.build
   cfg 3           ResNet-12 (10.43 M parameters, 122 tensors, 25 x 3 x 84 x 84), CG K = 20   tests/zoo.py
   cfg 4           RobertaForSequenceClassification (124.6 M parameters, 201 tensors, 16 x 50 tokens), darts
-  cfg 5           Network(16, 10, 8) as named: tests/test_gpu_parity.py::test_cfg5_reference_network_16_10_8_neumann20_batch64
-                  (BHG_RUN_SLOW=1; its line is in profiles/r04_cfg5_as_named.log)
+  cfg 5           Network(16, 10, 8) as named: scripts/cfg5_oracle_on_gpu.py (round 5: 37 s per step with forward-over-reverse HVP passes
+                  against 368 s for the reference's algorithm, profiles/r05_cfg5_product_vs_reference_algorithm_on_gpu.txt)
 
 "reference algorithm" = oracle/hypergrad_oracle.py (the line-for-line restatement of cg.py / darts.py, pinned bit-for-bit to the
 reference) on the same device tensors — i.e. what leopard-ai/betty itself launches on this GPU.  Prints steps/s of both."""
@@ -54,6 +54,14 @@ curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=20
 ours = rate(lambda: hg.cg(vector, curr, prev, False), 5)
 ref = rate(lambda: horc.cg(vector, curr, prev, False), 5)
 print(f"cfg 3 ResNet-12 CG-20 : betty_amd {ours:7.2f} steps/s | reference algorithm on this GPU {ref:7.2f} steps/s | x{ours / ref:.2f}")
+# the opt-in forward-over-reverse passes (round 5; pays for grouped convolutions, cfg 5 — measured here on a dense-convolution net)
+want = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).double()
+curr.hypergradient_hvp = "forward_over_reverse"
+ours_f = rate(lambda: hg.cg(vector, curr, prev, False), 5)
+got = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).double()
+print(f"cfg 3 ResNet-12 CG-20 : betty_amd with forward-over-reverse HVP passes {ours_f:7.2f} steps/s (x{ours_f / ref:.2f} over the reference's algorithm; "
+      f"vs the double-backward product {float((got - want).norm() / want.norm()):.2e})")
+curr.hypergradient_hvp = None
 del inner, upper, curr, prev, vector
 torch.cuda.empty_cache()
 
