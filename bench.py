@@ -641,8 +641,8 @@ def main():
             roof = {"bound": "hbm",
                     "kernel": ("bhg_mlp_cg_solve: one whole CG-HVP iteration — fully projected form, SIX dependent launches: the R-chain "
                                "through the constant weights on packed operands (k_wskpl: first product by linearity on Rh_0(r'), beta computed "
-                               "and published inside the launch; k_wskpu: pre-head product + the recurrences G(p') = G(r') + beta G(p); "
-                               "k_head_forward; k_wskpc x2; the B x B Gram products ride in them), then k_graw (G(raw) products with the inner "
+                               "and published inside the launch; k_wskpc: pre-head product; k_headu: the head with the recurrences G(p') = G(r') + "
+                               "beta G(p) as a second block class; k_wskpc x2; the B x B Gram products ride in them), then k_graw (G(raw) products with the inner "
                                "products, the residual step G(r') = G(r) - alpha (G(raw) + shift G(p)) and Rh_0(r') in their epilogue, small "
                                "slices' outputs, step length)" if (args.algo == "cg" and solver_form and solver_form.startswith("fully")) else
                                "bhg_mlp_cg_solve: one whole fused CG-HVP iteration (R-chain + k_cg_alpha + k_outer_all, whose "

@@ -311,6 +311,7 @@ int pick_splits(int tiles, int K, int pairs) {
 
 #include "mlp/pstep.inc"   // round 4: k_proj_step with its kernel arguments in two scalar-memory round trips (k_pstep)
 #include "mlp/wskpl.inc"   // round 4: the chain's first product by linearity, with the update launch riding in it (k_wskpl)
+#include "mlp/headu.inc"   // round 5: the head launch with the update blocks riding in it (k_headu)
 
 // One chain product (no riders) with `nu` update blocks leading its grid (k_wskpu).  Tiling as WskpBuilder::launch does it.
 void launch_wskpu(const WskpProb& q_in, const PstepArgs& ps, int nu, hipStream_t st) {
@@ -415,6 +416,7 @@ struct HoistPlan {
   // iteration parity, packed Rh_0(r'), the second slot of Gf_1(p) (slot 0 is g_off[gf[1]]), a copy of r|b0
   size_t z1_off[2], rh0rp_off, gp1alt_off, rb0c_off; bool lin_ok;
   size_t rh0alt_off;   // projected Neumann with the update inside k_graw: the second slot of the ROW-MAJOR Rh_0 (slot 0 is m->Rh[0])
+  size_t gp2alt_off;   // update blocks in the head launch (k_headu): the second slot of Gf_{L-2}(p) (slot 0 is g_off[gf[L-2]])
   bool proj_ok;                                                          // the projected solvers pay off and fit (cost model below)
   size_t floats;
   int gf[BHG_MLP_MAX_LAYERS], gb[BHG_MLP_MAX_LAYERS];   // index of the forward / backward product of layer l (-1: none)
@@ -527,6 +529,7 @@ void hoist_plan(const bhg_mlp* m, HoistPlan* hp) {
     hp->rb0c_off = off; off += (size_t)((m->dims[1] + 63) & ~63);
   }
   if (hp->proj_ok) { hp->rh0alt_off = off; off += (size_t)Bp * m->dims[1]; }
+  if (hp->lin_ok) { hp->gp2alt_off = off; off += (size_t)Bp * m->dims[L - 1]; }
   hp->graw_tiles = 0;
   for (int i = 0; i < n; ++i) hp->graw_tiles += (Bp / 64) * (hp->N[i] / 32);
   hp->blk0[n] = blk;
@@ -701,6 +704,7 @@ struct ChainMode {
   int lin;                      // fully projected CG: the chain's first product by linearity, update launch inside it (k_wskpl; cg_ctx_init decides)
   int nk;                       // projected Neumann: iteration index (the row-major Rh_0 lives in two slots by its parity, see vnew)
   const void* const* rhs;       // fully projected CG, first iteration: the right-hand side's own tensors (bhg_mlp_cg_solve_rhs) or NULL
+  int lin_head;                 // lin on a four-layer net: the update blocks ride in the HEAD launch (k_headu), the pre-head launch is the plain product
 };
 
 // One Hessian-vector product of the MLP in direction `dir`, its weight-shaped outputs stored (FUSE_NONE) or consumed
@@ -795,6 +799,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   int lin_nu = 0, lin_U = 4;
   bool lin_update_pending = false;   // the update blocks ride in the launch after the first product (k_wskpu)
   auto gp1 = [&](int par) { return cm.ws->hoist + (par ? hp->gp1alt_off : hp->g_off[hp->gf[1]]); };   // Gf_1(p): two slots (lin)
+  const bool lin_head = lin && cm.lin_head != 0;
+  auto gp2 = [&](int par) { return cm.ws->hoist + (par ? hp->gp2alt_off : hp->g_off[hp->gf[L - 2]]); };   // Gf_{L-2}(p): two slots (lin_head)
   // Gram products riding in chain launches: ONE K slab each — every rider sits in a launch whose tiles have the same K (T_1 with
   // the forward product through W_1; E_l and T_{l+1} with the backward product through W_l), so it ends when they do
   auto tsplit = [&](int K) { return gram_in_chain ? 1 : gram_ksplit(K); };
@@ -897,6 +903,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
             const ProjProb& q = pa.p[i];
             ps.p[i] = {q.Gr, q.Gp, q.Graw, q.bias, q.mask, q.out, q.outp, q.N, q.Graw ? 1 : 0};
             if (lin && i == hp->gf[1]) { ps.p[i].Gp = gp1(cm.kpar ^ 1); ps.p[i].X = gp1(cm.kpar); ps.p[i].xkind = 2; }
+            if (lin_head && i == hp->gf[L - 2]) { ps.p[i].Gp = gp2(cm.kpar ^ 1); ps.p[i].X = gp2(cm.kpar); ps.p[i].xkind = 2; }
             if (lin) ps.p[i].outp = nullptr;   // (nobody reads a packed Rh_0(p): the first product runs on Rh_0(r'))
           }
           if (lin) {
@@ -1019,7 +1026,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           if (sp > K / 64) sp = K / 64;
           if (sp < 1) sp = 1;
           q.nsplit = sp; q.raw = 1; q.out = m->partial;
-          head_fuse = {m->partial, sp, Bp * N, c, m->mask[l], m->Rh[l], Gf};
+          // (lin_head, past the first iteration: the head forms Gf(p') = Gf(r') + beta Gf(p) itself — k_headu, see there)
+          head_fuse = {m->partial, sp, Bp * N, c, m->mask[l], m->Rh[l], (lin_head && !cm.first) ? hbase + hp->gr_off[hp->gf[l]] : Gf};
           fuse_head = true;
         } else {
           q.bias = c; q.mask = m->mask[l]; q.addend = Gf; q.out = m->Rh[l]; q.outp = cm.ws->Rhp[l];
@@ -1031,7 +1039,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           t.nsplit = 1; t.raw = 1; t.out = hbase + hp->tslab_off[l]; t.outp = graw2 ? hbase + hp->tslabp_off[l] : nullptr;
           wb.add(t);
         }
-        if (lin_update_pending && wb.g.n == 1) {   // (l = 2: nothing this product reads is written by the update blocks)
+        if (lin_update_pending && wb.g.n == 1 && !lin_head) {   // (l = 2: nothing this product reads is written by the update blocks)
           launch_wskpu(wb.g.p[0], lin_ps, lin_ps.h.update_blocks, st);
           lin_update_pending = false;
         } else wb.launch(st);
@@ -1070,8 +1078,23 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         launch_gemm_wsk<LAYOUT_KC>(w, st, K >= staged_mink);
       }
     }
-    BHG_REQUIRE(!lin_update_pending, "the update blocks found no launch to ride in");
-    {
+    BHG_REQUIRE(!lin_update_pending || lin_head, "the update blocks found no launch to ride in");
+    if (lin_update_pending) {   // the head launch with the update blocks leading its grid (k_headu)
+      const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
+      BHG_REQUIRE(fuse_head && cg && packed && N <= 12 && K <= 512, "k_headu was planned for a head it cannot run");
+      HeaduArgs ha{};
+      ha.Rh = (const float*)m->Rh[l - 1]; ha.h = m->h[l]; ha.W = m->W[l]; ha.V = static_cast<const float*>(dir[2 * l]);
+      ha.cb = static_cast<const float*>(dir[2 * l + 1]); ha.prob = m->prob; ha.sd = m->sd; ha.rd = m->Rd[l];
+      ha.K = K; ha.C = N; ha.B = B; ha.mode = HEAD_JVP;
+      ha.delta_top = (const float*)m->delta[l]; ha.mask_prev = (const float*)m->mask[l - 1]; ha.rd_prev = m->Rd[l - 1];
+      ha.fz = head_fuse;
+      ha.partT1 = cm.ws->partT1; ha.partT2h = cm.ws->partT2h; ha.rz_out = cm.ws->rz; ha.rzx_acc = cm.rzx_acc; ha.rzx_first = cm.first;
+      ha.rows = Bp; ha.rd_prev_p = cm.ws->Rdp[l - 1];
+      ha.addend2 = gp2(cm.kpar ^ 1); ha.gran = cm.ws->gran;
+      ha.nu = lin_ps.h.update_blocks; ha.ps = lin_ps;
+      hipLaunchKernelGGL(k_headu<4>, dim3(ha.nu + Bp), dim3(256), (size_t)K * sizeof(float), st, ha);
+      lin_update_pending = false;
+    } else {
       const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
       launch_head_forward(st, Bp, (const float*)m->Rh[l - 1], m->h[l], m->W[l], static_cast<const float*>(dir[2 * l]),
                           static_cast<const float*>(dir[2 * l + 1]), m->prob, m->sd, m->Rd[l], K, N, B, HEAD_JVP, nullptr, nullptr,
@@ -1401,7 +1424,8 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           q.Gr = q.Gp = q.B1;   // (always loadable)
           if (vnew) q.Gr = q.Gp = hbase + hp->g_off[i];   // G(v): updated in place by the tile that owns the element
           if (full) {           // the inner products' partner: Rd_l (= B1) forward, Rh_{l-1} (= B2) backward
-            q.Gr = hbase + hp->gr_off[i]; q.Gp = (lin && i == hp->gf[1]) ? gp1(cm.kpar) : hbase + hp->g_off[i];
+            q.Gr = hbase + hp->gr_off[i];
+            q.Gp = (lin && i == hp->gf[1]) ? gp1(cm.kpar) : ((lin_head && i == hp->gf[L - 2]) ? gp2(cm.kpar) : hbase + hp->g_off[i]);
             q.dots = hp->bwd[i] ? 2 : 1;
           }
           q.Graw = hbase + hp->graw_off[i]; q.N = hp->N[i];
@@ -1690,7 +1714,7 @@ struct CgCtx {
   const bhg_mlp* m; float* x; float* r; float* p; const int64_t* starts; const bhg_chunk* chunks_dev; int n_chunks, K;
   float cg_alpha, shift;
   FusedWs w; double* scal; const double* partR0; int n_init, pgrid, bgrid;
-  bool lazy, hoist, lin; int proj_level;
+  bool lazy, hoist, lin, lin_head; int proj_level;
   const void* const* rhs;
   BetaArgs ba; HoistPlan hplan;
   const void* dir[2 * BHG_MLP_MAX_LAYERS];
@@ -1736,6 +1760,10 @@ static void cg_ctx_init(CgCtx* c, const bhg_mlp* m, float* x, float* r, float* p
   c->lin = c->proj_level == 2 && c->hplan.lin_ok && packed_chain_on(c->w) && dbg(DBG_packed_gram, 1) != 0 && dbg(DBG_graw_v2, 1) != 0 &&
            graw_batch_ok(m->Bp) && dbg(DBG_proj_small_alone, 0) == 0 && dbg(DBG_alpha_in_hoist, 1) != 0 && dbg(DBG_rnew_in_graw, 1) != 0 &&
            c->ba.nt <= 16 && proj_step_merged() && dbg(DBG_pstep_v2, 1) != 0 && dbg(DBG_lin_first, 1) != 0;
+  // ... and on a four-layer net the update blocks ride in the head launch (k_headu, headu.inc) rather than in the pre-head one: the head's
+  // prefetching instance must apply (<= 12 classes, last hidden width <= 512), and like lin it holds for the whole solve (slot parity)
+  c->lin_head = c->lin && m->L == 4 && dbg(DBG_lin_update_next, 1) != 0 && dbg(DBG_lin_update_in_head, 1) != 0 && dbg(DBG_lin_nub, 0) == 0 &&
+                m->dims[m->L] <= 12 && m->dims[m->L - 1] <= 512 && dbg(DBG_head_no_prefetch, 0) == 0;
 }
 // gphase 0: the whole iteration (one rank) | 1: up to this rank's p.H_data p | 2: from the step length on (see ChainMode)
 static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_world, hipStream_t st) {
@@ -1784,6 +1812,7 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
     c->dir[1] = k == 0 ? static_cast<const void*>(c->p + c->starts[1]) : static_cast<const void*>(w.pb0[k & 1]);
   if (c->lin) c->dir[3] = k == 0 ? static_cast<const void*>(c->p + c->starts[3]) : static_cast<const void*>(w.pb1[k & 1]);
   cm.lin = c->lin ? 1 : 0;
+  cm.lin_head = c->lin_head ? 1 : 0;
   cm.rhs = c->rhs;
   if (int rc = run_chain(m, c->dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));

@@ -1097,6 +1097,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         # pre-head launch (k_wskpu) — the arms: update blocks inside k_wskpl; the k_pstep launch; k_graw storing G(raw) instead of
         # applying the residual step (on other nets the three arms run the default's launches)
         arms["full-updfirst"] = dict(arms["full"], BHG_LIN_UPDATE_NEXT="0")
+        arms["full-upd-prehead"] = dict(arms["full"], BHG_LIN_UPDATE_IN_HEAD="0")   # round 4's place for the update blocks (k_wskpu)
         arms["full-deep-kpstep"] = dict(arms["full"], BHG_LIN_DEEP="0")   # nets deeper than four layers with round 4's k_pstep launch
         arms["full-kpstep"] = dict(arms["full"], BHG_LIN_FIRST="0")
         arms["full-grawraw"] = dict(arms["full"], BHG_RNEW_IN_GRAW="0")
