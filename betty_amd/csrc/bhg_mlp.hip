@@ -163,6 +163,7 @@ int chip_cus() {
 inline void wskp_tiling(WskpProb* q, bool ragged) {
   q->nfull = q->RA / 32;
   q->nstrip = 0;
+  q->pairs = dbg(DBG_xcd_pairs, 1);
   if (!ragged || q->raw || q->nsplit != 1 || q->RB % 64 != 0) return;
   int nf = q->B / 32, rem = q->B % 32;
   if (rem > 16) { ++nf; rem = 0; }
@@ -1079,7 +1080,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       }
     }
     BHG_REQUIRE(!lin_update_pending || lin_head, "the update blocks found no launch to ride in");
-    if (lin_update_pending) {   // the head launch with the update blocks leading its grid (k_headu)
+    if (lin_update_pending) {   // the head launch with the update blocks behind the head's rows (k_headu)
       const int l = L - 1, K = m->dims[l], N = m->dims[l + 1];
       BHG_REQUIRE(fuse_head && cg && packed && N <= 12 && K <= 512, "k_headu was planned for a head it cannot run");
       HeaduArgs ha{};
@@ -1091,7 +1092,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       ha.partT1 = cm.ws->partT1; ha.partT2h = cm.ws->partT2h; ha.rz_out = cm.ws->rz; ha.rzx_acc = cm.rzx_acc; ha.rzx_first = cm.first;
       ha.rows = Bp; ha.rd_prev_p = cm.ws->Rdp[l - 1];
       ha.addend2 = gp2(cm.kpar ^ 1); ha.gran = cm.ws->gran;
-      ha.nu = lin_ps.h.update_blocks; ha.ps = lin_ps;
+      ha.nu = lin_ps.h.update_blocks; ha.ps = lin_ps; ha.head_first = dbg(DBG_headu_head_first, 1);
       hipLaunchKernelGGL(k_headu<4>, dim3(ha.nu + Bp), dim3(256), (size_t)K * sizeof(float), st, ha);
       lin_update_pending = false;
     } else {

@@ -78,7 +78,7 @@ def demangle(n):
 # Kernels that may DECLARE a private segment: their frame is explained by SGPR spills that the compiler parked in VGPR lanes
 # (.sgpr_spill_count > 0, .vgpr_spill_count == 0) and their code contains no scratch / stack instruction.  Everything else with a
 # non-zero .private_segment_fixed_size fails the build (an allow-list per kernel, not a global relaxation).
-FRAME_ALLOWED = ("k_wskpl<", "k_wskpu<")
+FRAME_ALLOWED = ("k_wskpl<", "k_wskpu<", "k_headu<")
 
 
 def check(build_dir):

@@ -6,7 +6,7 @@
 # stamped with the sha256 of the libbhg.so that ran (bench.py replays `roofline.traffic` only on a matching stamp).
 set -u
 mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
-for ALGO in cg neumann; do
+for ALGO in ${ALGOS:-cg neumann}; do
   EXTRA=""; [ $ALGO = neumann ] && EXTRA="--algo neumann --cg-iters 10"
   for C in FETCH_SIZE WRITE_SIZE; do
     cd /tmp && rm -rf /tmp/pmc_${ALGO}_$C && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${ALGO}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --settle-ms 0 --reps 1 --cpu-steps 0 --no-kernel-timing --no-slope --no-parity $EXTRA > /tmp/pmc_${ALGO}_$C.log 2>&1; echo "$ALGO $C rc=$?"

@@ -46,6 +46,10 @@ run cg_split_k_prepare --debug packed_prepare=0
 run cg_rhs_copied --debug cg_rhs_direct=0
 run cg_upper_autograd --upper autograd
 run cg_kpstep_launch --debug lin_first=0
+run cg_upd_in_prehead --debug lin_update_in_head=0
+run cg_head_last --debug headu_head_first=0
+run cg_unpaired --debug xcd_pairs=0
+run cg_round5_start_loop --debug lin_update_in_head=0 --debug xcd_pairs=0
 run neumann_default --algo neumann --cg-iters 10
 run neumann_update_launch --algo neumann --cg-iters 10 --debug neumann_vnew=0
 run neumann_round4_form --algo neumann --cg-iters 10 --debug neumann_vnew=0 --debug packed_prepare=0 --upper autograd

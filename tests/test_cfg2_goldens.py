@@ -99,6 +99,8 @@ def _arms(algo):
                  ("fused-upd-in-first", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_UPDATE_NEXT": "0"})),
                  # round 5: the default has the update blocks in the HEAD launch (k_headu); the arm keeps them in the pre-head launch (k_wskpu)
                  ("fused-upd-in-prehead", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_UPDATE_IN_HEAD": "0"})),
+                 ("fused-head-last", dict(hvp="hip", fused=True, wsk=None, env={"BHG_HEADU_HEAD_FIRST": "0"})),
+                 ("fused-unpaired", dict(hvp="hip", fused=True, wsk=None, env={"BHG_XCD_PAIRS": "0"})),
                  ("fused-kpstep-launch", dict(hvp="hip", fused=True, wsk=None, env={"BHG_LIN_FIRST": "0"})),
                  ("fused-graw-stores-raw", dict(hvp="hip", fused=True, wsk=None, env={"BHG_RNEW_IN_GRAW": "0"})),
                  # WskpBuilder::launch builds depths 2 (the default) and 3 only — any other value runs depth 3 — and the
@@ -144,7 +146,7 @@ def _run_arm(algo, K, seed, ridge, arm, bhg_debug):
     else:
         bhg_debug.setenv("BHG_MLP_PROJ", arm["proj"])
     for key in ("BHG_PROJ_STEP_ALONE", "BHG_GRAM_KSPLIT", "BHG_GRAM_KCHUNK", "BHG_PACKED_CHAIN", "BHG_PACKED_GRAM", "BHG_PACKED_DEPTH", "BHG_GRAW_V2",
-                "BHG_ALPHA_IN_HOIST", "BHG_LIN_UPDATE_NEXT", "BHG_LIN_FIRST", "BHG_RNEW_IN_GRAW", "BHG_NEUMANN_VNEW", "BHG_LIN_UPDATE_IN_HEAD"):
+                "BHG_ALPHA_IN_HOIST", "BHG_LIN_UPDATE_NEXT", "BHG_LIN_FIRST", "BHG_RNEW_IN_GRAW", "BHG_NEUMANN_VNEW", "BHG_LIN_UPDATE_IN_HEAD", "BHG_HEADU_HEAD_FIRST", "BHG_XCD_PAIRS"):
         bhg_debug.delenv(key, raising=False)
     for key, val in arm.get("env", {}).items():
         bhg_debug.setenv(key, val)

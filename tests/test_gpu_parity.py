@@ -1098,9 +1098,11 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         # applying the residual step (on other nets the three arms run the default's launches)
         arms["full-updfirst"] = dict(arms["full"], BHG_LIN_UPDATE_NEXT="0")
         arms["full-upd-prehead"] = dict(arms["full"], BHG_LIN_UPDATE_IN_HEAD="0")   # round 4's place for the update blocks (k_wskpu)
+        arms["full-head-last"] = dict(arms["full"], BHG_HEADU_HEAD_FIRST="0")        # k_headu with the update blocks leading the grid
         arms["full-deep-kpstep"] = dict(arms["full"], BHG_LIN_DEEP="0")   # nets deeper than four layers with round 4's k_pstep launch
         arms["full-kpstep"] = dict(arms["full"], BHG_LIN_FIRST="0")
         arms["full-grawraw"] = dict(arms["full"], BHG_RNEW_IN_GRAW="0")
+    arms["full-unpaired"] = dict(arms["full"], BHG_XCD_PAIRS="0")       # column tiles of a strip's 64 columns on two XCDs (before round 5)
     arms["full-no-kloop"] = dict(arms["full"], BHG_GRAW_KLOOP="0")      # batches beyond 128 with round 3's closing launches
     out = {}
     for name, env in arms.items():
