@@ -4,6 +4,7 @@
   * closed forms at BASELINE.json's full size (N = 10,034,826) where the oracle would be slow.
 Tolerances are written next to each assertion.
 """
+import contextlib
 import ctypes
 import os
 import sys
@@ -1505,16 +1506,33 @@ def _resnet12_case(cfg):
     return curr, prev, vector
 
 
+@contextlib.contextmanager
+def _deterministic_convolutions():
+    """cfg 3 runs under MIOpen's deterministic solver filter.  With the default solvers the REFERENCE'S OWN algorithm has two outcomes
+    on this instance: about one run in sixteen — of the checker (pure PyTorch: no kernel of this package runs) as of the product, which
+    share autograd's convolution double backward — lands 4.4e-3 from the others, always the same second answer, while one
+    Hessian-vector product repeats to 1.4e-6 (tests/probe_cfg3_flake.py; profiles/r05_cfg3_two_outcomes_probe.log: checker 1 / 17,
+    resident 2 / 16, stream 0 / 16).  Under the filter checker, resident and stream kernels are bit-reproducible run to run
+    (profiles/r05_cfg3_two_outcomes_probe_deterministic_convs.log: 66 solves, no second outcome) at the same speed."""
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.deterministic = was
+
+
 @pytest.fixture(scope="module")
 def resnet12_checker():
     """The checker's answer for cfg 3 (oracle restatement on the device: opaque double backward + per-tensor ATen
-    recurrence), computed ONCE for both kernel variants, and its own run-to-run spread (MIOpen atomics)."""
+    recurrence), computed ONCE for both kernel variants, and its own run-to-run spread."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hypergrad_oracle as horc
 
-    curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
-    want = _np(horc.cg(vector, curr, prev, False))
-    again = _np(horc.cg(vector, curr, prev, False))
+    with _deterministic_convolutions():
+        curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=20, cg_alpha=1.0))
+        want = _np(horc.cg(vector, curr, prev, False))
+        again = _np(horc.cg(vector, curr, prev, False))
     noise, _ = rel_err(again, want)
     return want, noise
 
@@ -1528,7 +1546,8 @@ def test_cfg3_resnet12_cg20(variant, be, resnet12_checker):
     assert len(vector) == 122 and sum(v.numel() for v in vector) == 10_430_533
     be.cg_variant = VARIANTS[variant]
     try:
-        got = hg.jvp_fn_mapping["cg"](vector, curr, prev, False)
+        with _deterministic_convolutions():
+            got = hg.jvp_fn_mapping["cg"](vector, curr, prev, False)
     finally:
         be.cg_variant = _native.BHG_CG_AUTO
     rel, mx = rel_err(_np(got), want)
