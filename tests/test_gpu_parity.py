@@ -1053,6 +1053,7 @@ def test_withheld_beta_times_out_poisons_the_result_and_is_diagnosed(be, bhg_deb
     [([256, 384, 128, 10], 100, 5), ([512, 256, 256, 64, 10], 128, 4), ([256, 256, 256, 256, 128, 10], 100, 6), ([512, 1024, 64, 10], 200, 3),
      ([64, 96, 64, 32, 64, 96, 32, 64, 10], 50, 4),   # eight layers: the deepest net the hoisted / projected forms take
      ([512, 256, 256, 64, 10], 200, 4), ([256, 256, 128, 64, 10], 256, 5), ([256, 192, 128, 64, 32, 10], 300, 3),   # round 5: batches > 128
+     ([256, 256, 192, 640, 10], 100, 5), ([256, 256, 128, 64, 24], 100, 5),   # four layers, a head k_headu does not take (K > 512; C > 12)
      ([3072, 2048, 1536, 384, 10], 100, 20)],
     ids=lambda v: str(v),
 )
@@ -1070,7 +1071,7 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
     lib = _native.load()
     # ridge 0.5 at the full size: with 0.05 the Hessian of this random instance is indefinite and twenty CG iterations turn
     # ANY difference in summation order into an O(1) difference (measured: 1.97 between two correct arms)
-    ridge = 2.0 if dims[0] >= 3072 else 0.05
+    ridge = 2.0 if dims[0] >= 3072 else (0.5 if 640 in dims else 0.05)   # (the 640-wide instance: same remark, measured 3.9e-4 classic vs un-fused at 0.05)
     arms = {"classic": {"BHG_MLP_HOIST": "0"}, "hoisted": {"BHG_MLP_HOIST": "1" if algo == "cg" else "2", "BHG_MLP_PROJ": "0"}}
     if algo == "cg":
         # projected: G(r) by recurrence, r / p still N-sized (what a caller who wants x gets); full: NO N-sized state after the
@@ -1141,6 +1142,25 @@ def test_hoisted_and_projected_chain_match_classic_chain(algo, dims, B, K, bhg_d
         rel_v, _ = rel_err(out["full"][0], out["full-updatelaunch"][0])
         print(f"neumann {dims} K={K}: update inside k_graw vs update launch: {'bit-identical' if same else 'rel %.2e' % rel_v}")
         assert rel_v <= 1e-6, rel_v
+
+
+@pytest.mark.parametrize("dims", [[256, 256, 192, 640, 10], [256, 256, 128, 64, 24], [256, 256, 192, 640, 24]], ids=lambda v: str(v))
+def test_four_layer_nets_outside_the_head_launch_form(dims):
+    """PRODUCT build, no key set: four-layer nets whose head k_headu does not take — a last hidden layer wider than 512, more than
+    12 classes — keep their update blocks in the pre-head launch (k_wskpu; `lin_head` in cg_ctx_init).  Against the un-fused loop,
+    bit-reproducible."""
+    assert not _native.is_ab()
+    lib = _native.load()
+    B, K, ridge = 100, 5, 0.5   # (ridge 0.05 leaves the 640-wide random instance close to indefinite: CG turns summation order into 4e-4)
+    l0 = lib.bhg_mlp_lin_launches()
+    got, _ = _run_solver("cg", dims, B, ridge, K, sum(dims) + B, True, keep=False)
+    lin = lib.bhg_mlp_lin_launches() - l0
+    again, _ = _run_solver("cg", dims, B, ridge, K, sum(dims) + B, True, keep=False)
+    unf, _ = _run_solver("cg", dims, B, ridge, K, sum(dims) + B, False)
+    rel, _ = rel_err(got, unf)
+    print(f"cg {dims} K={K}: k_wskpl launches {lin}, fused vs un-fused {rel:.2e}")
+    assert all(np.array_equal(u, v) for u, v in zip(again, got)), "bit-reproducible"
+    assert rel <= 5e-5, (dims, rel)
 
 
 @pytest.mark.parametrize("algo", ["cg", "neumann"])
