@@ -104,7 +104,10 @@ def declare_structure(curr, impl, fused=True, keep_solution=False, native_upper=
     def wnet(prev):
         if not native_upper:
             return None
-        return SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=True if prev.fwd is not prev.module else None)
+        # overlap=True: the M-float all-reduce of step i is asynchronous and the compute stream is fenced behind it only at step
+        # i + 1's hop (or the upper optimizer's step): it runs under the next solve's CG iterations (betty_amd/distributed.py)
+        ddp = prev.fwd is not prev.module
+        return SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=True if ddp else None, overlap=ddp)
 
     curr.hypergradient_structure = lambda prev: WeightedCEMLP(
         curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)), ridge=curr.ridge, impl=impl,
@@ -299,7 +302,8 @@ def parity_check(args, device, jvp_fn, curr, prev, vector, K):
     tests/golden/make_cfg2_golden.py from /root/reference).
       metric instance (ridge 1e-2, seed 0 — what was timed): the reference's own fp32 answer sits `reference_own_spread` from its
         fp64 answer (20 un-preconditioned CG iterations on an indefinite-plus-small-ridge Hessian), so rtol 1e-4 is undecidable
-        there; the product is held to 3x that spread against the fp64 truth (the rule of tests/test_cfg2_goldens.py);
+        there against the fp32 output: the product is held to rtol 1e-4 against the reference's fp64 output (the truth), and to 3x
+        the reference's own spread against its fp32 output;
       well-conditioned variant (ridge 0.3, same shapes, same kernels, same K): rtol 1e-4 against the reference's fp32 output,
         ASSERTED — bench.py refuses to print a throughput when it fails."""
     import numpy as np
@@ -326,7 +330,12 @@ def parity_check(args, device, jvp_fn, curr, prev, vector, K):
         },
     }
     mi = res["metric_instance"]
-    mi["ok"] = bool(mi["vs_reference_fp64"] <= max(1e-4, 3.0 * spread))
+    # Two gates of different width: the distance to the fp64 TRUTH is held to north_star's rtol 1e-4 (the product
+    # delivers ~1e-6 on this seed); only the distance to the reference's fp32 CPU output — which itself sits `spread` from that
+    # truth — keeps the bound of 3x the reference's own spread.
+    mi["rtol_vs_fp64"] = 1e-4
+    mi["bound_vs_reference_cpu_fp32"] = max(1e-4, 3.0 * spread)
+    mi["ok"] = bool(mi["vs_reference_fp64"] <= mi["rtol_vs_fp64"] and mi["vs_reference_cpu_fp32"] <= mi["bound_vs_reference_cpu_fp32"])
     wseed = int(gold["well/seeds"][0])
     curr_w, prev_w, vector_w = build(device, seed=wseed, K=K, algo=args.algo, ridge=RIDGE_WELL)
     if args.hvp == "analytic":
@@ -343,6 +352,138 @@ def parity_check(args, device, jvp_fn, curr, prev, vector, K):
         raise SystemExit("bench.py: the timed solver does not reproduce the reference's CPU output — refusing to report a "
                          "throughput for a wrong result: " + json.dumps(res))
     return res
+
+
+def secondary_lines(args, device, be, N):
+    """Driver-visible evidence beside the headline, ~2 s, AFTER every timed region of the headline:
+      neumann10     — BASELINE cfg 2's OWN algorithm (betty/hypergradient/neumann.py:59-66, K = 10) on the same workload: steps/s,
+                      the event-free per-iteration time from interleaved (K, K/2) regions, SURVEY 8(d)'s 20*N-byte yardstick against
+                      8 TB/s, and the in-run parity against the reference-CPU goldens (tests/golden/cfg2_full.npz: neumann10);
+      cg_resident   — the opaque path's streaming recurrence kernel k_cg_resident (one launch per CG iteration after PyTorch's double
+                      backward; what an un-annotated Betty problem runs): HIP-event time per launch on the launch stream and the
+                      28*N bytes it really moves against 8 TB/s."""
+    import argparse
+    import ctypes
+
+    from betty_amd import _native
+
+    out = {}
+    steps = max(5, min(args.steps, 100))
+
+    def region(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+    # ---- Neumann K = 10 --------------------------------------------------------------------------------------------------
+    K = 10
+    curr, prev, vector = build(device, seed=0, K=K, algo="neumann")
+    declare_structure(curr, "hip", native_upper=args.upper == "closed-form")
+    fn = hg.jvp_fn_mapping["neumann"]
+
+    def step():
+        for p in prev.parameters():
+            p.grad = None
+        assert fn(vector, curr, prev, True) is None
+
+    p0 = int(be.lib.bhg_mlp_proj_iterations())
+    region(step, 8)
+    t_full, t_half = [], []
+    for _ in range(3):
+        t_full.append(region(step, steps))
+        curr.config.neumann_iterations = K // 2
+        step()
+        t_half.append(region(step, steps))
+        curr.config.neumann_iterations = K
+        step()
+    projected = int(be.lib.bhg_mlp_proj_iterations()) > p0
+    pair_us = [1e6 * (a - b) / (steps * (K - K // 2)) for a, b in zip(t_full, t_half)]
+    it_us = med(pair_us)
+    nargs = argparse.Namespace(**{**vars(args), "algo": "neumann"})
+    par = parity_check(nargs, device, fn, curr, prev, vector, K)
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
+    out["neumann10"] = {
+        "metric": "hypergradient-steps/sec (neumann K=10, 10M inner params) — BASELINE cfg 2's own algorithm on the metric workload",
+        "value": steps / med(t_full), "unit": "hypergradient-steps/sec", "ms_per_step": 1e3 * med(t_full) / steps,
+        "steps_each": steps, "pairs": 3, "per_iteration_us": it_us, "per_iteration_us_pairs": pair_us,
+        "solver_form": "projected Neumann (six launches per iteration)" if projected else "classic chain",
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": 20.0 * N, "achieved": 20.0 * N / (it_us * 1e-6) / 1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 20.0 * N / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                     "note": "SURVEY 8(d)'s yardstick: the 20*N bytes the reference's Neumann recurrence moves per iteration over this "
+                             "solver's event-free iteration time"},
+        "finite": finite, "parity": par,
+    }
+    del curr, prev, vector
+    # ---- the opaque path's recurrence kernel -----------------------------------------------------------------------------
+    K = 20
+    curr, prev, vector = build(device, seed=0, K=K, algo="cg")
+    curr.hypergradient_graph = False
+    fn = hg.jvp_fn_mapping["cg"]
+    layout = be.layout(vector)
+    resident = bool(be.lib.bhg_cg_resident_usable(int(layout.n_chunks)))
+    for _ in range(2):
+        fn(vector, curr, prev, False)
+    torch.cuda.synchronize()
+    be.lib.bhg_timing_enable(1)
+    n_op = 4
+    t_op = region(lambda: fn(vector, curr, prev, False), n_op)
+    tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+    _native.check(be.lib.bhg_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt)), "bhg_timing_read")
+    be.lib.bhg_timing_enable(0)
+    if cnt.value:
+        us = 1e3 * tot.value / cnt.value
+        out["cg_resident"] = {
+            "kernel": ("k_cg_resident (1 launch per CG iteration)" if resident else "k_cg_dot + k_cg_resid + k_cg_dir (3 launches per CG iteration)") +
+                      " behind PyTorch's double backward: the path of an inner problem WITHOUT a declared structure",
+            "avg_launch_us": us, "launches_timed": cnt.value, "timer": "HIP events recorded inside libbhg on the launch stream (bhg_timing)",
+            "algorithmic_bytes_per_launch": 28.0 * N, "achieved": 28.0 * N / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": 28.0 * N / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": pmc_traffic("k_cg_resident" if resident else "cg_stream", N)[0],
+            "opaque_steps_per_sec": n_op / t_op,
+            "note": "this kernel really moves its 28*N bytes (read Hp, p, r, x; write x, r, p); the state fits the 256 MiB Infinity Cache, "
+                    "cache-defeated figure: profiles/r02_bench_kernels_N10M_cache_defeated.json",
+        }
+    return out
+
+
+def device_census(dist, world, rank, device, M):
+    """Makes an N > 1 line falsifiable: how many ranks the process group REALLY spans (an all-reduce of ones), which
+    physical device each rank holds (name, PCI bus id, uuid when the runtime exposes them: N distinct entries or the run is not N GPUs), and
+    the measured latency of the one collective a replica-mode step contains — the all-reduce of the M-sized hypergradient."""
+    props = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "device_index": device.index, "name": props.name,
+            "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xFF, getattr(props, "pci_device_id", -1) & 0xFF)
+            if hasattr(props, "pci_bus_id") else None,
+            "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid()}
+    if dist is None or world == 1:
+        return {"ranks_seen": 1, "devices": [mine], "distinct_devices": 1, "backend": None, "allreduce_M_floats_us": None}
+    ones = torch.ones(1, device=device, dtype=torch.float32)
+    dist.all_reduce(ones)
+    devices = [None] * world
+    dist.all_gather_object(devices, mine)
+    buf = torch.zeros(M, device=device, dtype=torch.float32)
+    for _ in range(5):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    n = 50
+    for _ in range(n):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    lat = torch.tensor([1e6 * (time.perf_counter() - t0) / n], device=device, dtype=torch.float64)
+    dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+    ids = {(d.get("pci"), d.get("uuid"), d.get("device_index")) for d in devices}
+    return {"ranks_seen": int(round(float(ones.item()))), "devices": devices, "distinct_devices": len(ids), "backend": dist.get_backend(),
+            "allreduce_M_floats_us": float(lat.item()),
+            "allreduce_note": "%d back-to-back all-reduces of the M = %d float hypergradient, max over ranks: the only collective of a replica-mode step" % (n, M)}
 
 
 def self_launch(args):
@@ -398,6 +539,8 @@ def main():
                          "sustained state before the first timed region (0 = off)")
     ap.add_argument("--reps", type=int, default=5,
                     help="timed regions of `--steps` steps each (full and, interleaved, K/2): the line reports the MEDIAN region and the spread")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (Neumann K = 10 and the opaque path's k_cg_resident, ~2 s after the timed regions)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the in-run check of the timed solver against the committed reference-CPU goldens (A/B sweeps)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) | gloo (debug only)")
@@ -612,6 +755,11 @@ def main():
     if not finite:
         raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
     parity = parity_check(args, device, jvp_fn, curr, prev, vector, K) if (world == 1 and not args.no_parity) else None
+    census = device_census(dist, world, rank, device, M)
+    secondary = None
+    if (world == 1 and args.algo == "cg" and K == 20 and fused and not args.no_secondary and not args.no_parity and not args.debug
+            and not args.keep_solution):
+        secondary = secondary_lines(args, device, be, N)
     out = None
     one_pass_solves = 0
     if args.mode == "global":
@@ -800,6 +948,9 @@ def main():
                 "lib_sha256": lib_sha256()[:16],
             },
             "parity": parity,
+            "secondary": secondary,
+            "ranks_seen": census["ranks_seen"],
+            "devices": census,
             "roofline": roof,
             "hvp_roofline": hvp_roof,
             "value_with_kernel_timing": ((world if args.mode == "replica" else 1) * args.steps / elapsed_timed) if elapsed_timed else None,

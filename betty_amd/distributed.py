@@ -64,3 +64,72 @@ def exchange_async(grads: Sequence[torch.Tensor], group: Optional[dist.ProcessGr
     if world > 1:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return ExchangeHandle(layout, flat, grads, work, world, be if hasattr(be, "collectives_in_flight") else None)
+
+
+# ---- deferred data-parallel mean of an upper hypergradient that was accumulated into ``.grad`` (round 6) ---------------------------
+# north_star: "DDP hypergradient all-reduce ... overlapped with the next CG matvec".  The closed-form upper hop
+# (hypergradient/structured.py:mixed_vjp with SigmoidMLPWeightNet(average_over=..., overlap=True)) issues its M-sized flat all-reduce
+# with async_op=True — RCCL runs it on its own stream — and registers the work here instead of making the compute stream wait at once:
+# the next step's inner forward / backward / CG iterations run under the collective.  The compute stream is fenced behind it at the
+# first point where the reduced values can be READ or ACCUMULATED INTO:
+#   * the next closed-form hop into the same parameters (before it touches ``.grad``),
+#   * ``optimizer.step()`` of the upper problem (a step pre-hook, installed on ``prev.optimizer`` when the problem has one),
+#   * ``betty_amd.distributed.fence_grads()`` — callers that read ``.grad`` themselves (a custom loop, a test).
+# Nothing else may read those ``.grad`` tensors in between; that is the contract of ``overlap=True`` (off by default).
+_PENDING: list = []
+
+
+class _PendingGradSync:
+    def __init__(self, work, flat, backend):
+        self.work, self.flat = work, flat   # `flat` is kept alive until the fence (.grad may have been reset to None meanwhile)
+        self.handle = ExchangeHandle(None, flat, None, work, 2, backend)   # shares the in-flight accounting of exchange_async
+
+    def fence(self):
+        if self.work is not None:
+            self.work.wait()                # the CURRENT stream waits for the collective; the host does not (RCCL)
+            self.work = None
+            h = self.handle
+            h._work = None
+            if h._counted is not None:
+                h._counted()
+        self.flat = None
+
+
+def defer_grad_sync(work, flat, backend=None) -> None:
+    """``backend``: the vector backend whose resident CG kernel must stay off while the collective is in flight (None: no accounting)."""
+    _PENDING.append(_PendingGradSync(work, flat, backend if hasattr(backend, "collectives_in_flight") else None))
+
+
+def pending_grad_syncs() -> int:
+    return len(_PENDING)
+
+
+def fence_grads() -> int:
+    """Order the current stream behind every deferred hypergradient all-reduce; returns how many were outstanding.  Cheap when none is."""
+    n = len(_PENDING)
+    while _PENDING:
+        _PENDING.pop(0).fence()
+    return n
+
+
+def install_optimizer_fence(optimizer) -> bool:
+    """``optimizer.step()`` reads ``.grad``: fence first.  Idempotent per optimizer; False when the optimizer has no pre-hook API."""
+    if optimizer is None or getattr(optimizer, "_bhg_grad_fence", False):
+        return optimizer is not None
+    reg = getattr(optimizer, "register_step_pre_hook", None)
+    if reg is None:
+        return False
+    reg(lambda *a, **k: (fence_grads(), None)[1])
+    optimizer._bhg_grad_fence = True
+    return True
+
+
+def ddp_process_group_of(*modules):
+    """(found, group): the process group of a DistributedDataParallel wrapper among ``modules`` — the group whose mean the reference's
+    sync=True hop would have taken through the wrapper's reducer (betty/problems/problem.py:220-224)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP  # noqa: PLC0415
+
+    for m in modules:
+        if isinstance(m, DDP):
+            return True, m.process_group
+    return False, None

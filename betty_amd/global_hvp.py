@@ -136,6 +136,7 @@ def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: f
             provider.cg_global_phase(full, x, r, p, k, K, _native.BHG_CG_GLOBAL_DOTS, G, st.php, alpha)
     solve = provider.cg_global_finish(full, K, alpha)
     neg_x = full.views(x, vector)
+    provider.expects_data_parallel_mean = G > 1   # a closed-form upper hop refuses to accumulate a rank-local share
     if solve is not True:
         out = provider.mixed_vjp(neg_x, sync, solve=solve)
     else:
@@ -205,6 +206,8 @@ def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = Non
 
     all_gather_flat(st.x, st.x_full, group)
     neg_x = full.views(st.x_full, vector)
+    if provider is not None:
+        provider.expects_data_parallel_mean = G > 1
     out = provider.mixed_vjp(neg_x, sync) if provider is not None else mixed_vjp(in_grad, prev, neg_x, sync)
     if sync:
         return None          # accumulated through backward(): the DDP reducer of prev's module averaged it

@@ -72,6 +72,41 @@ class ForwardOverReverseHVP:
         self._dev = dev
         self.passes = 0
         self.fallback = self.in_grad = None
+        # the first pass updates module buffers in place (batch-norm statistics): kept so that a FAILED first pass can be undone before
+        # the double backward runs training_step again — buffers advance once per solve either way
+        self._buffers0 = {n: b.detach().clone() for n, b in self.module.named_buffers()}
+        self._warn_train_mode_batchnorm()
+
+    def _warn_train_mode_batchnorm(self):
+        """on the dense-convolution ResNet-12 of BASELINE cfg 3 (train-mode batch norm) this method measured 0.57x the double
+        backward's speed and a solve 4.4e-3 away from it (profiles/r05_opaque_product_vs_reference_on_gpu.txt) — it pays only where the
+        double backward is host-bound (grouped convolutions: cfg 5, x 9.9, 8.7e-5).  Said loudly, once per problem, where the module
+        normalises with batch statistics; `problem.hypergradient_hvp_ack_batchnorm = True` acknowledges it."""
+        bn = [n for n, m in self.module.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training]
+        if not bn or getattr(self.curr, "hypergradient_hvp_ack_batchnorm", False) or getattr(self.curr, "_bhg_for_bn_warned", False):
+            return
+        grouped = any(isinstance(m, torch.nn.modules.conv._ConvNd) and m.groups > 1 for m in self.module.modules())
+        warnings.warn(
+            f"betty_amd: hypergradient_hvp = 'forward_over_reverse' on a module with {len(bn)} train-mode batch-norm layer(s) "
+            f"(first: {bn[0]!r}){'' if grouped else ' and NO grouped convolution'}: forward-mode tangents through batch statistics measured "
+            "4.4e-3 from the double backward's solve on a dense-convolution ResNet-12 at 0.57x its speed; the method pays where the "
+            "double backward is host-bound (grouped / depthwise convolutions).  Compare both on your problem; set "
+            "problem.hypergradient_hvp_ack_batchnorm = True to silence this.", RuntimeWarning, stacklevel=3)
+        try:
+            self.curr._bhg_for_bn_warned = True
+        except AttributeError:
+            pass
+
+    @staticmethod
+    def _is_missing_forward_formula(exc) -> bool:
+        """Only a missing forward-mode derivative may trigger the fall-back — not an out-of-memory error or a shape bug in the user's
+        training_step, which must surface as they are."""
+        if isinstance(exc, NotImplementedError):
+            return True
+        if isinstance(exc, torch.cuda.OutOfMemoryError):
+            return False
+        msg = str(exc).lower()
+        return any(k in msg for k in ("forward ad", "forward-mode", "forward mode", "jvp", "dual level", "dual tensor", "fwad"))
 
     def _pass(self, tangents, wrt_upper: bool):
         fwAD = self.fwAD
@@ -104,8 +139,14 @@ class ForwardOverReverseHVP:
         try:
             return self._pass(direction_views, wrt_upper=False)
         except (NotImplementedError, RuntimeError) as exc:
-            if self.passes > 1:
+            if self.passes > 1 or not self._is_missing_forward_formula(exc):
                 raise
+            # undo what the failed pass did to the module's buffers: inner_gradient() below runs training_step once more, and the
+            # statistics must have advanced exactly once when the solve returns
+            with torch.no_grad():
+                for n, b in self.module.named_buffers():
+                    if n in self._buffers0 and b.shape == self._buffers0[n].shape:
+                        b.copy_(self._buffers0[n])
             # an operator of this training_step has no forward-mode formula: the reference's double backward takes over for the solve
             warnings.warn(f"betty_amd: forward-over-reverse HVP not available for this training_step ({type(exc).__name__}: {exc}); "
                           "using the double backward", RuntimeWarning)

@@ -123,8 +123,12 @@ class HipMLPState:
             buf.h[0][B:].zero_()
         buf.last_B = B
         xs, ys = x.detach().reshape(B, -1), y.detach().reshape(-1)
-        if (xs.dtype == torch.float32 and xs.is_contiguous() and xs.data_ptr() % 16 == 0 and dims[0] % 4 == 0 and ys.dtype == torch.int64
-                and ys.is_contiguous() and ys.device == xs.device):
+        # raw pointers go into a kernel launched on the CURRENT device: the batch must live on the buffers' device and that device must
+        # be the current one — anything else takes copy_(), which handles cross-device batches
+        same_dev = (xs.device == buf.h[0].device and ys.device == xs.device and xs.is_cuda
+                    and torch.cuda.current_device() == (xs.device.index if xs.device.index is not None else torch.cuda.current_device()))
+        if (same_dev and xs.dtype == torch.float32 and xs.is_contiguous() and xs.data_ptr() % 16 == 0 and dims[0] % 4 == 0
+                and ys.dtype == torch.int64 and ys.is_contiguous()):
             _native.check(lib.bhg_mlp_stage_batch(ctypes.byref(d), xs.data_ptr(), ys.data_ptr(), buf.labels.data_ptr(), _stream()),
                           "bhg_mlp_stage_batch")   # one launch for both
         else:

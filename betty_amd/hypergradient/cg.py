@@ -10,6 +10,8 @@ streaming kernels (40*N bytes) instead of ~10*T ATen launches moving ~140*N byte
 """
 from __future__ import annotations
 
+import torch
+
 from ..backend import get_backend
 from ._common import (AutogradHVP, ForwardOverReverseHVP, GraphedHVP, forward_over_reverse_wanted, hvp_graph_wanted, inner_gradient,
                       mixed_vjp, persistent_graphs_for, solve_stream)
@@ -63,6 +65,10 @@ def _cg(vector, curr, prev, sync, provider, K, graphed, persist=None):
     # it says which tensors' slices of r / p it needs at all (fused_cg_state_mask) and reads the others from `vector` itself
     state_mask = getattr(provider, "fused_cg_state_mask", None)
     keep_mask = state_mask(layout, K) if (skip_x and state_mask is not None) else None
+    # the solver reads the un-masked tensors' values straight from `vector` with 16-byte loads: a right-hand side that is a slice of
+    # some flat buffer at an odd offset (or another dtype / layout) takes the copying initialisation instead
+    if keep_mask is not None and not all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in vector):
+        keep_mask = None
     # x = 0, r = p = vector, rr = r.r   (cg.py:34-36)
     rhs = be.cg_init(layout, vector, None if skip_x else x, r, p, keep_mask=keep_mask) if keep_mask is not None else \
         be.cg_init(layout, vector, None if skip_x else x, r, p)

@@ -26,6 +26,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence
 
+import warnings
+
 import torch
 import torch.nn.functional as F
 
@@ -49,6 +51,7 @@ VERIFY_RTOL = 1e-3
 # The check still separates a wrong declaration (label smoothing, dropout, another reduction: 1e-1 .. 1e+2) from a right one there.
 VERIFY_KINK_MARGIN = 1e-6
 VERIFY_RTOL_ON_A_KINK = 3e-2
+VERIFY_KINK_RETRIES = 3   # relaxed passes (one per prepare) before a kink-ridden problem's verdict is cached after all
 
 
 def structured_hvp_for(curr, prev):
@@ -75,15 +78,21 @@ class SigmoidMLPWeightNet:
     of the upper module all-reduces (mean) the hypergradient (betty/problems/problem.py:220-224, cg.py:58-63).  The closed form
     does not pass through that wrapper, so a data-parallel caller says so here: ``True`` (the default process group) or a process
     group -> the M-sized flat result is all-reduced (RCCL) and averaged before it is accumulated into ``.grad``; ``None`` (the
-    default) -> no collective, as for an un-wrapped module in the reference.
+    default) -> what the reference would have done: when the upper problem's forward module (``prev.fwd`` / ``prev.module``) IS a
+    DistributedDataParallel wrapper, the mean over that wrapper's process group (its reducer's job in the reference; ADVICE r5:
+    never a silently rank-local gradient under DDP), otherwise no collective, as for an un-wrapped module in the reference.
+
+    ``overlap=True`` (with a mean to take): the all-reduce is issued asynchronously and the compute stream is NOT made to wait for it
+    at once — the next step's solve runs under it; see betty_amd/distributed.py (``fence_grads``) for where the fence falls and the
+    contract (nobody reads these ``.grad`` tensors before the upper optimizer's step, the next hop, or an explicit fence).
     """
 
-    def __init__(self, hidden: torch.nn.Linear, out: torch.nn.Linear, average_over=None):
+    def __init__(self, hidden: torch.nn.Linear, out: torch.nn.Linear, average_over=None, overlap: bool = False):
         if hidden.in_features != 1 or out.out_features != 1 or hidden.out_features != out.in_features:
             raise ValueError("SigmoidMLPWeightNet: hidden must be Linear(1, H) and out Linear(H, 1)")
         if hidden.bias is None or out.bias is None:
             raise ValueError("SigmoidMLPWeightNet: both layers carry a bias in the reference's meta-weight-net")
-        self.hidden, self.out, self.average_over = hidden, out, average_over
+        self.hidden, self.out, self.average_over, self.overlap = hidden, out, average_over, bool(overlap)
 
     def tensors(self):
         return [self.hidden.weight, self.hidden.bias, self.out.weight, self.out.bias]
@@ -213,7 +222,7 @@ class WeightedCEMLP:
             return num / den if den > 0 else num
 
         e_hvp, e_mix = rel(hv, hv_auto), rel(mixed, mixed_auto)
-        tol = VERIFY_RTOL
+        tol, relaxed = VERIFY_RTOL, False
         # Config.precision fp16 / bf16: training_step_exec ran the autograd side under autocast (problem.py:327-332) while the closed
         # form is fp32 — a correct declaration then differs by the reduced precision's own error
         if str(getattr(getattr(self.curr, "config", None), "precision", "fp32")) in ("fp16", "bf16"):
@@ -227,22 +236,39 @@ class WeightedCEMLP:
                     h = torch.relu(a)
             if margin < VERIFY_KINK_MARGIN:
                 tol = VERIFY_RTOL_ON_A_KINK
+                relaxed = True
         bad = not (e_hvp <= tol and e_mix <= tol)
-        try:   # data-parallel runs: every rank raises or none does (a rank that raised alone would leave the others in a collective)
-            import torch.distributed as dist  # noqa: PLC0415
+        # data-parallel runs: every rank raises or none does (a rank that raised alone would leave the others in a collective).  A
+        # collective that FAILS is not swallowed: the ranks' verdicts would be unknown.
+        import torch.distributed as dist  # noqa: PLC0415
 
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                flag = torch.tensor([1.0 if bad else 0.0], device=params[0].device if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                bad = bool(flag.item() > 0)
-        except (ImportError, RuntimeError):
-            pass
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([1.0 if bad else 0.0, 1.0 if relaxed else 0.0], device=params[0].device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            bad, relaxed = bool(flag[0].item() > 0), bool(flag[1].item() > 0)
         if bad:
             raise StructureMismatchError(
                 f"hypergradient_structure of problem {getattr(self.curr, 'name', '?')!r} declares {type(self).__name__}, but its "
                 f"training_step disagrees with that closed form on a random direction: Hessian-vector product off by {e_hvp:.2e}, "
                 f"mixed second derivative by {e_mix:.2e} (tolerance {tol:g}).  Typical causes: label smoothing, dropout, a "
                 f"reduction other than the batch mean, a ridge that is not `ridge * sum(w^2)`, layers missing from `layers`.")
+        if relaxed:
+            # a pass under the kink tolerance is NOT cached at once: a slightly wrong declaration (label smoothing ~0.01) can hide under
+            # 3e-2 on such a batch, so the next prepare() — normally another batch — is checked again at the strict tolerance
+            # (ADVICE r5).  A problem that only ever shows such batches (one fixed batch: bench.py's seed 4) is accepted after
+            # VERIFY_KINK_RETRIES relaxed passes, said once.
+            tries = self.curr.__dict__.setdefault("_bhg_structure_relaxed", {}) if hasattr(self.curr, "__dict__") else {}
+            tries[key] = tries.get(key, 0) + 1
+            final = tries[key] >= VERIFY_KINK_RETRIES
+            if tries[key] == 1 or final:
+                warnings.warn(
+                    f"betty_amd: structure check of problem {getattr(self.curr, 'name', '?')!r} passed only under the ReLU-kink tolerance "
+                    f"({tol:g}; Hessian-vector product off by {e_hvp:.2e}, mixed second derivative by {e_mix:.2e}: some hidden "
+                    "pre-activation of this batch sits within 1e-6 of zero) — " +
+                    (f"accepted after {tries[key]} such batches" if final else "not cached, the next batch is checked again"),
+                    RuntimeWarning, stacklevel=3)
+            if not final:
+                return
         done.add(key)
 
     # Optional protocol extension: a provider whose HVP kernels can apply the recurrence themselves runs the whole K
@@ -315,15 +341,45 @@ class WeightedCEMLP:
             # into .grad like Problem.set_grads (problem.py:583-597) after the data-parallel mean the declaration asks for
             wn = self.weight_net
             world, group = 1, None
-            if sync and wn.average_over is not None:
+            if sync:
                 import torch.distributed as dist  # noqa: PLC0415
 
                 if dist.is_available() and dist.is_initialized():
-                    group = None if wn.average_over is True else wn.average_over
-                    world = dist.get_world_size(group)
+                    from ..distributed import ddp_process_group_of  # noqa: PLC0415
+
+                    if wn.average_over is not None:
+                        group = None if wn.average_over is True else wn.average_over
+                        world = dist.get_world_size(group)
+                    else:
+                        # no declaration: do what the reference's backward() through the wrapper would have done
+                        wrapped, group = ddp_process_group_of(getattr(self.prev, "fwd", None), getattr(self.prev, "module", None))
+                        if wrapped:
+                            world = dist.get_world_size(group)
+                        elif dist.get_world_size() > 1 and getattr(self, "expects_data_parallel_mean", False):
+                            # the global-batch mode promises a GLOBAL hypergradient: a rank-local accumulation would silently diverge
+                            raise RuntimeError(
+                                "cg_global(sync=True) with a closed-form weight net: declare SigmoidMLPWeightNet(average_over=True) (or a "
+                                "process group) or wrap the upper module in DistributedDataParallel — otherwise every rank would "
+                                "accumulate the hypergradient of its own batch share only")
             grads, flat = st.upper_vjp(coeff, upper, scale=1.0 / world, with_flat=True)
+            if sync:
+                from ..distributed import defer_grad_sync, fence_grads, install_optimizer_fence  # noqa: PLC0415
+
+                fence_grads()   # an earlier deferred mean into these parameters: order this stream behind it before .grad is touched
             if world > 1:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)   # pre-scaled by 1 / world: the mean (DDP's reduction)
+                if wn.overlap and sync:
+                    # pre-scaled by 1 / world: the mean (DDP's reduction).  Issued asynchronously: the views of `flat` below are
+                    # accumulated / assigned only AFTER the collective in stream order wherever they are read (fence_grads)
+                    if all(p_.grad is None for p_ in upper):
+                        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                        from ..backend import get_backend  # noqa: PLC0415
+
+                        defer_grad_sync(work, flat, get_backend())
+                        install_optimizer_fence(getattr(self.prev, "optimizer", None))
+                    else:   # accumulation onto an existing .grad reads the reduced values right away: nothing to overlap with
+                        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
             if sync:
                 for p_, g_ in zip(upper, grads):
                     p_.grad = g_ if p_.grad is None else p_.grad + g_

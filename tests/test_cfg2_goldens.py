@@ -199,3 +199,50 @@ def test_metric_configuration_against_the_reference_cpu_goldens(seed, bhg_debug)
             assert e64 <= max(RTOL, 3.0 * spread), (seed, e64, spread)
         else:
             assert min(e32, e64) <= RTOL, (seed, e32, e64, spread)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aname", list(mk.ALGOS))
+@pytest.mark.parametrize("seed", WELL_SEEDS)
+def test_the_shipped_library_matches_the_reference_cpu_golden(seed, aname):
+    """the every-arm test above takes the `bhg_debug` fixture, i.e. runs on the measurement build libbhg_ab.so.  This one
+    takes no fixture: it runs on the PRODUCT libbhg.so (what bench.py, smoke() and a user load; asserted) in its only form, at full
+    size, against the reference's own CPU outputs — rtol 1e-4 against fp32 AND against fp64 — and the solve is bit-reproducible."""
+    from betty_amd import _native
+    from betty_amd import hypergradient as hg
+    from betty_amd.backend import get_backend
+
+    assert not _native.is_ab() and not _native.load().bhg_is_ab_build() and _native.load().bhg_debug_key_count() == 0
+    assert get_backend().name == "hip"
+    assert os.path.basename(_native.current_lib_path()) == "libbhg.so"
+    algo, K = mk.ALGOS[aname]
+    curr, prev, vector = bench.build(torch.device("cuda:0"), seed, K=K, algo=algo, ridge=mk.RIDGE_WELL)
+    bench.declare_structure(curr, "hip")
+    lib = _native.load()
+    p0 = int(lib.bhg_mlp_proj_iterations())
+    got = [t.detach().cpu().numpy() for t in hg.jvp_fn_mapping[algo](vector, curr, prev, False)]
+    again = [t.detach().cpu().numpy() for t in hg.jvp_fn_mapping[algo](vector, curr, prev, False)]
+    assert int(lib.bhg_mlp_proj_iterations()) - p0 > 0, "the fused projected solver is the product's form on this workload"
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))
+    e32, e64 = rel(got, GOLD[f"well/{seed}/{aname}/fp32"]), rel(got, GOLD[f"well/{seed}/{aname}/fp64"])
+    print(f"cfg2 well seed={seed} {aname} libbhg.so (product): vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert e32 <= RTOL and e64 <= RTOL, (seed, aname, e32, e64)
+
+
+@pytest.mark.gpu
+def test_the_shipped_library_on_the_metric_instance_against_the_fp64_truth():
+    """The instance bench.py times (ridge 1e-2, seed 0) on the product library: rtol 1e-4 against the reference's fp64 output (the
+    truth; measured 8e-7), the loose bound — 3x the reference's own fp32-vs-fp64 spread — only against its fp32 output."""
+    from betty_amd import _native
+    from betty_amd import hypergradient as hg
+
+    assert not _native.is_ab()
+    for aname, (algo, K) in mk.ALGOS.items():
+        curr, prev, vector = bench.build(torch.device("cuda:0"), 0, K=K, algo=algo, ridge=bench.RIDGE)
+        bench.declare_structure(curr, "hip")
+        got = [t.detach().cpu().numpy() for t in hg.jvp_fn_mapping[algo](vector, curr, prev, False)]
+        spread = float(GOLD[f"metric/0/{aname}/ref_spread"])
+        e32, e64 = rel(got, GOLD[f"metric/0/{aname}/fp32"]), rel(got, GOLD[f"metric/0/{aname}/fp64"])
+        print(f"cfg2 metric seed=0 {aname} libbhg.so (product): vs fp64 truth {e64:.2e}, vs reference-CPU fp32 {e32:.2e} (its own spread {spread:.2e})")
+        assert e64 <= RTOL, (aname, e64)
+        assert e32 <= max(RTOL, 3.0 * spread), (aname, e32, spread)

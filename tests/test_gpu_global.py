@@ -278,6 +278,91 @@ def _average_over_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _overlap_or_ddp_worker(rank, world, port, q, mode):
+    """mode "ddp": average_over left unset, the upper module wrapped in DistributedDataParallel (the closed form must take the
+    mean the wrapper's reducer would have taken, never a rank-local gradient).  mode "overlap": average_over=True, overlap=True — the
+    all-reduce is deferred (betty_amd/distributed.py), .grad holds the mean after the fence / the optimizer's step."""
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zoo
+        from betty_amd import Config
+        from betty_amd import distributed as bd
+
+        torch.cuda.set_device(0)
+        case = zoo.CASE_BY_NAME["reweight_cg20"]
+        inputs = zoo.seed_family_inputs(case.family, seed=rank)
+        shared = zoo.seed_family_inputs(case.family, seed=0)
+        for k in inputs:
+            if not k.startswith(("batch", "vec")):
+                inputs[k] = shared[k]
+        res, pending, fenced_by_step = {}, None, None
+        for sync in (False, True):
+            curr, prev, vector = zoo.build_case(case, inputs, Config, device=DEV)
+            if mode == "ddp":
+                from torch.nn.parallel import DistributedDataParallel as DDP
+
+                prev.fwd = DDP(prev.module, device_ids=[0], gradient_as_bucket_view=True, find_unused_parameters=True)   # as bench.py / problem.py:220-224
+                zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=True, average_over=None)
+            else:
+                zoo.attach_mlp_structure(curr, case.family, impl="hip", weight_net=True, average_over=True, overlap=True)
+                prev.optimizer = torch.optim.SGD(prev.trainable_parameters(), lr=0.0)
+            out = hg.jvp_fn_mapping[case.algo](vector, curr, prev, sync)
+            if sync and mode == "overlap":
+                pending = bd.pending_grad_syncs()
+                prev.optimizer.step()                      # lr = 0: reads .grad, changes nothing; its pre-hook is the fence
+                fenced_by_step = bd.pending_grad_syncs() == 0
+                # a second hop accumulates ONTO the fenced .grad: twice the mean
+                hg.jvp_fn_mapping[case.algo](vector, curr, prev, True)
+                bd.fence_grads()
+                res["twice"] = torch.cat([p.grad.reshape(-1) for p in prev.trainable_parameters()])
+                for p in prev.trainable_parameters():
+                    p.grad = None
+                hg.jvp_fn_mapping[case.algo](vector, curr, prev, True)
+                bd.fence_grads()
+            res[sync] = torch.cat([p.grad.reshape(-1) for p in prev.trainable_parameters()]) if sync else \
+                torch.cat([t.reshape(-1) for t in out])
+        local = res[False].cpu()
+        every = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        mean = sum(every) / world
+        differ = float((every[0] - every[-1]).norm() / every[0].norm())
+        rel = float((res[True].cpu() - mean).norm() / mean.norm())
+        rel2 = float((res["twice"].cpu() - 2 * mean).norm() / mean.norm()) if "twice" in res else 0.0
+        q.put((rank, rel, differ, rel2, pending, fenced_by_step))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ddp", "overlap"])
+def test_closed_form_upper_net_under_ddp_wrapper_and_with_the_deferred_all_reduce(mode):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_overlap_or_ddp_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, differ, rel2, pending, fenced_by_step in sorted(q.get(timeout=5) for _ in range(world)):
+        assert differ > 1e-3, "the ranks must hold different local results for the test to mean anything"
+        assert rel <= 1e-5 and rel2 <= 1e-5, (mode, rank, rel, rel2)
+        if mode == "overlap":
+            assert pending == 1 and fenced_by_step, (pending, fenced_by_step)
+
+
 def test_closed_form_upper_net_averages_over_ranks():
     """sync=True with the upper module declared in closed form and average_over=True: what lands in .grad is the MEAN over the ranks of
     their local hypergradients (sync=False does no collective) — the reduction DistributedDataParallel's reducer performs for the

@@ -1822,8 +1822,10 @@ def test_cfg2_metric_workload_end_to_end(algo, K, ridge, be):
     if algo == "neumann" or ridge >= 0.1:
         assert e_got <= 1e-4 and rel <= 1e-4, (algo, ridge, e_got, rel, e_ref)
     else:
-        bound = max(1e-4, 3.0 * max(e_ref, 1.85e-2))   # 1.85e-2: the reference's CPU fp32-vs-fp64 distance on this seed (cfg2_full.npz)
-        assert e_got <= bound and rel <= bound + e_ref, (algo, ridge, e_got, rel, e_ref)
+        # the distance to the TRUTH is held to rtol 1e-4 (measured 8e-7 on this seed); only the distance to the reference's own fp32
+        # answer keeps the loose bound — 1.85e-2 is the reference's CPU fp32-vs-fp64 distance on this seed (cfg2_full.npz)
+        bound = max(1e-4, 3.0 * max(e_ref, 1.85e-2))
+        assert e_got <= 1e-4 and rel <= bound + e_ref, (algo, ridge, e_got, rel, e_ref)
 
 
 def test_structure_guard_on_the_hip_path(be):

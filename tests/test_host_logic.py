@@ -562,3 +562,150 @@ def test_forward_over_reverse_falls_back_when_an_operator_has_no_forward_formula
         res[mode] = [o.detach().numpy().astype(np.float64) for o in out]
     rel, _ = rel_err(res["forward_over_reverse"], res[None])
     assert rel <= 1e-6, rel
+
+
+# ---- round 6: the deferred data-parallel mean of an accumulated hypergradient (betty_amd/distributed.py) ---------------------------
+class _FakeWork:
+    def __init__(self):
+        self.waits = 0
+
+    def wait(self):
+        self.waits += 1
+
+
+def test_deferred_grad_sync_is_fenced_once_and_by_the_optimizer_step():
+    from betty_amd import distributed as bd
+
+    assert bd.fence_grads() == 0
+    w1, w2 = _FakeWork(), _FakeWork()
+    bd.defer_grad_sync(w1, torch.zeros(4))
+    bd.defer_grad_sync(w2, torch.zeros(4))
+    assert bd.pending_grad_syncs() == 2
+    assert bd.fence_grads() == 2 and (w1.waits, w2.waits) == (1, 1) and bd.pending_grad_syncs() == 0
+    assert bd.fence_grads() == 0 and (w1.waits, w2.waits) == (1, 1)          # a second fence does nothing
+    # optimizer.step() reads .grad: the pre-hook fences first (idempotent installation)
+    p = torch.nn.Parameter(torch.ones(3))
+    opt = torch.optim.SGD([p], lr=0.1)
+    assert bd.install_optimizer_fence(opt) and bd.install_optimizer_fence(opt)
+    p.grad = torch.ones(3)
+    w3 = _FakeWork()
+    bd.defer_grad_sync(w3, p.grad)
+    opt.step()
+    assert w3.waits == 1 and bd.pending_grad_syncs() == 0
+    opt.step()
+    assert w3.waits == 1
+    assert bd.install_optimizer_fence(None) is False
+
+
+def test_ddp_wrapper_names_the_group_whose_mean_the_reference_would_take():
+    from betty_amd import distributed as bd
+
+    lin = torch.nn.Linear(2, 2)
+    assert bd.ddp_process_group_of(lin, None) == (False, None)
+
+    class _Fake(torch.nn.parallel.DistributedDataParallel):   # (constructing a real wrapper needs a process group: tests/test_distributed_cpu.py)
+        def __init__(self):   # noqa: D107
+            torch.nn.Module.__init__(self)
+            self.process_group = "the-group"
+
+    assert bd.ddp_process_group_of(None, _Fake()) == (True, "the-group")
+
+
+def test_forward_over_reverse_says_so_on_train_mode_batchnorm_and_can_be_acknowledged(checker):
+    """the opt-in passes measured 4.4e-3 off on a dense-convolution batch-norm net; a user who sets the flag on such a module
+    is told once per problem, and can acknowledge it."""
+    import warnings as _w
+
+    curr, prev, vector = _convbn_case("neumann", 2)
+    curr.hypergradient_hvp = "forward_over_reverse"
+    with pytest.warns(RuntimeWarning, match="train-mode batch-norm"):
+        hg.neumann(vector, curr, prev, False)
+    with _w.catch_warnings():
+        _w.simplefilter("error")
+        hg.neumann(vector, curr, prev, False)              # once per problem
+        curr2, prev2, vector2 = _convbn_case("neumann", 2)
+        curr2.hypergradient_hvp, curr2.hypergradient_hvp_ack_batchnorm = "forward_over_reverse", True
+        hg.neumann(vector2, curr2, prev2, False)           # acknowledged
+        curr3, prev3, vector3 = _convbn_case("neumann", 2)
+        curr3.module.eval()                                 # eval-mode statistics: nothing to say
+        curr3.hypergradient_hvp = "forward_over_reverse"
+        hg.neumann(vector3, curr3, prev3, False)
+
+
+def test_forward_over_reverse_fallback_is_only_for_a_missing_formula_and_leaves_buffers_advanced_once(checker):
+    """ADVICE r5: (a) a RuntimeError that is NOT a missing forward-mode formula (here: a shape bug in training_step) surfaces as it is;
+    (b) when the fall-back does run on a module with batch-norm statistics, they advance once per solve, as in the default path."""
+    curr, prev, vector = _convbn_case("neumann", 2)
+    curr.hypergradient_hvp, curr.hypergradient_hvp_ack_batchnorm = "forward_over_reverse", True
+
+    def broken(self, batch):
+        xb, _ = batch
+        return (self.module(xb, prev.module()) @ torch.ones(7)).sum()      # 3 classes against 7: a shape error, not a missing jvp
+
+    curr._loss_fn = broken
+    with pytest.raises(RuntimeError, match="shape|size|mat"):
+        hg.neumann(vector, curr, prev, False)
+
+    class NoJvp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    res = {}
+    for mode in (None, "forward_over_reverse"):
+        curr, prev, vector = _convbn_case("neumann", 2)
+
+        def loss_fn(self, batch, prev=prev):
+            xb, yb = batch
+            return torch.nn.functional.cross_entropy(NoJvp.apply(self.module(xb, prev.module())), yb) + 0.5 * sum((p * p).sum() for p in self.module.parameters())
+
+        curr._loss_fn = loss_fn
+        if mode:
+            curr.hypergradient_hvp, curr.hypergradient_hvp_ack_batchnorm = mode, True
+            with pytest.warns(RuntimeWarning, match="forward-over-reverse HVP not available"):
+                torch.manual_seed(11)
+                out = hg.neumann(vector, curr, prev, False)
+        else:
+            torch.manual_seed(11)
+            out = hg.neumann(vector, curr, prev, False)
+        res[mode] = ([o.detach().numpy().astype(np.float64) for o in out], curr.module.bn.running_mean.clone(), int(curr.module.bn.num_batches_tracked))
+    assert res["forward_over_reverse"][2] == res[None][2] == 1
+    torch.testing.assert_close(res["forward_over_reverse"][1], res[None][1], rtol=1e-6, atol=1e-7)
+    rel, _ = rel_err(res["forward_over_reverse"][0], res[None][0])
+    assert rel <= 1e-6, rel
+
+
+def test_structure_guard_does_not_cache_a_pass_under_the_kink_tolerance_at_once():
+    """a batch with a hidden pre-activation on the ReLU kink relaxes the check 30x — such a pass is said aloud and NOT cached
+    (the next batch is checked strictly again); a problem that only ever shows such a batch is accepted after VERIFY_KINK_RETRIES."""
+    import warnings as _w
+
+    from betty_amd.hypergradient import structured
+
+    smoothing = 0.004
+    curr, prov = _guard_case(smoothing)
+    x, _ = curr.cur_batch
+    lin = prov.layers[0]
+    with torch.no_grad():   # put sample 0's first hidden unit exactly on the kink
+        lin.bias[0] -= (lin.weight[0] @ x[0].reshape(-1) + lin.bias[0])
+    # the mild smoothing must sit between the two tolerances for the test to mean anything
+    structured_tol = (structured.VERIFY_RTOL, structured.VERIFY_RTOL_ON_A_KINK)
+    for n in range(1, structured.VERIFY_KINK_RETRIES + 1):
+        with _w.catch_warnings(record=True) as rec:
+            _w.simplefilter("always")
+            prov.prepare()
+        msgs = [str(r.message) for r in rec if "ReLU-kink tolerance" in str(r.message)]
+        cached = len(curr.__dict__.get("_bhg_structure_verified", ()))
+        if n < structured.VERIFY_KINK_RETRIES:
+            assert cached == 0, (n, structured_tol)
+            assert (len(msgs) == 1 and "not cached" in msgs[0]) if n == 1 else not msgs
+        else:
+            assert cached == 1 and len(msgs) == 1 and "accepted after" in msgs[0]
+    # the same declaration on a batch clear of the kink is rejected at the strict tolerance
+    curr2, prov2 = _guard_case(smoothing)
+    with pytest.raises(structured.StructureMismatchError):
+        prov2.prepare()

@@ -490,7 +490,7 @@ def build_case(case: Case, inputs: Dict[str, np.ndarray], config_cls, device="cp
 RIDGE = {"reweight": 0.5, "deep": 0.5}
 
 
-def attach_mlp_structure(curr, family, impl=None, fused=True, weight_net=False, average_over=None):
+def attach_mlp_structure(curr, family, impl=None, fused=True, weight_net=False, average_over=None, overlap=False):
     """Opt the inner problem into the analytic HVP (betty_amd.hypergradient.structured).  weight_net=True also declares the upper
     module (zoo.MWN) as the closed-form meta-weight-net (SigmoidMLPWeightNet)."""
     from betty_amd.hypergradient.structured import SigmoidMLPWeightNet, WeightedCEMLP
@@ -499,7 +499,7 @@ def attach_mlp_structure(curr, family, impl=None, fused=True, weight_net=False, 
         return WeightedCEMLP(
             curr, prev, layers=list(curr.module.layers), weight_fn=lambda ce: prev.fwd(ce.reshape(-1, 1)),
             ridge=RIDGE[family], impl=impl, fused=fused,
-            weight_net=SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=average_over) if weight_net else None,
+            weight_net=SigmoidMLPWeightNet(prev.module.l1, prev.module.l2, average_over=average_over, overlap=overlap) if weight_net else None,
         )
 
     curr.hypergradient_structure = structure
