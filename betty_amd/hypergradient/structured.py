@@ -54,11 +54,103 @@ VERIFY_RTOL_ON_A_KINK = 3e-2
 VERIFY_KINK_RETRIES = 3   # relaxed passes (one per prepare) before a kink-ridden problem's verdict is cached after all
 
 
+# betty_amd.install(auto_structure=True): an inner problem WITHOUT a declaration is looked at once — a Linear / ReLU stack with a
+# per-sample-weighted cross-entropy is the shape of the reference's data-reweighting example (examples/learning_to_reweight/
+# main.py:117-127), whose training_step is opaque to the reference (betty/problems/problem.py:327-332) — and, when the closed form of
+# WeightedCEMLP survives the SAME check a declaration gets (one double backward through the problem's real training_step), the
+# fused solver takes it; anything else stays on the opaque path, silently.  Off by default: the look costs a double backward at the
+# first hypergradient of every inner problem, and a structure is a promise the user has not made.
+AUTO_STRUCTURE = False
+AUTO_IMPL = None          # TEST HOOK ONLY: "torch" lets the CPU suite exercise the recognition with the ATen closed form
+AUTO_STATS = {"looked": 0, "accepted": 0, "rejected": 0}
+
+
 def structured_hvp_for(curr, prev):
     hook = getattr(curr, "hypergradient_structure", None)
-    if hook is None:
+    if hook is not None:
+        return hook(prev)
+    if AUTO_STRUCTURE:
+        return _auto_structure(curr, prev)
+    return None
+
+
+def _linear_stack(module):
+    """The nn.Linear layers of ``module`` in registration order when they carry ALL of its parameters, chain (out_l = in_{l+1}) and all
+    have a bias; else None.  (What sits between them is not visible from here: the guard decides.)"""
+    if module is None:
         return None
-    return hook(prev)
+    inner = getattr(module, "module", None)
+    if isinstance(module, torch.nn.parallel.DistributedDataParallel) and inner is not None:
+        module = inner
+    layers = [m for m in module.modules() if isinstance(m, torch.nn.Linear)]
+    if not layers or any(lin.bias is None for lin in layers):
+        return None
+    owned = {id(t) for lin in layers for t in (lin.weight, lin.bias)}
+    if any(id(p) not in owned for p in module.parameters()) or len(owned) != 2 * len(layers):
+        return None
+    if any(a.out_features != b.in_features for a, b in zip(layers[:-1], layers[1:])):
+        return None
+    for m in module.modules():   # randomness / batch statistics inside the step: not this closed form
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training:
+            return None
+        if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.training and m.p > 0:
+            return None
+    return layers
+
+
+def _auto_structure(curr, prev):
+    """None, or a WeightedCEMLP for this (curr, prev) whose closed form was checked against the problem's own training_step.  The
+    verdict is cached on the problem (keyed by the parameter shapes and the batch size)."""
+    if len(getattr(curr, "paths", []) or []) > 0:
+        return None
+    store = curr.__dict__ if hasattr(curr, "__dict__") else None
+    batch = getattr(curr, "cur_batch", None)
+    if store is None or not (isinstance(batch, (tuple, list)) and len(batch) == 2 and all(torch.is_tensor(t) for t in batch)):
+        return None
+    x, y = batch
+    params = list(curr.trainable_parameters()) if hasattr(curr, "trainable_parameters") else list(curr.parameters())
+    key = (tuple(tuple(p.shape) for p in params), int(x.shape[0]))
+    cache = store.setdefault("_bhg_auto_structure", {})
+
+    def build(verdict, verify):
+        layers = verdict["layers"]
+        fwd = getattr(prev, "fwd", None) or prev.module
+        wn = SigmoidMLPWeightNet(*verdict["weight_net"]) if verdict["weight_net"] is not None else None
+        return WeightedCEMLP(curr, prev, layers=layers, weight_fn=lambda ce: fwd(ce.reshape(-1, 1)), ridge=verdict["ridge"],
+                             impl=AUTO_IMPL, verify=verify, weight_net=wn)
+
+    if key in cache:
+        return build(cache[key], False) if cache[key] is not None else None
+    AUTO_STATS["looked"] += 1
+    cache[key] = None
+    layers = _linear_stack(getattr(curr, "module", None))
+    ok = (layers is not None and len(params) == 2 * len(layers)
+          and all(a is b for a, b in zip(params, [t for lin in layers for t in (lin.weight, lin.bias)]))
+          and y.dtype in (torch.int64, torch.int32) and y.dim() == 1 and x.shape[0] == y.shape[0] and x.is_floating_point()
+          and x[0].numel() == layers[0].in_features and (AUTO_IMPL == "torch" or (x.is_cuda and params[0].dtype == torch.float32)))
+    if ok:
+        upper_layers = _linear_stack(getattr(prev, "module", None))
+        wn = None
+        if (upper_layers is not None and len(upper_layers) == 2 and upper_layers[0].in_features == 1 and upper_layers[1].out_features == 1):
+            wn = (upper_layers[0], upper_layers[1])
+        for cand in ([wn, None] if wn is not None else [None]):
+            verdict = {"layers": layers, "weight_net": cand, "ridge": 0.0}
+            try:
+                # the one quantity a declaration states that cannot be read off the modules: `ridge * sum(w^2)` in the loss shows up as
+                # 2 ridge v in H v — estimated from one product, then the estimate goes through the ordinary guard like a declared value
+                probe = build(verdict, False)
+                probe.prepare()
+                verdict["ridge"] = probe._estimate_ridge()
+                build(verdict, True).prepare()           # raises StructureMismatchError when the closed form does not describe the step
+            except (StructureMismatchError, ValueError, NotImplementedError):
+                continue
+            cache[key] = verdict
+            break
+    if cache[key] is None:
+        AUTO_STATS["rejected"] += 1
+        return None
+    AUTO_STATS["accepted"] += 1
+    return build(cache[key], False)
 
 
 class SigmoidMLPWeightNet:
@@ -192,14 +284,8 @@ class WeightedCEMLP:
             self._verify_against_autograd(x, y)
         return self._state.hvp
 
-    def _verify_against_autograd(self, x, y):
-        """See VERIFY_STRUCTURE.  The verdict is cached on the problem object, keyed by what the closed form depends on."""
-        params = list(self.curr.parameters())
-        key = (tuple(tuple(p.shape) for p in params), int(x.shape[0]), self.ridge, type(self._state).__name__)
-        done = self.curr.__dict__.setdefault("_bhg_structure_verified", set()) if hasattr(self.curr, "__dict__") else set()
-        if key in done:
-            return
-        upper = list(self.prev.trainable_parameters())
+    def _autograd_second_order(self, params, upper):
+        """(direction, H direction, d(g . direction)/d upper) through the problem's REAL training_step: one double backward."""
         gen = torch.Generator(device="cpu").manual_seed(20240926)
         direction = [torch.randn(p.shape, generator=gen).to(device=p.device, dtype=p.dtype) for p in params]
         # the extra training_step of the check must not be seen by the run: the RNG streams are forked around it (dropout elsewhere in
@@ -210,7 +296,40 @@ class WeightedCEMLP:
             grads = torch.autograd.grad(loss, params, create_graph=True)
             dot = sum((g * d).sum() for g, d in zip(grads, direction))
             second = torch.autograd.grad(dot, params + upper, allow_unused=True)
-        hv_auto, mixed_auto = second[:len(params)], second[len(params):]
+        return direction, second[:len(params)], second[len(params):]
+
+    def _estimate_ridge(self) -> float:
+        """auto-structure only (after prepare()): the coefficient rho of a `rho * sum(w^2)` term in the problem's loss, read off ONE
+        Hessian-vector product — H_autograd v - H_closed-form(ridge = 0) v = 2 rho v when that term is all the closed form misses.
+        0.0 when the difference is not a multiple of v (the guard then judges the structure with ridge 0, and rejects it)."""
+        params = list(self.curr.parameters())
+        direction, hv_auto, _ = self._autograd_second_order(params, list(self.prev.trainable_parameters()))
+        hv0 = [h.detach().clone() for h in self._state.hvp(direction)]
+        num = sum(float(((a.double() - b.double()) * d.double()).sum()) for a, b, d in zip(hv_auto, hv0, direction))
+        den = sum(float((d.double() ** 2).sum()) for d in direction)
+        c = num / den
+        res = sum(float(((a.double() - b.double() - c * d.double()) ** 2).sum()) for a, b, d in zip(hv_auto, hv0, direction)) ** 0.5
+        ref = sum(float((a.double() ** 2).sum()) for a in hv_auto) ** 0.5
+        # (a multiple of v below the product's own fp32 noise is no ridge: 1e-5 of |H v|)
+        if c <= 0.0 or res > VERIFY_RTOL * max(ref, 1e-300) or c * den ** 0.5 <= 1e-5 * ref:
+            return 0.0
+        rho = 0.5 * c
+        # a coefficient written as a short decimal in the user's code is recovered exactly when the estimate sits within fp32 noise of one
+        for digits in range(1, 7):
+            r = round(rho, digits)
+            if r > 0 and abs(r - rho) <= 2e-4 * rho:
+                return float(r)
+        return float(rho)
+
+    def _verify_against_autograd(self, x, y):
+        """See VERIFY_STRUCTURE.  The verdict is cached on the problem object, keyed by what the closed form depends on."""
+        params = list(self.curr.parameters())
+        key = (tuple(tuple(p.shape) for p in params), int(x.shape[0]), self.ridge, type(self._state).__name__)
+        done = self.curr.__dict__.setdefault("_bhg_structure_verified", set()) if hasattr(self.curr, "__dict__") else set()
+        if key in done:
+            return
+        upper = list(self.prev.trainable_parameters())
+        direction, hv_auto, mixed_auto = self._autograd_second_order(params, upper)
         hv = [h.detach().clone() + self.hvp_shift * d for h, d in zip(self._state.hvp(direction), direction)]
         coeff = self._state.mixed_coeff(direction)   # (the graph of the sample weights is kept: the real mixed_vjp comes later)
         mixed = self._state.upper_vjp(coeff, upper, retain_graph=True)   # closed-form weight net: its kernels are what is checked

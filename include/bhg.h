@@ -404,6 +404,22 @@ int bhg_mwn_forward(const float* ce, int B, const float* w1, const float* b1, co
 int bhg_mwn_backward(const float* ce, const float* coeff, int B, const float* w1, const float* b1, const float* w2, const float* b2,
                      int H, float scale, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
 
+/* ---- batch normalisation inside an opaque Hessian-vector product (round 6; csrc/bhg_bn.hip) -------------------------------------------
+ * The reference takes H p as the double backward torch.autograd.grad(in_grad, params, grad_outputs=p) (betty/hypergradient/cg.py:39-41,
+ * neumann.py:62).  For an inner network with training-mode batch norm (BASELINE cfg 3: examples/implicit_maml/models.py:278-483) ATen
+ * differentiates batch norm's backward through ~340 element-wise / reduction launches per layer and product.  This entry point is that
+ * derivative in two launches: the vector-Jacobian product of
+ *     F : (x, gy, gamma) -> (gx, ggamma, gbeta)      (batch_norm_backward with batch statistics, biased variance)
+ * i.e. for cotangents a (of gx, shaped like x; may be NULL = zero), b (of ggamma, [C]; may be NULL), c (of gbeta, [C]; may be NULL):
+ *     dx, dgy (shaped like x, overwritten), dgamma ([C], overwritten; may be NULL)  =  d( <a, gx> + <b, ggamma> + <c, gbeta> ) / d(x, gy, gamma)
+ * with mean / invstd ([C], what the forward saved) treated as the functions of x they are.  x, gy, a, dx, dgy: fp32, NCHW contiguous,
+ * N x C x HW elements, 16-byte aligned when HW % 4 == 0; gamma may be NULL (affine = False).  `ws`: bhg_bn_ws_bytes(C) bytes of scratch.
+ * Deterministic (two-stage sums in fixed order, fp64 accumulation), asynchronous on `stream`; 32 algorithmic bytes per element.          */
+size_t bhg_bn_ws_bytes(int C);
+int bhg_bn_backward_vjp(const float* x, const float* gy, const float* a, const float* gamma, const float* mean, const float* invstd,
+                        const float* b, const float* c, int N, int C, int HW, float* dx, float* dgy, float* dgamma, void* ws,
+                        size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

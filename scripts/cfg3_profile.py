@@ -21,6 +21,7 @@ import zoo  # noqa: E402
 from betty_amd import Config, hypergradient as hg  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+fused_bn = len(sys.argv) > 2 and sys.argv[2] == "fused-bn"   # declare the batch-norm layers (betty_amd.nn.fuse_batchnorm_)
 dev = "cuda:0"
 g = torch.Generator().manual_seed(77)
 torch.manual_seed(77)
@@ -32,6 +33,10 @@ y = torch.arange(5).repeat_interleave(5).to(dev)
 vector = [0.01 * torch.randn(p.shape, generator=g).to(dev) for p in inner.parameters()]
 prev = zoo.StubProblem("upper", upper, config=Config())
 curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=20), loss_fn=zoo.make_imaml_loss(prev, 0.5), batch=(x, y))
+if fused_bn:
+    from betty_amd import nn as bnn
+
+    print("declared batch-norm layers:", bnn.fuse_batchnorm_(inner))
 for _ in range(2):
     hg.cg(vector, curr, prev, False)
 torch.cuda.synchronize()
@@ -41,4 +46,4 @@ for _ in range(steps):
     hg.cg(vector, curr, prev, False)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"cfg3 ResNet-12 CG-20 opaque: {steps} steps in {dt:.3f} s = {steps / dt:.3f} steps/s ({1e3 * dt / steps / 21:.1f} ms per (HVP + recurrence), 21 double-backward-sized passes per step)")
+print(f"cfg3 ResNet-12 CG-20 opaque{' (declared batch norm)' if fused_bn else ''}: {steps} steps in {dt:.3f} s = {steps / dt:.3f} steps/s ({1e3 * dt / steps / 21:.1f} ms per (HVP + recurrence), 21 double-backward-sized passes per step)")

@@ -27,6 +27,14 @@ def bench(fn, n=5):
 
 ours = bench(lambda: hg.cg(vector, curr, prev, False))
 ref = bench(lambda: horc.cg(vector, curr, prev, False))
+# round 6: the batch-norm layers declared (betty_amd.nn.fuse_batchnorm_): their double backward is bhg_bn_backward_vjp
+from betty_amd import nn as bnn
+want = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).double()
+n_bn = bnn.fuse_batchnorm_(inner)
+got = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).double()
+ours_bn = bench(lambda: hg.cg(vector, curr, prev, False))
+print(f"ResNet-12 cfg3 CG-20 with {n_bn} declared batch-norm layers: betty_amd {ours_bn:.2f} steps/s (x{ours_bn / ref:.2f} over the reference's algorithm on "
+      f"this GPU, x{ours_bn / ours:.2f} over the undeclared product); result vs the undeclared product: rel {float((got - want).norm() / want.norm()):.2e}")
 zoo.attach_prox_structure(curr)
 ours_struct = bench(lambda: hg.cg(vector, curr, prev, False))
 print(f"ResNet-12 cfg3 CG-20, opaque HVP: betty_amd {ours:.2f} steps/s | reference algorithm on the same GPU {ref:.2f} steps/s"

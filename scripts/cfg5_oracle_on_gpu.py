@@ -20,7 +20,9 @@ from betty_amd import hypergradient as hg  # noqa: E402
 
 dev = torch.device("cuda:0")
 gold = np.load(os.path.join(ROOT, "tests", "golden", "cfg5_as_named.npz"))
-K = zoo.CFG5_K
+K = int(sys.argv[1]) if len(sys.argv) > 1 else zoo.CFG5_K   # 3: the short-horizon golden of round 6
+if len(sys.argv) > 2 and sys.argv[2] == "deterministic":
+    torch.backends.cudnn.deterministic = True
 
 
 def flat(ts):
@@ -31,7 +33,7 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-curr, prev, vector = zoo.cfg5_as_named_case(Config, dev)
+curr, prev, vector = zoo.cfg5_as_named_case(Config, dev, K=K)
 curr.hypergradient_hvp = "forward_over_reverse"
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -40,7 +42,7 @@ torch.cuda.synchronize()
 t_got = time.perf_counter() - t0
 print(f"product (forward-over-reverse HVP): {t_got:.1f} s/step; vs reference-CPU fp32 {rel(got, gold[f'neumann{K}/fp32']):.2e}, "
       f"vs reference fp64 {rel(got, gold[f'neumann{K}/fp64']):.2e} (reference's own fp32-vs-fp64 {float(gold[f'neumann{K}/ref_spread']):.2e})", flush=True)
-curr2, prev2, vector2 = zoo.cfg5_as_named_case(Config, dev)
+curr2, prev2, vector2 = zoo.cfg5_as_named_case(Config, dev, K=K)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 want = flat(horc.neumann(vector2, curr2, prev2, False))

@@ -9,7 +9,12 @@ path is compared with) and in fp64 (the truth; |fp32 - fp64| is the reference's 
 The inputs are not stored: ``tests/zoo.cfg5_as_named_case`` regenerates them from the seed with the CPU generator; the file carries
 fp64 checksums of every input tensor so the GPU test proves it rebuilt the very same problem.
 
-Usage:  python tests/golden/make_cfg5_golden.py        (build container only: needs /root/reference; 8 threads)
+Round 6 adds SHORT-HORIZON goldens of the same named network (K = 3): the fp32-vs-fp64 spread of the reference itself grows with the
+number of Neumann terms (9.9e-4 at K = 20: below what fp32 resolves across devices) — at K = 3 it is far below north_star's rtol 1e-4,
+so the GPU test can hold the product to 1e-4 against the reference's own CPU output there.
+
+Usage:  python tests/golden/make_cfg5_golden.py            (build container only: needs /root/reference; 8 threads; K = 20: ~35 min)
+        python tests/golden/make_cfg5_golden.py 3 [5 ...]  (adds / refreshes neumann<K> entries, keeps the others of the file as they are)
 """
 import os
 import sys
@@ -43,8 +48,13 @@ def run(dtype, K):
 
 def main():
     assert zoo.nas_dir() is not None
+    path = os.path.join(HERE, "cfg5_as_named.npz")
+    Ks = [int(a) for a in sys.argv[1:]] or [zoo.CFG5_K]
     blob = {}
-    for K in (zoo.CFG5_K,):
+    if os.path.exists(path) and Ks != [zoo.CFG5_K]:
+        old = np.load(path)
+        blob = {k: old[k] for k in old.files}
+    for K in Ks:
         t0 = time.time()
         r32, cs = run(torch.float32, K)
         t1 = time.time()
@@ -52,10 +62,11 @@ def main():
         spread = ((r32.double() - r64).norm() / r64.norm()).item()
         blob[f"neumann{K}/fp32"], blob[f"neumann{K}/fp64"] = r32.numpy(), r64.numpy()
         blob[f"neumann{K}/ref_spread"] = np.array(spread)
+        assert "checksum" not in blob or np.array_equal(blob["checksum"], cs), "the seeded inputs changed under the committed golden"
         blob["checksum"] = cs
         print(f"cfg 5 as named, neumann K={K} alpha={zoo.CFG5_ALPHA}: |out| = {r64.norm().item():.6e}, {r32.numel()} floats; reference fp32-vs-fp64 "
               f"= {spread:.2e}   (fp32 {t1 - t0:.0f} s, fp64 {time.time() - t1:.0f} s, {torch.get_num_threads()} threads)", flush=True)
-    np.savez_compressed(os.path.join(HERE, "cfg5_as_named.npz"), **blob)
+    np.savez_compressed(path, **blob)
     print(f"wrote cfg5_as_named.npz ({os.path.getsize(os.path.join(HERE, 'cfg5_as_named.npz')) / 1024:.1f} KiB)")
 
 

@@ -32,7 +32,7 @@ def ref():
     finally:
         sys.path.remove(REF)
     saved = dict(bh.jvp_fn_mapping)
-    yield dict(bh=bh, Config=Config, EngineConfig=EngineConfig, Engine=Engine, ImplicitProblem=ImplicitProblem)
+    yield dict(bh=bh, Config=Config, EngineConfig=EngineConfig, Engine=Engine, ImplicitProblem=ImplicitProblem, saved_mapping=dict(saved))
     bh.jvp_fn_mapping.clear()
     bh.jvp_fn_mapping.update(saved)
 
@@ -215,3 +215,99 @@ def test_reference_engine_drives_the_fused_mlp_solver(ref):
     print(f"reference Engine, reweighting MLP {dims}, cg K={K}, {steps} outer steps: meta-weight-net after the run: "
           f"|hip - reference| / |reference| = {num / den:.2e}; inner nets differ by {moved:.2e}")
     assert np.isfinite(num) and num / den <= 1e-4, (num, den)
+
+
+@pytest.mark.gpu
+def test_reference_engine_takes_the_fused_solver_without_a_declaration(ref):
+    """the headline path for an UNMODIFIED Betty user.  Same scenario as above, but the inner problem declares nothing:
+    `betty_amd.install(auto_structure=True)` looks at it once (Linear / ReLU stack, (x, y) batch, meta-weight-net of two Linear layers),
+    estimates the ridge from one Hessian-vector product, puts the closed form through the declaration's own check against autograd —
+    and every hypergradient is one fully projected bhg_mlp_cg_solve.  The same problem with label smoothing in its loss is looked at,
+    REJECTED by that check, and runs on the opaque path (no projected iteration), silently, with the reference's result."""
+    import betty_amd
+    from betty_amd import _native
+    from betty_amd.backend import get_backend
+    from betty_amd.hypergradient import structured
+
+    assert get_backend().name == "hip"
+    Config, EngineConfig, Engine, ImplicitProblem = ref["Config"], ref["EngineConfig"], ref["Engine"], ref["ImplicitProblem"]
+    dims, B, K, steps, ridge = [256, 384, 128, 10], 100, 5, 6, 0.05
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+
+        def forward(self, x):
+            for i, lin in enumerate(self.layers):
+                x = lin(x)
+                if i + 1 < len(self.layers):
+                    x = F.relu(x)
+            return x
+
+    class MWN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(1, 32), torch.nn.Linear(32, 1)
+
+        def forward(self, x):
+            return torch.sigmoid(self.l2(F.relu(self.l1(x))))
+
+    def run(smoothing):
+        torch.manual_seed(11)
+        g = torch.Generator().manual_seed(12)
+        net, mwn = MLP(), MWN()
+        xt, xv = torch.randn(B, dims[0], generator=g), torch.randn(B, dims[0], generator=g)
+        yt, yv = torch.randint(0, 10, (B,), generator=g), torch.randint(0, 10, (B,), generator=g)
+
+        class Reweight(ImplicitProblem):
+            def training_step(self, batch):
+                x, y = batch
+                return F.cross_entropy(self.classifier(x), y)
+
+        class Classifier(ImplicitProblem):       # nothing declared: an ordinary Betty problem
+            def training_step(self, batch):
+                x, y = batch
+                logits = self.module(x)
+                ce = F.cross_entropy(logits, y, reduction="none", label_smoothing=smoothing)
+                w = self.reweight(F.cross_entropy(logits, y, reduction="none").detach().reshape(-1, 1)).reshape(-1)
+                return torch.mean(w * ce) + ridge * sum((p * p).sum() for p in self.module.parameters())
+
+        outer = Reweight(name="reweight", module=mwn, optimizer=torch.optim.SGD(mwn.parameters(), lr=0.1),
+                         train_data_loader=[(xv, yv)], config=Config())
+        inner = Classifier(name="classifier", module=net, optimizer=torch.optim.SGD(net.parameters(), lr=0.05),
+                           train_data_loader=[(xt, yt)], config=Config(type="cg", cg_iterations=K, cg_alpha=1.0, unroll_steps=1))
+        engine = Engine(config=EngineConfig(train_iters=steps), problems=[outer, inner],
+                        dependencies={"u2l": {outer: [inner]}, "l2u": {inner: [outer]}})
+        engine.run()
+        return [p.detach().double().cpu().numpy().copy() for p in mwn.parameters()]
+
+    def dist(a, b):
+        num = sum(float(((x - y) ** 2).sum()) for x, y in zip(a, b)) ** 0.5
+        return num / sum(float((y ** 2).sum()) for y in b) ** 0.5
+
+    lib = _native.load()
+    saved_flag = structured.AUTO_STRUCTURE
+    try:
+        for smoothing in (0.0, 0.1):
+            ref["bh"].jvp_fn_mapping.clear()
+            ref["bh"].jvp_fn_mapping.update(ref["saved_mapping"])   # the reference's own functions for the baseline run
+            want = run(smoothing)                                    # the reference's own cg on this GPU
+            betty_amd.install(ref["bh"], auto_structure=True)
+            p0, s0 = lib.bhg_mlp_proj_iterations(), dict(structured.AUTO_STATS)
+            got = run(smoothing)
+            d_proj = lib.bhg_mlp_proj_iterations() - p0
+            looked = structured.AUTO_STATS["looked"] - s0["looked"]
+            acc, rej = structured.AUTO_STATS["accepted"] - s0["accepted"], structured.AUTO_STATS["rejected"] - s0["rejected"]
+            e = dist(got, want)
+            print(f"reference Engine, UNDECLARED reweighting MLP {dims}, label smoothing {smoothing}: looked {looked}, accepted {acc}, rejected {rej}, "
+                  f"projected iterations {d_proj}; meta-weight-net after {steps} outer steps vs the reference's own cg: {e:.2e}")
+            assert looked == 1, "one look per problem: the verdict is cached"
+            if smoothing == 0.0:
+                assert (acc, rej) == (1, 0) and d_proj == steps * (K - 1), (acc, rej, d_proj)
+            else:
+                assert (acc, rej) == (0, 1) and d_proj == 0, (acc, rej, d_proj)
+            assert np.isfinite(e) and e <= 1e-4, e
+            betty_amd.install(ref["bh"], auto_structure=False)
+    finally:
+        structured.AUTO_STRUCTURE = saved_flag

@@ -709,3 +709,145 @@ def test_structure_guard_does_not_cache_a_pass_under_the_kink_tolerance_at_once(
     curr2, prov2 = _guard_case(smoothing)
     with pytest.raises(structured.StructureMismatchError):
         prov2.prepare()
+
+
+# ---- round 6: betty_amd.install(auto_structure=True) — recognising the Linear / ReLU stack without a declaration -----------------
+@pytest.fixture()
+def auto_structure():
+    from betty_amd.hypergradient import structured
+
+    saved = (structured.AUTO_STRUCTURE, structured.AUTO_IMPL)
+    structured.AUTO_STRUCTURE, structured.AUTO_IMPL = True, "torch"   # (the ATen closed form: the CPU suite has no GPU)
+    try:
+        yield structured
+    finally:
+        structured.AUTO_STRUCTURE, structured.AUTO_IMPL = saved
+
+
+def _undeclared_case(smoothing=0.0, ridge=0.05, upper_act="relu", dropout=0.0, dtype=torch.float32):
+    torch.manual_seed(21)
+    g = torch.Generator().manual_seed(21)
+    dims, B = [12, 16, 8, 4], 10
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+            self.drop = torch.nn.Dropout(dropout)
+
+        def forward(self, x):
+            for i, lin in enumerate(self.layers):
+                x = lin(x)
+                if i + 1 < len(self.layers):
+                    x = self.drop(torch.relu(x))
+            return x
+
+    class MWN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(1, 8), torch.nn.Linear(8, 1)
+
+        def forward(self, c):
+            h = self.l1(c)
+            return torch.sigmoid(self.l2(torch.relu(h) if upper_act == "relu" else torch.tanh(h)))
+
+    inner, upper = Net().to(dtype), MWN().to(dtype)
+    x, y = torch.randn(B, dims[0], generator=g, dtype=dtype), torch.randint(0, dims[-1], (B,), generator=g)
+    prev = zoo.StubProblem("upper", upper, config=Config())
+
+    def loss_fn(self, batch):
+        xb, yb = batch
+        logits = self.module(xb)
+        ce = torch.nn.functional.cross_entropy(logits, yb, reduction="none", label_smoothing=smoothing)
+        w = prev.fwd(torch.nn.functional.cross_entropy(logits, yb, reduction="none").detach().reshape(-1, 1)).reshape(-1)
+        return torch.mean(w * ce) + ridge * sum((p * p).sum() for p in self.module.parameters())
+
+    curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=4, cg_alpha=1.0), loss_fn=loss_fn, batch=(x, y))
+    vector = [0.1 * torch.randn(p.shape, generator=g, dtype=dtype) for p in inner.parameters()]
+    return curr, prev, vector
+
+
+def _opaque(curr, prev, vector, structured):
+    structured.AUTO_STRUCTURE = False
+    try:
+        return [t.detach().numpy() for t in hg.cg(vector, curr, prev, False)]
+    finally:
+        structured.AUTO_STRUCTURE = True
+
+
+def test_auto_structure_recognises_the_reweighting_mlp_and_its_ridge(auto_structure, checker):
+    curr, prev, vector = _undeclared_case(ridge=0.05)
+    assert not hasattr(curr, "hypergradient_structure")
+    want = _opaque(curr, prev, vector, auto_structure)
+    s0 = dict(auto_structure.AUTO_STATS)
+    prov = auto_structure.structured_hvp_for(curr, prev)
+    assert isinstance(prov, auto_structure.WeightedCEMLP) and prov.ridge == 0.05 and prov.weight_net is not None
+    assert auto_structure.AUTO_STATS["accepted"] == s0["accepted"] + 1
+    got = [t.detach().numpy() for t in hg.cg(vector, curr, prev, False)]
+    assert auto_structure.AUTO_STATS["looked"] == s0["looked"] + 1, "the verdict is cached on the problem: one look"
+    rel, _ = rel_err(got, want)
+    assert rel <= 1e-4, rel
+    # no ridge in the loss: recognised with ridge 0
+    curr0, prev0, _ = _undeclared_case(ridge=0.0)
+    assert auto_structure.structured_hvp_for(curr0, prev0).ridge == 0.0
+
+
+@pytest.mark.parametrize("why", ["label_smoothing", "dropout", "no_tuple_batch", "extra_parameter", "declared_wins"])
+def test_auto_structure_leaves_everything_else_on_the_opaque_path(why, auto_structure, checker):
+    kw = {"label_smoothing": dict(smoothing=0.1), "dropout": dict(dropout=0.3)}.get(why, {})
+    curr, prev, vector = _undeclared_case(**kw)
+    if why == "no_tuple_batch":
+        x, y = curr.cur_batch
+        curr.cur_batch = {"x": x, "y": y}
+        curr._loss_fn = (lambda f: lambda self, batch: f(self, (batch["x"], batch["y"])))(curr._loss_fn)
+    if why == "extra_parameter":
+        curr.module.scale = torch.nn.Parameter(torch.ones(()))
+    if why == "declared_wins":
+        sentinel = object()
+        curr.hypergradient_structure = lambda prev_: sentinel
+        assert auto_structure.structured_hvp_for(curr, prev) is sentinel
+        return
+    s0 = dict(auto_structure.AUTO_STATS)
+    assert auto_structure.structured_hvp_for(curr, prev) is None
+    if why in ("label_smoothing",):
+        assert auto_structure.AUTO_STATS["rejected"] == s0["rejected"] + 1
+    if why != "extra_parameter":   # (the stub's parameter list no longer matches its vector there)
+        torch.manual_seed(5)
+        got = [t.detach().numpy() for t in hg.cg(vector, curr, prev, False)]   # silently opaque: still the reference's answer
+        torch.manual_seed(5)
+        want = _opaque(curr, prev, vector, auto_structure)
+        rel, _ = rel_err(got, want)
+        assert rel <= 1e-12, rel
+
+
+def test_auto_structure_keeps_a_wrong_weight_net_guess_out_but_the_inner_form_in(auto_structure, checker):
+    """The upper module LOOKS like the meta-weight-net (Linear(1, H), Linear(H, 1)) but uses tanh: the closed-form weight net is
+    rejected by the guard's mixed-derivative check, the inner closed form with weight_fn under autograd is accepted."""
+    curr, prev, vector = _undeclared_case(upper_act="tanh", ridge=0.5)   # (2 ridge dominates: four fp32 CG steps stay comparable)
+    prov = auto_structure.structured_hvp_for(curr, prev)
+    # (impl="torch" never uses the closed-form weight net — both candidates pass there; on the HIP path the first is rejected:
+    #  tests/test_dropin_reference.py)
+    assert isinstance(prov, auto_structure.WeightedCEMLP)
+    want = _opaque(curr, prev, vector, auto_structure)
+    got = [t.detach().numpy() for t in hg.cg(vector, curr, prev, False)]
+    rel, _ = rel_err(got, want)
+    assert rel <= 1e-4, rel
+
+
+def test_install_switches_auto_structure():
+    import betty_amd
+    from betty_amd.hypergradient import structured
+
+    class _Reg:
+        jvp_fn_mapping = {}
+
+    saved = structured.AUTO_STRUCTURE
+    try:
+        betty_amd.install(_Reg, auto_structure=True)
+        assert structured.AUTO_STRUCTURE is True
+        betty_amd.install(_Reg)
+        assert structured.AUTO_STRUCTURE is True          # None leaves it
+        betty_amd.install(_Reg, auto_structure=False)
+        assert structured.AUTO_STRUCTURE is False
+    finally:
+        structured.AUTO_STRUCTURE = saved
