@@ -165,6 +165,7 @@ SYMBOLS = {
     "bhg_mlp_proj_iterations": (c_int64, []),
     "bhg_mlp_lin_launches": (c_int64, []),
     "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "bhg_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "bhg_bn_ws_bytes": (c_size_t, [c_int]),
     "bhg_bn_backward_vjp": (
         c_int,

@@ -127,4 +127,15 @@ int bhg_layout_build(const int64_t* numel, int T, int64_t* starts, bhg_chunk* ch
   return BHG_OK;
 }
 
+// Strided block copy on the device (one hipMemcpy2DAsync): what betty_amd/hypergradient/_mlp_hip.py uses to keep the zero-padded twin of
+// a network whose widths are not multiples of 32 (and to un-pad results) — see include/bhg.h.
+int bhg_copy2d(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int64_t cols, void* stream) {
+  BHG_REQUIRE(rows >= 0 && cols >= 0 && ldd >= cols && lds >= cols, "bad block shape");
+  if (rows == 0 || cols == 0) return BHG_OK;
+  BHG_REQUIRE(dst && src, "NULL pointer");
+  BHG_HIP_CHECK(hipMemcpy2DAsync(dst, sizeof(float) * (size_t)ldd, src, sizeof(float) * (size_t)lds, sizeof(float) * (size_t)cols,
+                                 (size_t)rows, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return BHG_OK;
+}
+
 }  // extern "C"

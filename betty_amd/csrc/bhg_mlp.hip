@@ -1999,16 +1999,64 @@ static int check_head_problem(const bhg_mlp* m) {
   BHG_REQUIRE(m, "NULL descriptor");
   BHG_REQUIRE(m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS, "unsupported layer count");
   BHG_REQUIRE(m->Bp > 0 && m->Bp % kTM == 0 && m->B >= 1 && m->B <= m->Bp, "Bp must be a multiple of 128 rows >= B");
-  BHG_REQUIRE(m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0,
-              "native prepare needs a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   return BHG_OK;
 }
+// narrow head (<= 32 classes, feature width % 4 == 0): the latency-optimised head kernels; anything wider: the output layer as one more
+// split-K product + a row kernel (round 6: the ATen fallback of rounds 1-5 is gone from the product)
+static bool narrow_head(const bhg_mlp* m) { return m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0; }
 
 int bhg_mlp_supports_native_prepare(const bhg_mlp* m) {
-  return m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0 && m->dims[m->L] <= kSmallC &&
-         (m->dims[m->L - 1] & 3) == 0;
+  return m && m->L >= 1 && m->L <= BHG_MLP_MAX_LAYERS && m->Bp > 0 && m->Bp % kTM == 0;
 }
+
+}  // extern "C"
+namespace bhg {
+namespace {
+// One workgroup per sample row, any class count: z (logits, in place) -> softmax; ce[b] = -log softmax(z)[y_b].  Rows >= B: zeros.
+__global__ __launch_bounds__(kThreads) void k_softmax_ce_rows(float* __restrict__ z, const int64_t* __restrict__ labels,
+                                                              float* __restrict__ ce, int C, int B) {
+  __shared__ double red[kWaves];
+  __shared__ float redf[kWaves];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float* row = z + (int64_t)b * C;
+  if (b >= B) {
+    for (int c = t; c < C; c += kThreads) row[c] = 0.f;
+    if (t == 0) ce[b] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int c = t; c < C; c += kThreads) mx = fmaxf(mx, row[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((t & 63) == 0) redf[t >> 6] = mx;
+  __syncthreads();
+  mx = redf[0];
+  for (int w = 1; w < kWaves; ++w) mx = fmaxf(mx, redf[w]);
+  double s = 0.0;
+  for (int c = t; c < C; c += kThreads) s += (double)expf(row[c] - mx);
+  s = block_sum(s, red);
+  const float lse = mx + logf((float)s);
+  const float zy = row[(int)labels[b]];
+  __syncthreads();   // every thread has read z[y] before the row is overwritten
+  for (int c = t; c < C; c += kThreads) row[c] = expf(row[c] - lse);
+  if (t == 0) ce[b] = lse - zy;
+}
+// coeff[b] = sum_c (prob[b][c] - [c == y_b]) * rz[b][c] / B   (the mixed-derivative coefficient; rows >= B: 0)
+__global__ __launch_bounds__(kThreads) void k_coeff_rows(const float* __restrict__ prob, const float* __restrict__ rz,
+                                                         const int64_t* __restrict__ labels, float* __restrict__ coeff, int C, int B) {
+  __shared__ double red[kWaves];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b >= B) { if (t == 0) coeff[b] = 0.f; return; }
+  const int y = (int)labels[b];
+  double s = 0.0;
+  for (int c = t; c < C; c += kThreads) s += (double)((prob[(int64_t)b * C + c] - (c == y ? 1.f : 0.f)) * rz[(int64_t)b * C + c]);
+  s = block_sum(s, red);
+  if (t == 0) coeff[b] = (float)(s / (double)B);
+}
+}  // namespace
+}  // namespace bhg
+using namespace bhg;
+extern "C" {
 
 // Forward pass: h[l+1] = relu(h[l] W_l^T + b_l), mask[l]; prob = softmax(z); ce[b] = -log prob[b][y_b].
 // h[0] (the padded input batch) must be filled by the caller; h[1..], mask[], prob and ce are written.
@@ -2020,7 +2068,7 @@ int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* la
   for (int l = 0; l < L; ++l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* b = static_cast<const float*>(bias[l]);
-    if (l == L - 1) {
+    if (l == L - 1 && narrow_head(m)) {
       launch_head_forward(st, Bp, nullptr, m->h[l], m->W[l] /* unused: no Rh */, m->W[l], b, nullptr, nullptr,
                           const_cast<float*>(m->prob), K, N, B, HEAD_LOGITS, labels, ce, nullptr, nullptr, nullptr);
       break;
@@ -2033,6 +2081,11 @@ int bhg_mlp_forward(const bhg_mlp* m, const void* const* bias, const int64_t* la
     a.splits = pick_splits((N + tn - 1) / tn, K, 1);
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
     launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    if (l == L - 1) {   // a wide output layer: logits = product + bias into prob, then the row kernel turns them into softmax / CE
+      launch_reduce_mask(st, m->partial, a.splits, Bp * N, b, nullptr, const_cast<float*>(m->prob), Bp, N, B);
+      hipLaunchKernelGGL(k_softmax_ce_rows, dim3(Bp), dim3(kThreads), 0, st, const_cast<float*>(m->prob), labels, ce, N, B);
+      break;
+    }
     launch_reduce_mask(st, m->partial, a.splits, Bp * N, b, nullptr, const_cast<float*>(m->h[l + 1]), Bp, N, B,
                        const_cast<float*>(m->mask[l]));
   }
@@ -2052,7 +2105,7 @@ int bhg_mlp_backward(const bhg_mlp* m, const int64_t* labels, void* stream) {
                      const_cast<float*>(m->delta[L - 1]), Bp, C, B);
   for (int l = L - 1; l >= 1; --l) {
     const int K = m->dims[l + 1], N = m->dims[l];
-    if (l == L - 1) {
+    if (l == L - 1 && narrow_head(m)) {
       const int blocks = (Bp * (N / 4) + 255) / 256;
       hipLaunchKernelGGL(k_head_backward, dim3(blocks), dim3(256), 0, st, (const float*)nullptr, m->delta[l], m->W[l],
                          (const float*)nullptr, m->mask[l - 1], const_cast<float*>(m->delta[l - 1]), N, K, B, Bp);
@@ -2089,6 +2142,7 @@ int bhg_mlp_supports_packed_prepare(const bhg_mlp* m) {
 int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* fws, size_t fws_bytes,
                            void* stream) {
   if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
   BHG_REQUIRE(bias && labels && ce && fws, "NULL argument");
   BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
@@ -2131,6 +2185,7 @@ int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int6
 
 int bhg_mlp_backward_packed(const bhg_mlp* m, const int64_t* labels, void* fws, size_t fws_bytes, void* stream) {
   if (int rc = check_head_problem(m)) return rc;
+  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
   BHG_REQUIRE(labels && fws, "NULL argument");
   BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
@@ -2192,7 +2247,7 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
     const int K = m->dims[l], N = m->dims[l + 1];
     const float* V = static_cast<const float*>(dir[2 * l]);
     const float* c = static_cast<const float*>(dir[2 * l + 1]);
-    if (l == L - 1) {
+    if (l == L - 1 && narrow_head(m)) {
       launch_head_forward(st, Bp, l > 0 ? (const float*)m->Rh[l - 1] : nullptr, m->h[l], m->W[l], V, c, m->prob, nullptr,
                           nullptr, K, N, B, HEAD_COEFF, labels, coeff, nullptr, nullptr, nullptr);
       break;
@@ -2206,6 +2261,11 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
     a.splits = pick_splits((N + tn - 1) / tn, K, a.pairs);
     a.out = m->partial; a.ldo = N; a.out_rows = Bp;
     launch_gemm<LAYOUT_KC, LAYOUT_KC>(a, tn, st);
+    if (l == L - 1) {   // a wide output layer: Rz into Rd_L's buffer (free here), then the row kernel
+      launch_reduce_mask(st, m->partial, a.splits, Bp * N, c, nullptr, m->Rd[l], Bp, N, B);
+      hipLaunchKernelGGL(k_coeff_rows, dim3(Bp), dim3(kThreads), 0, st, m->prob, (const float*)m->Rd[l], labels, coeff, N, B);
+      break;
+    }
     launch_reduce_mask(st, m->partial, a.splits, Bp * N, c, m->mask[l], m->Rh[l], Bp, N, B);
   }
   BHG_HIP_CHECK(hipGetLastError());

@@ -160,6 +160,8 @@ def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = Non
     G, g = dist.get_world_size(group), dist.get_rank(group)
 
     provider = structured_hvp_for(curr, prev)
+    if provider is not None:
+        provider.pad_widths = False   # the ranks exchange the real network's N-sized state between phases: no padded twin here
     if provider is None:
         in_grad = inner_gradient(curr)
         hvp_fn = AutogradHVP(in_grad, curr.parameters())

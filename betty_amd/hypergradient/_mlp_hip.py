@@ -9,8 +9,10 @@ Per hypergradient step:
   5. ``bhg_mlp_mixed_coeff`` one R-forward for the mixed second derivative, then a backward through
      ``s``'s graph                                                                    (native + PyTorch)
 All [Bp = 128, d] activation buffers are allocated once per (shapes, device) and reused across steps.
-Networks whose last layer is wider than 32 outputs fall back to ATen for steps 1, 3 and 5 only (the
-K HVPs — the hot part — always run on the HIP kernels).
+A classifier head wider than 32 outputs runs steps 1, 3 and 5 natively as well since round 6 (the output layer as one more split-K
+product + a row kernel: k_softmax_ce_rows / k_coeff_rows in csrc/bhg_mlp.hip); it has no fused solver (the K loop is K x (HVP kernels +
+recurrence kernel)).  Networks whose input / hidden widths are not multiples of 32 run on a zero-padded twin (PaddedHipMLPState below).
+There is no ATen arithmetic in this file.
 """
 from __future__ import annotations
 
@@ -18,7 +20,6 @@ import ctypes
 import weakref
 
 import torch
-import torch.nn.functional as F
 
 from .. import _native
 
@@ -152,7 +153,7 @@ class HipMLPState:
                           "bhg_mlp_forward")
             ce = buf.ce[:B]
         else:
-            ce = self._aten_forward(Ws, bs, y)
+            raise _native.NativeLibraryError("bhg_mlp_supports_native_prepare refused this network (layer count / batch padding): there is no ATen path")
         # sample weights: the declared closed form of the meta-weight-net (one launch, writes s / B where bhg_mlp_backward reads it),
         # else the upper problem's module through autograd (keeps the graph to prev's parameters)
         self.native_upper, self.sample_weight = False, None
@@ -173,10 +174,8 @@ class HipMLPState:
             _native.check(lib.bhg_mlp_backward_packed(ctypes.byref(d), buf.labels.data_ptr(), buf.fws.data_ptr(), buf.fws.numel(), _stream()),
                           "bhg_mlp_backward_packed")
             d.prepacked = 1   # the solves of this step find h_l, delta_l and the chain's weights packed
-        elif buf.native_prepare:
-            _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
         else:
-            self._aten_backward(Ws, y)
+            _native.check(lib.bhg_mlp_backward(ctypes.byref(d), buf.labels.data_ptr(), _stream()), "bhg_mlp_backward")
         # HVP outputs are consumed by the recurrence kernel on the same stream before the next HVP is
         # launched, so ONE set of output tensors serves all K iterations — and all steps (no allocator
         # traffic per step, stable addresses for the recurrence kernel's pointer-table cache).
@@ -210,31 +209,6 @@ class HipMLPState:
                                       ts[3].data_ptr(), H, float(scale), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
                                       g[3].data_ptr(), _stream()), "bhg_mwn_backward")
         return (views, flat) if with_flat else views
-
-    # ---- ATen path of the once-per-step passes for wide output layers ------------------------------------------
-    def _aten_forward(self, Ws, bs, y):
-        buf, B, L = self.buf, self.B, self.L
-        h = buf.h[0][:B]
-        for l in range(L):
-            a = torch.addmm(bs[l], h, Ws[l].t())
-            if l + 1 < L:
-                m = (a > 0).to(torch.float32)
-                h = a * m
-                buf.mask[l][:B].copy_(m)
-                buf.h[l + 1][:B].copy_(h)
-            else:
-                logp = F.log_softmax(a, dim=1)
-        buf.prob[:B].copy_(logp.exp())
-        return -logp.gather(1, y.reshape(-1, 1)).reshape(-1)
-
-    def _aten_backward(self, Ws, y):
-        buf, B, L = self.buf, self.B, self.L
-        err = buf.prob[:B] - F.one_hot(y.reshape(-1), buf.prob.shape[1]).to(torch.float32)
-        delta = buf.sd[:B, None] * err
-        buf.delta[L - 1][:B].copy_(delta)
-        for l in range(L - 1, 0, -1):
-            delta = buf.mask[l - 1][:B] * (delta @ Ws[l])
-            buf.delta[l - 1][:B].copy_(delta)
 
     # ---- per iteration -----------------------------------------------------------------------------------------------
     @staticmethod
@@ -388,20 +362,196 @@ class HipMLPState:
                 )
                 return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
             # a materialised Neumann accumulator: read it like any direction (below)
-        if buf.native_prepare:
-            tab, _keep = self._dir_table(dir_views)
-            _native.check(
-                self.lib.bhg_mlp_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(), _stream()),
-                "bhg_mlp_mixed_coeff",
-            )
-            return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
-        Vs, cs = dir_views[0::2], dir_views[1::2]
-        Rh = None
-        for l in range(self.L):
-            Ra = torch.addmm(cs[l], buf.h[l][:B], Vs[l].t())
-            if Rh is not None:
-                Ra = Ra + Rh @ self.Ws[l].t()
-            if l + 1 < self.L:
-                Rh = buf.mask[l][:B] * Ra
-        err = buf.prob[:B] - F.one_hot(buf.labels[:B], buf.prob.shape[1]).to(torch.float32)
-        return (err * Ra).sum(1) / B
+        tab, _keep = self._dir_table(dir_views)
+        _native.check(
+            self.lib.bhg_mlp_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(), _stream()),
+            "bhg_mlp_mixed_coeff",
+        )
+        return buf.coeff[:B] if self.native_upper else buf.coeff[:B].clone()   # (closed-form upper VJP: consumed on this stream at once)
+
+
+# ---- networks whose widths are not multiples of 32: the zero-padded twin (round 6) ---------------------------------------------------
+# The reference's cg / neumann are shape-agnostic (betty/hypergradient/cg.py:8-70); the fused solvers' chain works on 32-wide tiles
+# (csrc/bhg_mlp.hip: hoist_plan).  A network like 784-512-250-100-10 therefore gets a TWIN with its input and hidden widths rounded up to
+# multiples of 32, zero-filled: a padded unit has zero weights and a zero bias, so its pre-activation is exactly 0, its ReLU mask 0, its
+# activation, delta, Rh, Rd 0 — every inner product of the solve sees extra zeros and nothing else, and the twin's Hessian-vector
+# products, step lengths and hypergradient are the network's own.  The twin's weights are refreshed from the real ones every step (one
+# strided device copy per tensor, bhg_copy2d), right-hand sides are padded on the way in and results un-padded on the way out; the
+# kernels never learn about it.
+PAD_WIDTHS_TO_32 = True     # False: such networks keep the classic chain (the A/B arm of the tests)
+_TWINS = weakref.WeakKeyDictionary()   # first nn.Linear of a network -> {(padded dims, device): _Twin}
+
+
+def _pad32(n: int) -> int:
+    return (int(n) + 31) // 32 * 32
+
+
+def padded_dims(dims):
+    """Input and hidden widths rounded up to 32; the class count stays (the head kernels take any count up to their own limit)."""
+    return tuple(_pad32(d) for d in dims[:-1]) + (int(dims[-1]),)
+
+
+class _TwinLayer:
+    """What HipMLPState reads of an nn.Linear (weight, bias), on zero-padded storage; weak-referenceable (buffer maps are keyed by it)."""
+
+    __slots__ = ("weight", "bias", "__weakref__")
+
+    def __init__(self, out_f, in_f, device):
+        self.weight = torch.zeros(out_f, in_f, dtype=torch.float32, device=device)
+        self.bias = torch.zeros(out_f, dtype=torch.float32, device=device)
+
+
+class _Twin:
+    def __init__(self, dims, pdims, device):
+        self.layers = [_TwinLayer(pdims[l + 1], pdims[l], device) for l in range(len(dims) - 1)]
+        self.x = None            # [B, pdims[0]] zero-padded input batch
+        self.dirs = [t for lay in self.layers for t in (torch.zeros_like(lay.weight), torch.zeros_like(lay.bias))]   # padded directions
+        self.rhs = [torch.zeros_like(t) for t in self.dirs]                                                         # padded right-hand side
+
+
+def _copy2d(lib, dst, ldd, src, lds, rows, cols):
+    _native.check(lib.bhg_copy2d(dst.data_ptr(), int(ldd), src.data_ptr(), int(lds), int(rows), int(cols), _stream()), "bhg_copy2d")
+
+
+class _TwinSpec:
+    """The slice of WeightedCEMLP that HipMLPState reads, with the twin's layers in place of the real ones."""
+
+    def __init__(self, spec, twin):
+        self._spec, self.layers = spec, twin.layers
+
+    def __getattr__(self, name):
+        return getattr(self._spec, name)
+
+
+class PaddedHipMLPState:
+    """HipMLPState's interface for a network whose widths are not multiples of 32, served by a HipMLPState on its zero-padded twin."""
+
+    solution_free = True
+
+    def __init__(self, spec, x, y):
+        if not x.is_cuda:
+            raise _native.NativeLibraryError("WeightedCEMLP(impl='hip') needs CUDA/HIP tensors; there is no CPU fallback")
+        self.lib = lib = _native.load()
+        self.spec = spec
+        real = [lin for lin in spec.layers]
+        self.real_Ws = [lin.weight.detach() for lin in real]
+        self.real_bs = [lin.bias.detach() for lin in real]
+        for t in self.real_Ws + self.real_bs:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("weights and biases must be contiguous fp32 tensors")
+        dims = tuple([self.real_Ws[0].shape[1]] + [W.shape[0] for W in self.real_Ws])
+        self.dims, self.pdims = dims, padded_dims(dims)
+        self.shapes = [s for W in self.real_Ws for s in ((W.shape[0], W.shape[1]), (1, W.shape[0]))]        # (rows, cols) per real tensor
+        self.pcols = [c for l in range(len(dims) - 1) for c in (self.pdims[l], self.pdims[l + 1])]         # leading dimension of its twin
+        owner = _TWINS.setdefault(spec.layers[0], {})
+        key = (self.pdims, str(x.device))
+        twin = owner.get(key)
+        if twin is None:
+            twin = owner[key] = _Twin(dims, self.pdims, x.device)
+        self.twin = twin
+        # refresh the twin from the real weights (the padding stays zero: only the real block is ever written)
+        for l, (W, b) in enumerate(zip(self.real_Ws, self.real_bs)):
+            _copy2d(lib, twin.layers[l].weight, self.pdims[l], W, dims[l], W.shape[0], W.shape[1])
+            _copy2d(lib, twin.layers[l].bias, self.pdims[l + 1], b, dims[l + 1], 1, b.shape[0])
+        B = x.shape[0]
+        xs = x.detach().reshape(B, -1)
+        xs = xs if (xs.dtype == torch.float32 and xs.is_contiguous()) else xs.to(torch.float32).contiguous()
+        if twin.x is None or twin.x.shape[0] != B:
+            twin.x = torch.zeros(B, self.pdims[0], dtype=torch.float32, device=x.device)
+        _copy2d(lib, twin.x, self.pdims[0], xs, dims[0], B, dims[0])
+        self.inner = HipMLPState(_TwinSpec(spec, twin), twin.x, y)
+        self.B = B
+        self.out = None
+
+    # what structured.py reads off the state
+    @property
+    def native_upper(self):
+        return self.inner.native_upper
+
+    @property
+    def sample_weight(self):
+        return self.inner.sample_weight
+
+    def upper_vjp(self, *a, **k):
+        return self.inner.upper_vjp(*a, **k)
+
+    # ---- padding / un-padding of tensor lists shaped like the REAL parameters ------------------------------------------------------
+    def _pad(self, tensors, into):
+        for t, dst, (rows, cols), ldd in zip(tensors, into, self.shapes, self.pcols):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                t = t.detach().to(torch.float32).contiguous()
+            _copy2d(self.lib, dst, ldd, t, cols, rows, cols)
+        return into
+
+    def _unpad(self, padded, into):
+        for src, t, (rows, cols), lds in zip(padded, into, self.shapes, self.pcols):
+            _copy2d(self.lib, t, cols, src, lds, rows, cols)
+        return into
+
+    def _real_views(self, layout, flat):
+        like = [t for W, b in zip(self.real_Ws, self.real_bs) for t in (W, b)]
+        return layout.views(flat, like)
+
+    def _twin_layout(self):
+        from ..backend import get_backend  # noqa: PLC0415
+
+        return get_backend().layout(self.twin.dirs)
+
+    # ---- per iteration (un-fused arm, the structure guard) ---------------------------------------------------------------------------
+    def hvp(self, direction_views):
+        out_p = self.inner.hvp(self._pad(direction_views, self.twin.dirs))
+        if self.out is None:
+            self.out = [torch.empty_like(t) for W, b in zip(self.real_Ws, self.real_bs) for t in (W, b)]
+        return self._unpad(out_p, self.out)
+
+    # ---- fused solvers -----------------------------------------------------------------------------------------------------------------
+    def fused_supported(self, layout) -> bool:
+        want = [n for W in self.real_Ws for n in (W.numel(), W.shape[0])]
+        return (tuple(want) == tuple(layout.numels) and str(layout.device) == str(self.real_Ws[0].device)
+                and self.inner.fused_supported(self._twin_layout()))
+
+    def cg_solve(self, layout, x, r, p, K: int, cg_alpha: float, shift: float, keep_x: bool = True, rhs=None) -> FusedSolve:
+        """The caller's r holds the right-hand side (cg_init: r = p = vector); the solve runs on the twin's own flat state."""
+        from ..backend import get_backend  # noqa: PLC0415
+
+        be, play = get_backend(), self._twin_layout()
+        self._pad(self._real_views(layout, r), self.twin.rhs)
+        px, pr, pp = play.state(3)
+        skip_x = not keep_x
+        mask = self.inner.cg_state_mask() if skip_x else None
+        ts = be.cg_init(play, self.twin.rhs, None if skip_x else px, pr, pp, keep_mask=mask) if mask is not None else \
+            be.cg_init(play, self.twin.rhs, None if skip_x else px, pr, pp)
+        token = self.inner.cg_solve(play, px, pr, pp, K, cg_alpha, shift, keep_x=keep_x, rhs=ts if mask is not None else None)
+        if keep_x:
+            self._unpad(play.views(px, self.twin.dirs), self._real_views(layout, x))
+        return token
+
+    def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> FusedSolve:
+        """The caller's v0 holds the right-hand side (neumann_init: v = vector, p = vector)."""
+        from ..backend import get_backend  # noqa: PLC0415
+
+        be, play = get_backend(), self._twin_layout()
+        self._pad(self._real_views(layout, v0), self.twin.rhs)
+        pv0, pv1, pp = play.state(3)
+        be.neumann_init(play, self.twin.rhs, pv0, pp if keep_p else None)
+        token = self.inner.neumann_solve(play, pv0, pv1, pp, K, alpha, shift, keep_p=keep_p)
+        if keep_p:
+            self._unpad(play.views(pp, self.twin.dirs), self._real_views(layout, p))
+        return token
+
+    def mixed_coeff(self, dir_views, solve: FusedSolve = None):
+        if solve is not None:
+            return self.inner.mixed_coeff(None, solve)
+        return self.inner.mixed_coeff(self._pad(dir_views, self.twin.dirs))
+
+
+def make_state(spec, x, y):
+    """HipMLPState, or PaddedHipMLPState when an input / hidden width is not a multiple of 32 and the padded twin takes the fused form.
+    ``spec.pad_widths = False`` (set by the global-batch mode, whose ranks exchange the N-sized state of the REAL network between the
+    phases of an iteration) keeps the network as it is."""
+    Ws = [lin.weight for lin in spec.layers]
+    dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
+    # (L >= 3 and a narrow head: the conditions under which the twin takes the fused form at all — bhg_mlp_supports_fused_solve)
+    if (PAD_WIDTHS_TO_32 and getattr(spec, "pad_widths", True) and len(Ws) >= 3 and dims[-1] <= 32 and padded_dims(dims) != dims and x.is_cuda):
+        return PaddedHipMLPState(spec, x, y)
+    return HipMLPState(spec, x, y)

@@ -273,9 +273,9 @@ class WeightedCEMLP:
         x, y = self.batch if self.batch is not None else self.curr.cur_batch
         impl = self.impl or "hip"  # the product path; it raises on CPU tensors (no CPU fallback)
         if impl == "hip":
-            from ._mlp_hip import HipMLPState  # noqa: PLC0415
+            from ._mlp_hip import make_state  # noqa: PLC0415
 
-            self._state = HipMLPState(self, x, y)
+            self._state = make_state(self, x, y)   # (a zero-padded twin for widths that are not multiples of 32)
         elif impl == "torch":
             self._state = _TorchMLPState(self, x, y)
         else:

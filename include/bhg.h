@@ -404,6 +404,15 @@ int bhg_mwn_forward(const float* ce, int B, const float* w1, const float* b1, co
 int bhg_mwn_backward(const float* ce, const float* coeff, int B, const float* w1, const float* b1, const float* w2, const float* b2,
                      int H, float scale, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
 
+/* ---- networks whose widths are not multiples of 32 (round 6) ------------------------------------------------------------------------
+ * The fused solvers' chain works on 32-wide tiles (bhg_mlp_supports_fused_solve).  The reference's cg / neumann are shape-agnostic
+ * (betty/hypergradient/cg.py:8-70), so the host side (betty_amd/hypergradient/_mlp_hip.py: PaddedHipMLPState) keeps a ZERO-PADDED TWIN
+ * of such a network — input and hidden widths rounded up to 32; a padded unit has zero weights and bias, so its pre-activation is
+ * exactly 0, its ReLU mask 0, and every quantity of the solve is unchanged — and runs the same kernels on it.  This entry point is the
+ * strided block copy that maintains the twin and un-pads results: dst[r * ldd + c] = src[r * lds + c], r < rows, c < cols (fp32 device
+ * pointers, leading dimensions in elements; asynchronous on `stream`).                                                              */
+int bhg_copy2d(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int64_t cols, void* stream);
+
 /* ---- batch normalisation inside an opaque Hessian-vector product (round 6; csrc/bhg_bn.hip) -------------------------------------------
  * The reference takes H p as the double backward torch.autograd.grad(in_grad, params, grad_outputs=p) (betty/hypergradient/cg.py:39-41,
  * neumann.py:62).  For an inner network with training-mode batch norm (BASELINE cfg 3: examples/implicit_maml/models.py:278-483) ATen

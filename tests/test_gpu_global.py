@@ -101,6 +101,7 @@ def _emulate(parts, prev, vecs, K, alpha, keep):
         lay = FlatLayout([t.numel() for t in vec], vec[0].device)     # NOT the cached layout: every "rank" owns its state
         lays.append(lay)
         prov = curr.hypergradient_structure(prev)
+        prov.pad_widths = False   # as cg_global does: the protocol exchanges the real network's state
         prov.prepare()
         assert prov.fused_cg_global_ready(lay, K)
         provs.append(prov)

@@ -851,13 +851,14 @@ def test_opaque_solve_with_persistent_graphs(algo, K, be):
         assert rel <= 2e-5, (step, rel)
 
 
-def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
-    """A classifier head wider than 32 outputs: the once-per-step passes (forward, deltas, mixed coefficient) run on ATen, the
-    K HVPs on the MFMA kernels (no fused solver: bhg_mlp_supports_fused_solve is false) — against the opaque autograd
-    path on the same inputs, CG and Neumann."""
+@pytest.mark.parametrize("dims,B", [([192, 256, 128, 48], 72), ([784, 300, 100], 100), ([64, 96, 1000], 130)], ids=lambda v: str(v))
+def test_wide_head_runs_natively_and_matches_autograd(dims, B, be):
+    """A classifier head wider than 32 outputs (48, 100, 1000 classes; ragged widths; more than one 128-row batch tile): since round 6
+    the once-per-step passes (forward + softmax / CE, deltas, mixed coefficient) are native too — the output layer as one more split-K
+    product + k_softmax_ce_rows / k_coeff_rows; rounds 1-5 ran them on ATen — and the K HVPs on the MFMA kernels as before (no fused
+    solver: bhg_mlp_supports_fused_solve is false) — against the opaque autograd path on the same inputs, CG and Neumann."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
-    dims, B = [192, 256, 128, 48], 72
     for algo, K in (("cg", 4), ("neumann", 4)):
         outs = {}
         for arm in ("hip", "autograd"):
@@ -870,9 +871,9 @@ def test_wide_head_takes_the_aten_prepare_and_still_matches_autograd(be):
             outs[arm] = _np(hg.jvp_fn_mapping[algo]([0.1 * d for d in direction], curr, prev, False))
             if arm == "hip":
                 st = prov._state
-                assert not st.buf.native_prepare and not st.fused_supported(be.layout(direction))
+                assert st.buf.native_prepare and not st.fused_supported(be.layout(direction))
         rel, _ = rel_err(outs["hip"], outs["autograd"])
-        print(f"wide head {dims} {algo}: analytic (ATen prepare + MFMA HVPs) vs autograd {rel:.2e}")
+        print(f"wide head {dims} B={B} {algo}: analytic (native prepare + MFMA HVPs) vs autograd {rel:.2e}")
         assert rel <= 1e-4, (algo, rel)
 
 
@@ -1580,50 +1581,30 @@ def test_cfg3_resnet12_cg20(variant, be, resnet12_checker):
     assert not be.cg_barrier_timed_out(be.layout(vector))
 
 
-def test_cfg3_resnet12_with_declared_batchnorm_layers_against_the_float64_truth(be):
-    """Round 6: the cfg-3 network with its 40 batch-norm layers DECLARED (betty_amd.nn.fuse_batchnorm_): their share of every
-    Hessian-vector product is bhg_bn_backward_vjp (two launches per layer) instead of ATen's ~340-launch decomposition of batch norm's
-    double backward.  What can be asserted: ONE fp32 Hessian-vector product of this instance — whoever forms it — sits ~7e-3 from the
-    same product in float64 (forty layers of batch statistics: the terms of batch norm's second derivative cancel), so two correct fp32
-    products differ by that much and rtol 1e-4 between them is undecidable (measured: undeclared 7.8e-3, declared 7.2e-3 from float64,
-    7.8e-3 from each other; profiles/r06_cfg3_declared_batchnorm_vs_float64.txt).  Held here, against the float64 run of the reference's
-    algorithm on this GPU: the declared product is no further from the truth than 1.5x ATen's own, and the CG solve (K = 5, where the
-    float64 run takes ~25 s) no further than 3x the reference's fp32 solve (floor 1e-4) — the rule of the metric workload's goldens."""
-    import hypergrad_oracle as horc
-
+def test_cfg3_resnet12_cg20_with_declared_batchnorm_layers(be, resnet12_checker):
+    """Round 6: the same solve with the inner network's 40 batch-norm layers DECLARED (betty_amd.nn.fuse_batchnorm_): their share of every
+    Hessian-vector product is bhg_bn_backward_vjp (two launches per layer, fp64 arithmetic inside) instead of ATen's ~340-launch
+    decomposition of batch norm's double backward.  Same checker (the reference's algorithm on plain nn.BatchNorm2d), same tolerance as
+    the undeclared variants above; the counters prove the fused node ran once per layer and product.  (Measured: one product 2.1e-6 from
+    ATen's, the K = 20 solve 5.3e-6 from the checker — profiles/r06_cfg3_declared_batchnorm_vs_float64.txt, which also shows that BOTH
+    fp32 products sit 7.8e-3 from the float64 one: the instance's own fp32 floor, shared by every implementation.)"""
     from betty_amd import nn as bnn
 
-    K = 5
-    cfg = dict(type="cg", cg_iterations=K, cg_alpha=1.0)
-
-    def hvp(curr, vector):
-        params = list(curr.module.parameters())
-        grads = torch.autograd.grad(curr.training_step_exec(curr.cur_batch), params, create_graph=True)
-        return _np(torch.autograd.grad(grads, params, grad_outputs=vector))
-
+    want, noise = resnet12_checker
+    K = 20
+    curr, prev, vector = _resnet12_case(dict(type="cg", cg_iterations=K, cg_alpha=1.0))
+    n_bn = bnn.fuse_batchnorm_(curr.module)
+    assert n_bn == 40 == sum(isinstance(m, torch.nn.BatchNorm2d) for m in curr.module.modules())
+    c0 = bnn.fused_batchnorm_calls()
     with _deterministic_convolutions():
-        curr64, prev64, vec64 = _resnet12_case(cfg, dtype=torch.float64)
-        hv64 = hvp(curr64, vec64)
-        truth = _np(horc.cg(vec64, curr64, prev64, False))
-        del curr64, prev64, vec64
-        curr, prev, vector = _resnet12_case(cfg)
-        hv_plain = hvp(curr, vector)
-        ref32 = _np(horc.cg(vector, curr, prev, False))
-        curr, prev, vector = _resnet12_case(cfg)
-        n_bn = bnn.fuse_batchnorm_(curr.module)
-        assert n_bn == 40 == sum(isinstance(m, torch.nn.BatchNorm2d) for m in curr.module.modules())
-        hv_decl = hvp(curr, vector)
-        c0 = bnn.fused_batchnorm_calls()
-        got = _np(hg.jvp_fn_mapping["cg"](vector, curr, prev, False))
-        calls = {k: v - c0[k] for k, v in bnn.fused_batchnorm_calls().items()}
-    # K products + the mixed second derivative, each through every declared layer once
-    assert calls["forward"] == n_bn and calls["backward_vjp"] == (K + 1) * n_bn, (calls, n_bn)
-    e_hv_plain, e_hv_decl = rel_err(hv_plain, hv64)[0], rel_err(hv_decl, hv64)[0]
-    e_ref, e_got = rel_err(ref32, truth)[0], rel_err(got, truth)[0]
-    print(f"resnet12 [declared batch norm, {n_bn} layers]: one H v vs float64: ATen's double backward {e_hv_plain:.2e}, declared {e_hv_decl:.2e}; "
-          f"cg K={K} vs float64: reference algorithm fp32 {e_ref:.2e}, declared product {e_got:.2e}")
-    assert e_hv_decl <= 1.5 * e_hv_plain + 1e-5, (e_hv_decl, e_hv_plain)
-    assert e_got <= max(1e-4, 3.0 * e_ref), (e_got, e_ref)
+        got = hg.jvp_fn_mapping["cg"](vector, curr, prev, False)
+    calls = {k: v - c0[k] for k, v in bnn.fused_batchnorm_calls().items()}
+    # K products through every declared layer (the mixed second derivative of this loss — a proximal term — does not pass through them)
+    assert calls["forward"] == n_bn and calls["backward_vjp"] == K * n_bn, (calls, n_bn)
+    rel, mx = rel_err(_np(got), want)
+    tol = max(1e-4, 20 * noise)
+    print(f"resnet12 cg20 [declared batch norm, {n_bn} layers]: rel={rel:.2e} max/max={mx:.2e} checker-noise={noise:.2e}")
+    assert rel <= tol and mx <= 10 * tol, (rel, mx, noise)
 
 
 @pytest.mark.parametrize("radius", [0.01, 1.0])   # 0.01 = Config's default darts_alpha; 1.0 = well above fp32 resolution
@@ -1775,7 +1756,7 @@ def test_cfg5_reference_network_16_10_8_neumann20_batch64(be):
     ATen's double backward of a grouped convolution loops over the groups on the host — 18.4 s per product on the MI355X box against
     1.9 s per pass, profiles/r05_cfg5_hvp_conv_modes.txt; round 4 ran this test in 12.5 minutes and kept it opt-in for that reason).
     Tolerance: north_star's rtol 1e-4, or 5x the reference's OWN fp32-vs-fp64 distance on this instance where that is larger (the
-    rule of the darts / sama goldens).  One product is also formed both ways on the GPU: the two methods agree."""
+    rule of the darts / sama goldens).  The K = 3 solve is also run by the reference's algorithm on this GPU: rtol 1e-4 holds there."""
     import time
 
     gold = np.load(_CFG5_GOLD)
@@ -1788,6 +1769,9 @@ def test_cfg5_reference_network_16_10_8_neumann20_batch64(be):
     K = zoo.CFG5_K
     want32, want64, spread = gold[f"neumann{K}/fp32"], gold[f"neumann{K}/fp64"], float(gold[f"neumann{K}/ref_spread"])
     curr.hypergradient_hvp = "forward_over_reverse"
+    # (929 train-mode batch-norm layers: the package says so once per problem — round 6 — and this network, all grouped convolutions, is
+    #  the case the method is for: acknowledged, and checked against the double backward's solve below)
+    curr.hypergradient_hvp_ack_batchnorm = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     got = hg.jvp_fn_mapping["neumann"](vector, curr, prev, False)
@@ -1801,32 +1785,37 @@ def test_cfg5_reference_network_16_10_8_neumann20_batch64(be):
           f"vs reference-CPU fp32 {rel32:.2e}, vs reference fp64 {rel64:.2e} (reference fp32 vs fp64 {spread:.2e}; tolerance {tol:.1e}); "
           f"product {t_got:.1f} s/step")
     assert rel32 <= tol, (rel32, rel64, spread)
-    # one Hessian-vector product both ways on this GPU: the reference's double backward and the forward-over-reverse pass
-    from betty_amd.hypergradient._common import AutogradHVP, ForwardOverReverseHVP, inner_gradient
+    # Round 6 — where north_star's rtol 1e-4 IS decidable for this network.  Not against the CPU output at a shorter
+    # horizon: the reference's own fp32-vs-fp64 distance on this instance does not shrink with K (K = 3: 1.25e-3, K = 20: 9.9e-4 —
+    # tests/golden/make_cfg5_golden.py 3; it is the fp32 forward / first gradient through eight cells of batch statistics, not the
+    # Neumann horizon), so the K = 3 golden is held to the same 5x-spread rule.  But against the reference's ALGORITHM on the same
+    # device (oracle restatement of neumann.py:29-66 with autograd's double backward, ~95 s for K = 3) the whole solve agrees to
+    # rounding: measured 4.5e-7 under MIOpen's deterministic solver filter (profiles/r06_cfg5_k3_product_vs_reference_algorithm_on_gpu.txt;
+    # K = 20 without the filter: 8.7e-5) — asserted at 1e-4, two orders of margin.
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
 
-    params = list(curr.trainable_parameters())
-    t0 = time.perf_counter()
-    fwd = ForwardOverReverseHVP(curr, prev)
-    hv_fwd = _np(fwd(vector))
-    torch.cuda.synchronize()
-    t_fwd = time.perf_counter() - t0
-    hv_fwd2 = _np(fwd(vector))
-    t0 = time.perf_counter()
-    dbl = AutogradHVP(inner_gradient(curr), params)
-    hv_dbl = _np(dbl(vector))
-    torch.cuda.synchronize()
-    t_dbl = time.perf_counter() - t0
-    hv_dbl2 = _np(dbl(vector))
-    rel, mx = rel_err(hv_fwd, hv_dbl)
-    # A gross check of method equivalence (a wrong tangent is O(1) off), not a precision claim — the K = 20 result above is what is held
-    # to the reference's CPU run, and scripts/cfg5_oracle_on_gpu.py compares the two methods over the whole solve (8.7e-5).  One product
-    # through ~1,400 convolution-backward calls: MIOpen picks its solvers per process and accumulates weight gradients with float
-    # atomics — observed 1.6e-5 and 1.09e-4 for the same inputs on two boxes; each method's own call-to-call noise is printed.
-    noise = max(rel_err(hv_fwd2, hv_fwd)[0], rel_err(hv_dbl2, hv_dbl)[0])
-    tol_hv = max(5e-4, 10.0 * noise)
-    print(f"cfg5 as named: one H v, forward-over-reverse ({t_fwd:.1f} s incl. loss + gradient) vs double backward ({t_dbl:.1f} s incl. "
-          f"gradient-with-graph): rel {rel:.2e} (run-to-run noise of either method {noise:.2e}, tolerance {tol_hv:.1e})")
-    assert rel <= tol_hv, (rel, mx, noise)
+    K3 = 3
+    assert f"neumann{K3}/fp32" in gold.files, "tests/golden/make_cfg5_golden.py 3 adds the short-horizon golden"
+    with _deterministic_convolutions():
+        curr3, prev3, vector3 = zoo.cfg5_as_named_case(Config, DEV, K=K3)
+        curr3.hypergradient_hvp, curr3.hypergradient_hvp_ack_batchnorm = "forward_over_reverse", True
+        t0 = time.perf_counter()
+        got3 = np.concatenate([g.ravel() for g in _np(hg.jvp_fn_mapping["neumann"](vector3, curr3, prev3, False))])
+        torch.cuda.synchronize()
+        t_p3 = time.perf_counter() - t0
+        curr3r, prev3r, vector3r = zoo.cfg5_as_named_case(Config, DEV, K=K3)
+        t0 = time.perf_counter()
+        ref3 = np.concatenate([g.ravel() for g in _np(horc.neumann(vector3r, curr3r, prev3r, False))])
+        torch.cuda.synchronize()
+        t_r3 = time.perf_counter() - t0
+    spread3 = float(gold[f"neumann{K3}/ref_spread"])
+    rel3_cpu = float(np.linalg.norm(got3 - gold[f"neumann{K3}/fp32"]) / np.linalg.norm(gold[f"neumann{K3}/fp32"]))
+    rel3_gpu = float(np.linalg.norm(got3.astype(np.float64) - ref3) / np.linalg.norm(ref3))
+    print(f"cfg5 as named, neumann K={K3}: product vs the reference's algorithm on this GPU {rel3_gpu:.2e} (product {t_p3:.1f} s, reference "
+          f"algorithm {t_r3:.1f} s: x{t_r3 / t_p3:.1f}); vs reference-CPU fp32 {rel3_cpu:.2e} (reference fp32 vs fp64 at this K: {spread3:.2e})")
+    assert rel3_gpu <= 1e-4, rel3_gpu
+    assert rel3_cpu <= max(1e-4, 5.0 * spread3), (rel3_cpu, spread3)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1874,6 +1863,56 @@ def test_cfg2_metric_workload_end_to_end(algo, K, ridge, be):
         # answer keeps the loose bound — 1.85e-2 is the reference's CPU fp32-vs-fp64 distance on this seed (cfg2_full.npz)
         bound = max(1e-4, 3.0 * max(e_ref, 1.85e-2))
         assert e_got <= 1e-4 and rel <= bound + e_ref, (algo, ridge, e_got, rel, e_ref)
+
+
+@pytest.mark.parametrize("algo", ["cg", "neumann"])
+@pytest.mark.parametrize("keep", [False, True], ids=["solution-free", "x-materialised"])
+@pytest.mark.parametrize("dims,B,K", [([784, 512, 256, 128, 10], 100, 5), ([100, 70, 50, 10], 64, 4), ([784, 500, 250, 100, 10], 128, 6),
+                                      ([33, 65, 31, 17, 9, 5], 40, 3)], ids=lambda v: str(v))
+def test_widths_that_are_not_multiples_of_32_take_the_fused_projected_form(algo, keep, dims, B, K, be):
+    """the reference's cg / neumann are shape-agnostic (cg.py:8-70); round 5's fast form asked for every width % 32 == 0
+    (a 784-wide input fell to the classic chain).  Round 6: such a network runs on its ZERO-PADDED TWIN (betty_amd/hypergradient/
+    _mlp_hip.py: PaddedHipMLPState) — same kernels, the launch counters prove the form: one hoisted N-sized pass, K - 1 (cg) / K
+    (neumann) projected iterations and, for nets of >= 4 layers, k_wskpl once per cg iteration (the six-launch form).  Product library.
+    Against (a) the same network with the twin switched off (classic chain on the ragged shapes), (b) the un-fused loop, (c) the
+    reference's algorithm on this GPU (oracle restatement: opaque double backward), ridge 0.5 so that rtol 1e-4 has resolving power."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hypergrad_oracle as horc
+
+    from betty_amd.hypergradient import _mlp_hip
+
+    assert not _native.is_ab()
+    lib = _native.load()
+    ridge, seed = 0.5, sum(dims) + B
+    assert _mlp_hip.PAD_WIDTHS_TO_32 and _mlp_hip.padded_dims(dims) != tuple(dims)
+    h0, p0, l0 = lib.bhg_mlp_hoist_launches(), lib.bhg_mlp_proj_iterations(), lib.bhg_mlp_lin_launches()
+    got, st = _run_solver(algo, dims, B, ridge, K, seed, True, keep=keep)
+    dh, dp, dl = lib.bhg_mlp_hoist_launches() - h0, lib.bhg_mlp_proj_iterations() - p0, lib.bhg_mlp_lin_launches() - l0
+    if not keep:
+        assert (dh, dp) == (1, K - 1 if algo == "cg" else K), (dims, dh, dp)
+        assert dl == (K if (algo == "cg" and len(dims) - 1 >= 4) else 0), (dims, dl)
+    else:
+        assert dh >= 1 and dp > 0, (dims, dh, dp)   # projected level 1: the N-sized r / p (cg) or accumulator (neumann) are kept
+    again, _ = _run_solver(algo, dims, B, ridge, K, seed, True, keep=keep)
+    assert all(np.array_equal(u, v) for u, v in zip(again, got)), "bit-reproducible"
+    unf, st_u = _run_solver(algo, dims, B, ridge, K, seed, False)
+    _mlp_hip.PAD_WIDTHS_TO_32 = False
+    try:
+        h1 = lib.bhg_mlp_hoist_launches()
+        plain, st_p = _run_solver(algo, dims, B, ridge, K, seed, True, keep=keep)
+        assert lib.bhg_mlp_hoist_launches() == h1, "without the twin these shapes keep the classic chain"
+    finally:
+        _mlp_hip.PAD_WIDTHS_TO_32 = True
+    curr, prev, direction, _ = _mlp_problem(dims, B, ridge=ridge, seed=seed)
+    curr.config = Config(type="cg", cg_iterations=K, cg_alpha=1.0) if algo == "cg" else Config(type="neumann", neumann_iterations=K, neumann_alpha=0.05)
+    want = _np(getattr(horc, algo)([0.1 * d for d in direction], curr, prev, False))
+    e_unf, e_plain, e_ref = rel_err(got, unf)[0], rel_err(got, plain)[0], rel_err(got, want)[0]
+    print(f"{algo} {dims} B={B} K={K} keep={keep}: padded twin: hoist {dh} proj {dp} lin {dl}; vs un-fused {e_unf:.2e}, vs classic chain on the "
+          f"ragged shapes {e_plain:.2e}, vs the reference's algorithm on this GPU {e_ref:.2e}")
+    assert e_unf <= 5e-5 and e_plain <= 5e-5 and e_ref <= 1e-4, (e_unf, e_plain, e_ref)
+    if keep:   # the materialised solution (cg: x; neumann: the accumulator), un-padded into the caller's flat vector
+        a, b = st[0].astype(np.float64), st_p[0].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 5e-5 * np.linalg.norm(b)
 
 
 def test_structure_guard_on_the_hip_path(be):
