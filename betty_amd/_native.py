@@ -165,6 +165,7 @@ SYMBOLS = {
     "bhg_mlp_proj_iterations": (c_int64, []),
     "bhg_mlp_lin_launches": (c_int64, []),
     "bhg_mlp_neumann_mixed_coeff": (c_int, [POINTER(Mlp), _PP, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "bhg_mlp_plan_describe": (c_int, [POINTER(Mlp), c_int, c_int, ctypes.c_char_p, c_size_t]),
     "bhg_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "bhg_bn_ws_bytes": (c_size_t, [c_int]),
     "bhg_bn_backward_vjp": (
@@ -285,3 +286,23 @@ def ptr_array(ptrs):
     """Host array of device pointers (``const void* const*``)."""
     arr = (c_void_p * len(ptrs))(*ptrs)
     return ctypes.cast(arr, _PP), arr
+
+
+def plan_describe(dims, B: int, algo: str = "cg", keep_solution: bool = False) -> dict:
+    """The form the fused solvers take for an MLP of widths ``dims`` and a batch of ``B`` rows, as a dict (include/bhg.h:
+    bhg_mlp_plan_describe — host logic only: works on a box without a GPU).  ``dims`` are the widths the KERNELS see: a network with
+    widths that are not multiples of 32 runs on its zero-padded twin (hypergradient/_mlp_hip.py: padded_dims)."""
+    lib = load()
+    d = Mlp()
+    d.L, d.B, d.Bp = len(dims) - 1, int(B), (int(B) + 127) // 128 * 128
+    for i, v in enumerate(dims):
+        d.dims[i] = int(v)
+    buf = ctypes.create_string_buffer(2048)
+    check(lib.bhg_mlp_plan_describe(ctypes.byref(d), {"cg": 0, "neumann": 1}[algo], 1 if keep_solution else 0, buf, 2048), "bhg_mlp_plan_describe")
+    out, text = {}, buf.value.decode()
+    import re  # noqa: PLC0415
+
+    for key, quoted, plain in re.findall(r'(\w+)=(?:"([^"]*)"|(\S+))', text):
+        val = quoted if quoted else plain
+        out[key] = int(val) if re.fullmatch(r"-?\d+", val) else val
+    return out

@@ -22,6 +22,7 @@
 // helpers, the plan of the hoisted / projected forms (hoist_plan), the workspace carve-up, run_chain (one HVP chain with its
 // outputs stored or consumed), and the C entry points bhg_mlp_* of include/bhg.h.
 #include <stdlib.h>
+#include <vector>
 
 
 #include "bhg_common.hpp"
@@ -2269,6 +2270,62 @@ int bhg_mlp_mixed_coeff(const bhg_mlp* m, const void* const* dir, const int64_t*
     launch_reduce_mask(st, m->partial, a.splits, Bp * N, c, m->mask[l], m->Rh[l], Bp, N, B);
   }
   BHG_HIP_CHECK(hipGetLastError());
+  return BHG_OK;
+}
+
+// ---- the plan, described without running it (round 6; host only: no launch, no device access) -----------------------------------------
+// Which form bhg_mlp_cg_solve (algo 0) / bhg_mlp_neumann_solve (algo 1) takes for this descriptor is decided by host logic alone —
+// hoist_plan (shapes, cost model), cg_ctx_init (projection level, the linear first product, the head launch with the recurrences) —
+// before the first launch.  This entry point evaluates exactly that logic on the shapes and prints the decision, so that the map
+// "shape -> form" has a unit test of its own that runs on a CPU-only box (tests/test_plan_selection.py); the GPU suite ties the
+// description to the launch counters (bhg_mlp_hoist_launches / _proj_iterations / _lin_launches) on the same shapes.
+int bhg_mlp_plan_describe(const bhg_mlp* m, int algo, int keep_solution, char* buf, size_t buf_bytes) {
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(buf && buf_bytes >= 64, "output buffer too small");
+  BHG_REQUIRE(algo == 0 || algo == 1, "algo: 0 = cg, 1 = neumann");
+  const int L = m->L;
+  const bool fused = bhg_mlp_supports_fused_solve(m) != 0;
+  HoistPlan hp;
+  hoist_plan(m, &hp);
+  const char* form = "unfused";
+  int hoist = 0, proj_level = 0, lin = 0, lin_head = 0, upd_first = 0;
+  const char* closing = "k_outer_all";
+  if (fused) {
+    // the flat layout of [W_1, b_1, ...] (what the callers pass as `starts`), fake state pointers: nothing is dereferenced
+    int64_t numel[2 * BHG_MLP_MAX_LAYERS], starts[2 * BHG_MLP_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) { numel[2 * l] = (int64_t)m->dims[l] * m->dims[l + 1]; numel[2 * l + 1] = m->dims[l + 1]; }
+    const int64_t nch = bhg_layout_num_chunks(numel, 2 * L);
+    std::vector<bhg_chunk> chunks((size_t)(nch > 0 ? nch : 1));
+    if (int rc = bhg_layout_build(numel, 2 * L, starts, chunks.data())) return rc;
+    float* const fake = reinterpret_cast<float*>((uintptr_t)1 << 30);
+    if (algo == 0) {
+      static CgCtx c;   // (large: off the stack)
+      cg_ctx_init(&c, m, keep_solution ? fake : nullptr, fake, fake, starts, nullptr, (int)nch, 2, 1.f, 0.f, fake, fake, false);
+      hoist = c.hoist ? 1 : 0; proj_level = c.proj_level; lin = c.lin ? 1 : 0; lin_head = c.lin_head ? 1 : 0;
+      upd_first = (c.lin && L > 4) ? 1 : 0;
+      form = !c.lazy ? "classic-eager" : (!c.hoist ? "classic" : (c.proj_level == 0 ? "hoisted" : (c.proj_level == 1 ? "projected-keep-state" :
+             (c.lin ? (c.lin_head ? "six-launch (k_wskpl .. k_headu .. k_graw)" : "six-launch-class (k_wskpl first, recurrences beside the chain)") :
+              "fully-projected (k_pstep launch)"))));
+      if (c.proj_level >= 1) closing = graw_batch_ok(m->Bp) ? (m->Bp == 128 ? "k_graw" : "k_grawk") : "k_hoist+k_proj_update";
+    } else {
+      const bool want_proj = !keep_solution && proj_mode() != 0 && hoist_mode() != 0;
+      const bool proj = want_proj && hp.ok && hp.proj_ok && use_head(m);
+      hoist = (hp.ok && (hoist_mode() == 2 || want_proj)) ? 1 : 0;
+      proj_level = proj ? 1 : 0;
+      form = proj ? "projected-neumann (update inside k_graw)" : (hoist ? "hoisted" : "classic");
+      if (proj) closing = graw_batch_ok(m->Bp) ? (m->Bp == 128 ? "k_graw" : "k_grawk") : "k_hoist+k_proj_update";
+    }
+  }
+  size_t gram = 0;
+  if (hp.ok && hp.proj_ok)
+    for (int l = 0; l + 1 < L; ++l) gram += (size_t)m->Bp * m->Bp * (l >= 1 ? (2 + 2 * kGramSplitMax + 6) : 2);
+  const int n = snprintf(buf, buf_bytes,
+                         "algo=%s keep_solution=%d fused=%d form=\"%s\" hoist=%d proj_level=%d lin=%d lin_head=%d upd_first=%d closing=%s "
+                         "plan_ok=%d proj_ok=%d lin_ok=%d hoist_products=%d hoist_wgs=%d gram_floats=%zu fused_ws_bytes=%zu narrow_head=%d packed_prepare=%d",
+                         algo == 0 ? "cg" : "neumann", keep_solution ? 1 : 0, fused ? 1 : 0, form, hoist, proj_level, lin, lin_head, upd_first, closing,
+                         hp.ok ? 1 : 0, hp.proj_ok ? 1 : 0, hp.lin_ok ? 1 : 0, hp.n, hp.ok ? hp.blk0[hp.n] : 0, gram,
+                         fused ? bhg_mlp_fused_ws_bytes(m) : (size_t)0, narrow_head(m) ? 1 : 0, bhg_mlp_supports_packed_prepare(m));
+  BHG_REQUIRE(n > 0 && (size_t)n < buf_bytes, "output buffer too small");
   return BHG_OK;
 }
 

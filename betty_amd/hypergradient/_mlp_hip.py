@@ -535,12 +535,16 @@ class PaddedHipMLPState:
         pv0, pv1, pp = play.state(3)
         be.neumann_init(play, self.twin.rhs, pv0, pp if keep_p else None)
         token = self.inner.neumann_solve(play, pv0, pv1, pp, K, alpha, shift, keep_p=keep_p)
+        self._twin_p = (token, play, pp) if keep_p else None   # a materialised accumulator is read like a direction by mixed_coeff
         if keep_p:
             self._unpad(play.views(pp, self.twin.dirs), self._real_views(layout, p))
         return token
 
     def mixed_coeff(self, dir_views, solve: FusedSolve = None):
         if solve is not None:
+            held = getattr(self, "_twin_p", None)
+            if solve.kind == "neumann" and solve.materialised and held is not None and held[0] is solve:
+                return self.inner.mixed_coeff(held[1].views(held[2], self.twin.dirs), solve)   # the twin's own accumulator
             return self.inner.mixed_coeff(None, solve)
         return self.inner.mixed_coeff(self._pad(dir_views, self.twin.dirs))
 

@@ -404,6 +404,13 @@ int bhg_mwn_forward(const float* ce, int B, const float* w1, const float* b1, co
 int bhg_mwn_backward(const float* ce, const float* coeff, int B, const float* w1, const float* b1, const float* w2, const float* b2,
                      int H, float scale, float* gw1, float* gb1, float* gw2, float* gb2, void* stream);
 
+/* Host only (no launch, no device access): the form bhg_mlp_cg_solve (algo 0) / bhg_mlp_neumann_solve (algo 1) will take for this
+ * descriptor, with (keep_solution != 0) or without a materialised solution / accumulator vector — the decision of hoist_plan and of the
+ * solvers' set-up code, printed as `key=value` pairs into `buf` (form, hoist, proj_level, lin, lin_head, closing launch, workspace
+ * sizes).  Only L, B, Bp and dims of the descriptor are read.  For tests of the shape -> form map and for diagnostics; the reference has
+ * no counterpart (its cg / neumann have one form: betty/hypergradient/cg.py:8-70, neumann.py:8-66).                                  */
+int bhg_mlp_plan_describe(const bhg_mlp* m, int algo, int keep_solution, char* buf, size_t buf_bytes);
+
 /* ---- networks whose widths are not multiples of 32 (round 6) ------------------------------------------------------------------------
  * The fused solvers' chain works on 32-wide tiles (bhg_mlp_supports_fused_solve).  The reference's cg / neumann are shape-agnostic
  * (betty/hypergradient/cg.py:8-70), so the host side (betty_amd/hypergradient/_mlp_hip.py: PaddedHipMLPState) keeps a ZERO-PADDED TWIN
