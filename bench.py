@@ -164,7 +164,7 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
 def pmc_traffic(key, N):

@@ -32,7 +32,7 @@
 namespace bhg {
 namespace {
 
-constexpr int kBnMaxSlices = 64;    // slices of one channel's M elements (workgroups per channel)
+constexpr int kBnMaxSlices = 512;   // slices of one channel's M elements (workgroups per channel): sample groups x chunks of the H*W run
 constexpr int kBnSums = 5;
 
 struct BnArgs {
@@ -42,8 +42,12 @@ struct BnArgs {
   const float* b; const float* c;                       // [C], may be NULL (zero)
   float* dx; float* dgy; float* dgamma;                 // dgamma may be NULL
   double* part;                                         // [C][slices][5]
-  int N, C, HW, slices;
-  long long M, per;                                     // elements per channel; elements per slice (multiple of 4)
+  int N, C, HW;
+  int groups, ng;                                       // sample groups and samples per group
+  int tpr;                                              // threads per run (power of two <= 256): 256 / tpr samples side by side
+  int chunks, chunk;                                    // chunks of one sample's H*W run and their length (a multiple of 4)
+  int slices;                                           // groups * chunks
+  long long M;                                          // N * HW elements per channel
 };
 
 template <int VEC>
@@ -56,31 +60,39 @@ __device__ __forceinline__ void bn_load(const float* __restrict__ p, float (&v)[
   }
 }
 
-// grid = (slices, C).  Sums over this slice of channel blockIdx.y.
+// grid = (slices, C).  Slice s = (sample group, chunk of the H*W run): no division inside the loops — a sample's run of channel c is
+// contiguous, the workgroup walks its samples and, inside each, its chunk with a stride of 256 vectors.  (The first version cut the
+// channel's N * HW elements into equal ranges and found (n, position) by a 64-bit division per vector: 3.7 TB/s on the ResNet-12
+// shapes; round 6, profiles/r06_bench_bn_*.txt.)
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_vjp_stats(BnArgs q) {
   __shared__ double red[kWaves];
   const int c = blockIdx.y, s = blockIdx.x;
-  const long long lo = (long long)s * q.per;
-  const long long hi = lo + q.per < q.M ? lo + q.per : q.M;
+  const int grp = s / q.chunks, ck = s - grp * q.chunks;
+  const int n0 = grp * q.ng, n1 = n0 + q.ng < q.N ? n0 + q.ng : q.N;
+  const int lo = ck * q.chunk, hi = lo + q.chunk < q.HW ? lo + q.chunk : q.HW;
   const double mu = (double)q.mean[c], inv = (double)q.invstd[c];
   double sa = 0.0, sg = 0.0, sp = 0.0, sq = 0.0, sA = 0.0;
-  for (long long e = lo + (long long)VEC * threadIdx.x; e < hi; e += (long long)VEC * kThreads) {
-    const long long n = e / q.HW;
-    const long long off = (n * q.C + c) * q.HW + (e - n * q.HW);
-    float xv[VEC], gv[VEC], av[VEC];
-    bn_load<VEC>(q.x + off, xv);
-    bn_load<VEC>(q.gy + off, gv);
-    if (q.a) bn_load<VEC>(q.a + off, av);
+  // short runs (10 x 10 maps: 25 vectors): `tpr` threads walk one sample's chunk, 256 / tpr samples of the group side by side
+  const int tv = (int)threadIdx.x & (q.tpr - 1), tr = (int)threadIdx.x / q.tpr, rows = kThreads / q.tpr;
+  for (int n = n0 + tr; n < n1; n += rows) {
+    const long long base = ((long long)n * q.C + c) * q.HW;
+    for (int e = lo + VEC * tv; e < hi; e += VEC * q.tpr) {
+      const long long off = base + e;
+      float xv[VEC], gv[VEC], av[VEC];
+      bn_load<VEC>(q.x + off, xv);
+      bn_load<VEC>(q.gy + off, gv);
+      if (q.a) bn_load<VEC>(q.a + off, av);
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      const double xh = ((double)xv[u] - mu) * inv;
-      const double aa = q.a ? (double)av[u] : 0.0;
-      sa += aa;
-      sg += (double)gv[u];
-      sp += aa * xh;
-      sq += (double)gv[u] * xh;
-      sA += aa * (double)gv[u];
+      for (int u = 0; u < VEC; ++u) {
+        const double xh = ((double)xv[u] - mu) * inv;
+        const double aa = q.a ? (double)av[u] : 0.0;
+        sa += aa;
+        sg += (double)gv[u];
+        sp += aa * xh;
+        sq += (double)gv[u] * xh;
+        sA += aa * (double)gv[u];
+      }
     }
   }
   double* out = q.part + ((long long)c * q.slices + s) * kBnSums;
@@ -91,13 +103,18 @@ __global__ __launch_bounds__(kThreads) void k_bn_vjp_stats(BnArgs q) {
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void k_bn_vjp_apply(BnArgs q) {
   __shared__ double coef[8];
+  __shared__ double red[kWaves];
   const int c = blockIdx.y, s = blockIdx.x;
-  if (threadIdx.x == 0) {
-    double Sa = 0.0, Sg = 0.0, P = 0.0, Q = 0.0, A = 0.0;
+  // the channel's five sums: every block of the channel adds the same partials in the same (fixed) tree — the same bits everywhere
+  double Sa = 0.0, Sg = 0.0, P = 0.0, Q = 0.0, A = 0.0;
+  {
     const double* pp = q.part + (long long)c * q.slices * kBnSums;
-    for (int i = 0; i < q.slices; ++i) {   // slice order: the same bits in every block of the channel
+    for (int i = threadIdx.x; i < q.slices; i += kThreads) {
       Sa += pp[i * kBnSums + 0]; Sg += pp[i * kBnSums + 1]; P += pp[i * kBnSums + 2]; Q += pp[i * kBnSums + 3]; A += pp[i * kBnSums + 4];
     }
+    Sa = block_sum(Sa, red); Sg = block_sum(Sg, red); P = block_sum(P, red); Q = block_sum(Q, red); A = block_sum(A, red);
+  }
+  if (threadIdx.x == 0) {
     const double M = (double)q.M, inv = (double)q.invstd[c], g = q.gamma ? (double)q.gamma[c] : 1.0;
     const double b = q.b ? (double)q.b[c] : 0.0, cc = q.c ? (double)q.c[c] : 0.0;
     const double k = g * inv / M;
@@ -116,39 +133,60 @@ __global__ __launch_bounds__(kThreads) void k_bn_vjp_apply(BnArgs q) {
   // the like — and the vector fp64 rate is far above what 32 bytes per element of HBM traffic can feed.
   const double c0 = coef[0], c1 = coef[1], c2 = coef[2], d0 = coef[3], d1 = coef[4], d2 = coef[5], d3 = coef[6];
   const double mu = (double)q.mean[c], inv = (double)q.invstd[c];
-  const long long lo = (long long)s * q.per;
-  const long long hi = lo + q.per < q.M ? lo + q.per : q.M;
-  for (long long e = lo + (long long)VEC * threadIdx.x; e < hi; e += (long long)VEC * kThreads) {
-    const long long n = e / q.HW;
-    const long long off = (n * q.C + c) * q.HW + (e - n * q.HW);
-    float xv[VEC], gv[VEC], av[VEC], ox[VEC], og[VEC];
-    bn_load<VEC>(q.x + off, xv);
-    bn_load<VEC>(q.gy + off, gv);
-    if (q.a) bn_load<VEC>(q.a + off, av);
+  const int grp = s / q.chunks, ck = s - grp * q.chunks;
+  const int n0 = grp * q.ng, n1 = n0 + q.ng < q.N ? n0 + q.ng : q.N;
+  const int lo = ck * q.chunk, hi = lo + q.chunk < q.HW ? lo + q.chunk : q.HW;
+  // short runs (10 x 10 maps: 25 vectors): `tpr` threads walk one sample's chunk, 256 / tpr samples of the group side by side
+  const int tv = (int)threadIdx.x & (q.tpr - 1), tr = (int)threadIdx.x / q.tpr, rows = kThreads / q.tpr;
+  for (int n = n0 + tr; n < n1; n += rows) {
+    const long long base = ((long long)n * q.C + c) * q.HW;
+    for (int e = lo + VEC * tv; e < hi; e += VEC * q.tpr) {
+      const long long off = base + e;
+      float xv[VEC], gv[VEC], av[VEC], ox[VEC], og[VEC];
+      bn_load<VEC>(q.x + off, xv);
+      bn_load<VEC>(q.gy + off, gv);
+      if (q.a) bn_load<VEC>(q.a + off, av);
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      const double xh = ((double)xv[u] - mu) * inv;
-      const double aa = q.a ? (double)av[u] : 0.0;
-      og[u] = (float)(c0 * aa + c1 * xh + c2);
-      ox[u] = (float)(d0 * aa + d1 * (double)gv[u] + d2 * xh + d3);
-    }
-    if (VEC == 4) {
-      *reinterpret_cast<float4*>(q.dgy + off) = make_float4(og[0], og[1], og[2], og[3]);
-      *reinterpret_cast<float4*>(q.dx + off) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-    } else {
-      q.dgy[off] = og[0];
-      q.dx[off] = ox[0];
+      for (int u = 0; u < VEC; ++u) {
+        const double xh = ((double)xv[u] - mu) * inv;
+        const double aa = q.a ? (double)av[u] : 0.0;
+        og[u] = (float)(c0 * aa + c1 * xh + c2);
+        ox[u] = (float)(d0 * aa + d1 * (double)gv[u] + d2 * xh + d3);
+      }
+      if (VEC == 4) {
+        *reinterpret_cast<float4*>(q.dgy + off) = make_float4(og[0], og[1], og[2], og[3]);
+        *reinterpret_cast<float4*>(q.dx + off) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+      } else {
+        q.dgy[off] = og[0];
+        q.dx[off] = ox[0];
+      }
     }
   }
 }
 
-inline int bn_slices(int C, long long M) {
-  // about 2048 workgroups per launch (8 per CU), at least 1024 elements per workgroup, at most kBnMaxSlices per channel
-  long long s = (2048 + C - 1) / C;
-  const long long cap = (M + 1023) / 1024;
-  if (s > cap) s = cap;
-  if (s > kBnMaxSlices) s = kBnMaxSlices;
-  return s < 1 ? 1 : (int)s;
+// The slicing of one channel's N x HW elements: sample groups (<= 256, whole samples) x chunks of the H*W run (multiples of 4 elements, so
+// that 16-byte accesses stay aligned): about 2048 workgroups per launch, at least ~1024 elements per chunk.
+inline void bn_slicing(BnArgs* q, int vec) {
+  const int N = q->N, C = q->C, HW = q->HW;
+  const int target = (2048 + C - 1) / C;                        // workgroups per channel
+  int chunks = (target + N - 1) / N;                            // more than one chunk per run only when there are few samples
+  const int max_chunks = (HW + 1023) / 1024;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  const int chunk = (((HW + chunks - 1) / chunks) + 3) & ~3;
+  chunks = (HW + chunk - 1) / chunk;
+  // samples per group: about 1024 elements per workgroup at least, at most 256 groups.  (NOT "no more workgroups than the target": for a
+  // large layer 16 k workgroups of 3 k elements stream faster than 2 k workgroups of 25 k — 292 vs 330 us at 64 x 256 x 56 x 56.)
+  int ng = (1024 + chunk - 1) / chunk;
+  if ((N + 255) / 256 > ng) ng = (N + 255) / 256;
+  if (ng > N) ng = N;
+  if (ng < 1) ng = 1;
+  int groups = (N + ng - 1) / ng;
+  while (groups * chunks > kBnMaxSlices) { ++ng; groups = (N + ng - 1) / ng; }
+  const int vecs = (chunk + vec - 1) / vec;
+  int tpr = kThreads;
+  while (tpr > 16 && tpr / 2 >= vecs) tpr /= 2;
+  q->ng = ng; q->groups = groups; q->chunks = chunks; q->chunk = chunk; q->slices = groups * chunks; q->tpr = tpr;
 }
 
 }  // namespace
@@ -176,8 +214,7 @@ int bhg_bn_backward_vjp(const float* x, const float* gy, const float* a, const f
   q.dx = dx; q.dgy = dgy; q.dgamma = dgamma; q.part = static_cast<double*>(ws);
   q.N = N; q.C = C; q.HW = HW;
   q.M = (long long)N * HW;
-  q.slices = bn_slices(C, q.M);
-  q.per = ((q.M + q.slices - 1) / q.slices + 3) & ~3LL;
+  bn_slicing(&q, vec ? 4 : 1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(q.slices, C);
   if (vec) {

@@ -9,9 +9,10 @@ Per hypergradient step:
   5. ``bhg_mlp_mixed_coeff`` one R-forward for the mixed second derivative, then a backward through
      ``s``'s graph                                                                    (native + PyTorch)
 All [Bp = 128, d] activation buffers are allocated once per (shapes, device) and reused across steps.
-A classifier head wider than 32 outputs runs steps 1, 3 and 5 natively as well since round 6 (the output layer as one more split-K
-product + a row kernel: k_softmax_ce_rows / k_coeff_rows in csrc/bhg_mlp.hip); it has no fused solver (the K loop is K x (HVP kernels +
-recurrence kernel)).  Networks whose input / hidden widths are not multiples of 32 run on a zero-padded twin (PaddedHipMLPState below).
+Round 6: the head kernels take up to 256 classes (chunks of 4 * JMAX classes, csrc/mlp/head_body.inc; rounds 1-5: 32), so such heads
+have the fused solvers too; beyond that — or with a feature width that is not a multiple of 4 — steps 1, 3 and 5 still run natively (the
+output layer as one more split-K product + a row kernel: k_softmax_ce_rows / k_coeff_rows in csrc/bhg_mlp.hip) and the K loop is
+K x (HVP kernels + recurrence kernel).  Networks whose input / hidden widths are not multiples of 32 run on a zero-padded twin (PaddedHipMLPState below).
 There is no ATen arithmetic in this file.
 """
 from __future__ import annotations
@@ -555,7 +556,7 @@ def make_state(spec, x, y):
     phases of an iteration) keeps the network as it is."""
     Ws = [lin.weight for lin in spec.layers]
     dims = tuple([Ws[0].shape[1]] + [W.shape[0] for W in Ws])
-    # (L >= 3 and a narrow head: the conditions under which the twin takes the fused form at all — bhg_mlp_supports_fused_solve)
-    if (PAD_WIDTHS_TO_32 and getattr(spec, "pad_widths", True) and len(Ws) >= 3 and dims[-1] <= 32 and padded_dims(dims) != dims and x.is_cuda):
+    # (L >= 3 and a head the head kernels take — <= 256 classes: the conditions under which the twin takes the fused form at all)
+    if (PAD_WIDTHS_TO_32 and getattr(spec, "pad_widths", True) and len(Ws) >= 3 and dims[-1] <= 256 and padded_dims(dims) != dims and x.is_cuda):
         return PaddedHipMLPState(spec, x, y)
     return HipMLPState(spec, x, y)

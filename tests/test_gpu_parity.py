@@ -851,12 +851,15 @@ def test_opaque_solve_with_persistent_graphs(algo, K, be):
         assert rel <= 2e-5, (step, rel)
 
 
-@pytest.mark.parametrize("dims,B", [([192, 256, 128, 48], 72), ([784, 300, 100], 100), ([64, 96, 1000], 130)], ids=lambda v: str(v))
+@pytest.mark.parametrize("dims,B", [([192, 256, 128, 48], 72), ([784, 300, 100], 100), ([64, 96, 1000], 130), ([256, 384, 128, 100], 100),
+                                    ([512, 256, 256, 64, 100], 100), ([256, 256, 130, 40], 64)], ids=lambda v: str(v))
 def test_wide_head_runs_natively_and_matches_autograd(dims, B, be):
-    """A classifier head wider than 32 outputs (48, 100, 1000 classes; ragged widths; more than one 128-row batch tile): since round 6
-    the once-per-step passes (forward + softmax / CE, deltas, mixed coefficient) are native too — the output layer as one more split-K
-    product + k_softmax_ce_rows / k_coeff_rows; rounds 1-5 ran them on ATen — and the K HVPs on the MFMA kernels as before (no fused
-    solver: bhg_mlp_supports_fused_solve is false) — against the opaque autograd path on the same inputs, CG and Neumann."""
+    """A classifier head wider than 32 outputs (40, 48, 100, 1000 classes; ragged widths; more than one 128-row batch tile) against the
+    opaque autograd path on the same inputs, CG and Neumann.  Rounds 1-5: once-per-step passes on ATen, K loop un-fused.  Round 6:
+      * up to 256 classes with a feature width that is a multiple of 4 the head kernels take it (classes in chunks of 4 * JMAX,
+        csrc/mlp/head_body.inc) — the FUSED solvers run, in whatever form the plan gives the shapes (projected for the three- and four-layer nets);
+      * beyond that (1000 classes; a feature width of 130) the once-per-step passes are native all the same — the output layer as one more
+        split-K product + k_softmax_ce_rows / k_coeff_rows — and the K loop is K x (HVP kernels + recurrence kernel)."""
     from betty_amd.hypergradient.structured import WeightedCEMLP
 
     for algo, K in (("cg", 4), ("neumann", 4)):
@@ -871,9 +874,11 @@ def test_wide_head_runs_natively_and_matches_autograd(dims, B, be):
             outs[arm] = _np(hg.jvp_fn_mapping[algo]([0.1 * d for d in direction], curr, prev, False))
             if arm == "hip":
                 st = prov._state
-                assert st.buf.native_prepare and not st.fused_supported(be.layout(direction))
+                inner_state = getattr(st, "inner", st)
+                want_fused = dims[-1] <= 256 and dims[-2] % 4 == 0
+                assert inner_state.buf.native_prepare and st.fused_supported(be.layout(direction)) == want_fused, (dims, want_fused)
         rel, _ = rel_err(outs["hip"], outs["autograd"])
-        print(f"wide head {dims} B={B} {algo}: analytic (native prepare + MFMA HVPs) vs autograd {rel:.2e}")
+        print(f"wide head {dims} B={B} {algo}: analytic ({'fused solver' if want_fused else 'native prepare + MFMA HVPs'}) vs autograd {rel:.2e}")
         assert rel <= 1e-4, (algo, rel)
 
 
@@ -1055,6 +1060,7 @@ def test_withheld_beta_times_out_poisons_the_result_and_is_diagnosed(be, bhg_deb
      ([64, 96, 64, 32, 64, 96, 32, 64, 10], 50, 4),   # eight layers: the deepest net the hoisted / projected forms take
      ([512, 256, 256, 64, 10], 200, 4), ([256, 256, 128, 64, 10], 256, 5), ([256, 192, 128, 64, 32, 10], 300, 3),   # round 5: batches > 128
      ([256, 256, 192, 640, 10], 100, 5), ([256, 256, 128, 64, 24], 100, 5),   # four layers, a head k_headu does not take (K > 512; C > 12)
+     ([256, 256, 128, 64, 100], 100, 4),                                        # round 6: a 100-class head (classes in chunks of 32)
      ([3072, 2048, 1536, 384, 10], 100, 20)],
     ids=lambda v: str(v),
 )

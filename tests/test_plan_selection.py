@@ -63,8 +63,11 @@ def test_shape_to_form(dims, B, cg_free, cg_x, neu_free, neu_acc, closing):
 
 
 def test_wide_head_has_no_fused_solver_and_the_twin_rounds_widths_up():
-    d = _native.plan_describe([192, 256, 128, 48], 72)
+    d = _native.plan_describe([192, 256, 128, 1000], 72)               # beyond the head kernels' 256 classes
     assert (d["fused"], d["narrow_head"], d["form"]) == (0, 0, "unfused")
+    d = _native.plan_describe([256, 384, 128, 100], 100)               # round 6: a 100-class head takes the fused forms
+    assert (d["fused"], d["narrow_head"], d["form"]) == (1, 1, PSTEP)
+    assert _native.plan_describe([512, 256, 256, 64, 100], 100)["form"] == SIX_CLASS
     assert _native.plan_describe([192, 256, 132, 10], 72)["form"] == "classic"      # feature width % 32 != 0 as the kernels see it ...
     assert _native.plan_describe([192, 256, 130, 10], 72)["form"] == "unfused"      # (% 4 != 0: not even the narrow-head kernels)
     assert _mlp_hip.padded_dims([192, 256, 130, 10]) == (192, 256, 160, 10)          # ... so the host side hands them the twin
