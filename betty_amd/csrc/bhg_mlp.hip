@@ -1703,7 +1703,7 @@ size_t bhg_mlp_fused_ws_bytes(const bhg_mlp* m) {
 
 static int solve_common_checks(const bhg_mlp* m, const int64_t* starts, const void* fws, size_t fws_bytes) {
   if (int rc = check_mlp(m)) return rc;
-  BHG_REQUIRE(bhg_mlp_supports_fused_solve(m), "fused solve needs a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
+  BHG_REQUIRE(bhg_mlp_supports_fused_solve(m), "fused solve needs a narrow classifier head (<= 256 classes, feature width % 4 == 0)");
   BHG_REQUIRE(starts && fws, "NULL argument");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
@@ -2003,7 +2003,7 @@ static int check_head_problem(const bhg_mlp* m) {
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   return BHG_OK;
 }
-// narrow head (<= 32 classes, feature width % 4 == 0): the latency-optimised head kernels; anything wider: the output layer as one more
+// narrow head (<= 256 classes, feature width % 4 == 0): the latency-optimised head kernels; anything wider: the output layer as one more
 // split-K product + a row kernel (round 6: the ATen fallback of rounds 1-5 is gone from the product)
 static bool narrow_head(const bhg_mlp* m) { return m->dims[m->L] <= kSmallC && (m->dims[m->L - 1] & 3) == 0; }
 
@@ -2143,7 +2143,7 @@ int bhg_mlp_supports_packed_prepare(const bhg_mlp* m) {
 int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int64_t* labels, float* ce, void* fws, size_t fws_bytes,
                            void* stream) {
   if (int rc = check_head_problem(m)) return rc;
-  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
+  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 256 classes, feature width % 4 == 0)");
   BHG_REQUIRE(bias && labels && ce && fws, "NULL argument");
   BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
@@ -2186,7 +2186,7 @@ int bhg_mlp_forward_packed(const bhg_mlp* m, const void* const* bias, const int6
 
 int bhg_mlp_backward_packed(const bhg_mlp* m, const int64_t* labels, void* fws, size_t fws_bytes, void* stream) {
   if (int rc = check_head_problem(m)) return rc;
-  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 32 classes, feature width % 4 == 0)");
+  BHG_REQUIRE(narrow_head(m), "the packed once-per-step passes need a narrow classifier head (<= 256 classes, feature width % 4 == 0)");
   BHG_REQUIRE(labels && fws, "NULL argument");
   BHG_REQUIRE(bhg_mlp_supports_packed_prepare(m), "this network does not take the packed form (bhg_mlp_supports_packed_prepare)");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");

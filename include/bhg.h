@@ -253,8 +253,9 @@ int bhg_mlp_hvp(const bhg_mlp* m, const void* const* dir, void* const* out, void
  * un-fused Neumann loop passes 3 — what the fused Neumann solver uses — so the two arms stay bitwise comparable.     */
 int bhg_mlp_hvp_mode(const bhg_mlp* m, const void* const* dir, void* const* out, int gemm_mode, void* stream);
 
-/* Once-per-step passes on the same descriptor (narrow classifier head: dims[L] <= 32, dims[L-1] % 4 == 0;
- * bhg_mlp_supports_native_prepare tells).  They write the direction-independent buffers the HVP reads:
+/* Once-per-step passes on the same descriptor (any head since round 6: up to 256 classes with dims[L-1] % 4 == 0 on the head kernels,
+ * wider ones as one more split-K product + a row kernel; bhg_mlp_supports_native_prepare tells).  They write the
+ * direction-independent buffers the HVP reads:
  *   bhg_mlp_forward   h[1..L-1], mask[], prob, and ce[b] = -log softmax(z_b)[y_b]   (h[0] = padded input, bias = L ptrs)
  *   bhg_mlp_backward  delta[]  from sd (= per-sample weight / B, written by the caller between the two calls)
  *   bhg_mlp_mixed_coeff  coeff[b] = (prob_b - onehot(y_b)) . Rz_b(dir) / B  (the mixed second derivative's
