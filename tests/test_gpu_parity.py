@@ -1987,3 +1987,26 @@ def test_example_learning_to_reweight_runs_with_both_structures_declared():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith(f"algo={algo}")]
         assert line and "upper steps" in line[0], r.stdout[-500:]
         print(line[0])
+
+
+def test_example_implicit_maml_convnet_runs_with_declared_batchnorm():
+    """examples/implicit_maml_convnet.py end to end on the GPU (own Engine shim): the learner's batch-norm layers are declared
+    (betty_amd.nn.fuse_batchnorm_), so every Hessian-vector product of every hypergradient runs bhg_bn_backward_vjp once per layer — the
+    printed counter proves it — and the undeclared arm of the same script reaches the same query accuracy."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for arm in ([], ["--no-fuse"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "implicit_maml_convnet.py"), "--k", "3", "--iters", "12", "--size", "16"] + arm,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("implicit MAML")]
+        assert line and "finite True" in line[0], r.stdout[-500:]
+        print(line[0])
+        out[bool(arm)] = (int(re.search(r"fused double-backward calls (\d+)", line[0]).group(1)), int(re.search(r"(\d+) upper steps", line[0]).group(1)),
+                          float(re.search(r"query acc ([0-9.]+)", line[0]).group(1)))
+    calls, steps, acc = out[False]
+    assert steps == out[True][1] > 0 and calls == steps * 3 * 4, (calls, steps)     # K = 3 products x 4 declared layers per hypergradient
+    assert out[True][0] == 0 and abs(acc - out[True][2]) <= 0.21, out
