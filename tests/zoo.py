@@ -591,3 +591,46 @@ def cfg5_checksums(curr, prev, vector):
     x, y = curr.cur_batch
     ts = list(curr.parameters()) + list(prev.parameters()) + [x, y.double()] + list(vector)
     return np.array([t.detach().double().sum().item() for t in ts] + [t.detach().double().abs().sum().item() for t in ts])
+
+
+# ---- round 6: shapes OUTSIDE the benchmark's family (widths that are not multiples of 32, heads wider than 32 classes) ---------------
+# (dims, batch): the reweighting problem of examples/learning_to_reweight/main.py:117-127 on a ReLU-MLP of these widths; goldens from the
+# reference's own cg / neumann on the CPU in tests/golden/shapes.npz (tests/golden/make_shapes_golden.py)
+SHAPE_CASES = {
+    "mnist_784_512_256_128_10": ([784, 512, 256, 128, 10], 100),
+    "ragged_784_500_250_100_10": ([784, 500, 250, 100, 10], 128),
+    "head100_256_384_128_100": ([256, 384, 128, 100], 100),
+    "head100_512_256_256_64_100": ([512, 256, 256, 64, 100], 100),
+    "head1000_64_96_1000": ([64, 96, 1000], 130),
+}
+SHAPE_RIDGE, SHAPE_K = 0.3, 10
+
+
+def shape_case(name, Config, device, algo, seed=0, dtype=torch.float32):
+    """(curr, prev, vector): every tensor drawn by the CPU generator in fp32 and then moved / cast (the build container and the GPU box
+    see the same numbers)."""
+    dims, B = SHAPE_CASES[name]
+    g = torch.Generator().manual_seed(9000 + seed)
+    inner, upper = MLP(dims), MWN(16)
+    with torch.no_grad():
+        for p in list(inner.parameters()) + list(upper.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (1.0 / max(p.shape[-1], 4) ** 0.5))
+    x = torch.randn(B, dims[0], generator=g)
+    y = torch.randint(0, dims[-1], (B,), generator=g)
+    vector = [0.1 * torch.randn(p.shape, generator=g) for p in inner.parameters()]
+    inner, upper = inner.to(device=device, dtype=dtype), upper.to(device=device, dtype=dtype)
+    x, y = x.to(device=device, dtype=dtype), y.to(device)
+    vector = [v.to(device=device, dtype=dtype) for v in vector]
+    prev = StubProblem("upper", upper, config=Config())
+    cfg = Config(type="cg", cg_iterations=SHAPE_K, cg_alpha=1.0) if algo == "cg" else Config(type="neumann", neumann_iterations=SHAPE_K, neumann_alpha=0.1)
+    curr = StubProblem("inner", inner, config=cfg, loss_fn=make_reweight_loss(prev, SHAPE_RIDGE), batch=(x, y))
+    return curr, prev, vector
+
+
+def shape_checksums(name, Config, seed=0):
+    import numpy as np
+
+    curr, prev, vector = shape_case(name, Config, "cpu", "cg", seed=seed)
+    x, y = curr.cur_batch
+    ts = list(curr.module.parameters()) + list(prev.module.parameters()) + [x, y.double()] + list(vector)
+    return np.array([t.detach().double().sum().item() for t in ts] + [t.detach().double().abs().sum().item() for t in ts])
