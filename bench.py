@@ -584,6 +584,7 @@ def main():
 
     from betty_amd import _native
     from betty_amd.backend import get_backend
+    from betty_amd.distributed import fence_grads
 
     be = get_backend()
     if args.debug or args.ab_lib:   # measurement arms live in the measurement build (libbhg_ab.so: same sources, -DBHG_AB)
@@ -640,6 +641,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             step()
+        fence_grads()   # the deferred all-reduce of the region's LAST step belongs to the region (steps 1 .. n-1 were fenced by their successors)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -751,6 +753,7 @@ def main():
         elapsed_timed = float(t.item())
     be.check_health()
 
+    fence_grads()
     finite = all(bool(torch.isfinite(p.grad).all()) for p in prev.parameters())
     if not finite:
         raise SystemExit("bench.py: non-finite hypergradient — refusing to report a throughput for a wrong result")
