@@ -25,7 +25,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _native
 
-__all__ = ["FusedBatchNorm2d", "fuse_batchnorm_", "fused_batchnorm_calls"]
+__all__ = ["FusedBatchNorm2d", "fuse_batchnorm_", "fused_batchnorm_calls", "PointwiseConv2d", "declare_pointwise_convs_", "declare_layers_"]
 
 _CALLS = {"forward": 0, "backward": 0, "backward_vjp": 0}   # test / measurement hook: which nodes ran
 
@@ -155,3 +155,40 @@ def fuse_batchnorm_(module: torch.nn.Module) -> int:
             m.__class__ = FusedBatchNorm2d
             n += 1
     return n
+
+
+class PointwiseConv2d(torch.nn.Conv2d):
+    """``nn.Conv2d`` with a 1 x 1 kernel (stride 1, no padding, one group) evaluated as what it is — a matrix product over the channels,
+    ``y[n] = W x[n]`` — so that autograd's double backward of it (cg.py:39-41, neumann.py:62) is three more matrix products on
+    rocBLAS / hipBLASLt instead of MIOpen's convolution double backward, which for these shapes can fall to a PER-SAMPLE im2col + GEMM
+    loop: on BASELINE cfg 3's ResNet-12 the four 1 x 1 shortcut projections cost 25 launches per sample-loop, 12.6 k ``Im2d2Col`` + 16.6 k
+    small GEMM launches and ~220 ms of a 900 ms step (profiles/r06_cfg3_step_kernel_breakdown_declared_batchnorm.txt).  Same parameters,
+    ``state_dict`` and results to fp32 rounding; any other configuration of the layer IS ``nn.Conv2d``."""
+
+    def _pointwise(self) -> bool:
+        return (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding in ((0, 0), "valid") and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding_mode == "zeros")
+
+    def forward(self, x):
+        if not self._pointwise() or x.dim() != 4:
+            return super().forward(x)
+        n, _, h, w = x.shape
+        y = torch.matmul(self.weight.reshape(self.out_channels, self.in_channels), x.reshape(n, self.in_channels, h * w))
+        if self.bias is not None:
+            y = y + self.bias.reshape(1, -1, 1)
+        return y.reshape(n, self.out_channels, h, w)
+
+
+def declare_pointwise_convs_(module: torch.nn.Module) -> int:
+    """Re-class every 1 x 1 / stride 1 / ungrouped ``nn.Conv2d`` of ``module`` (exact class) as :class:`PointwiseConv2d`, in place."""
+    n = 0
+    for m in module.modules():
+        if type(m) is torch.nn.Conv2d and PointwiseConv2d._pointwise(m):
+            m.__class__ = PointwiseConv2d
+            n += 1
+    return n
+
+
+def declare_layers_(module: torch.nn.Module) -> dict:
+    """Every layer declaration this module offers, in place: ``{"batchnorm": n, "pointwise_conv": m}``."""
+    return {"batchnorm": fuse_batchnorm_(module), "pointwise_conv": declare_pointwise_convs_(module)}

@@ -34,6 +34,8 @@ def case(dtype=torch.float32, fused=False, K=20):
     vector = [(0.01 * torch.randn(p.shape, generator=g)).to(dev, dtype) for p in inner.parameters()]
     if fused:
         bnn.fuse_batchnorm_(inner)
+    if fused == "pointwise":   # ... and the 1 x 1 shortcut projections as matrix products
+        bnn.declare_pointwise_convs_(inner)
     prev = zoo.StubProblem("upper", upper, config=Config())
     curr = zoo.StubProblem("inner", inner, config=Config(type="cg", cg_iterations=K, cg_alpha=1.0), loss_fn=zoo.make_imaml_loss(prev, 0.5), batch=(x, y))
     return curr, prev, vector
@@ -67,17 +69,22 @@ if want64:
     h64 = hvp(curr, vector)
     print(f"one H v in float64 ({time.time() - t0:.1f} s): undeclared fp32 {rel(res[False], h64):.2e}, declared fp32 {rel(res[True], h64):.2e} from it", flush=True)
 
+curr, prev, vector = case(fused="pointwise")
+hpw = hvp(curr, vector)
+print(f"one H v: declared batch norm + 1x1 convolutions as matrix products vs undeclared: rel {rel(hpw, res[False]):.2e}" +
+      (f"; from the float64 product {rel(hpw, h64):.2e}" if want64 else ""), flush=True)
 for K in (1, 2, 5, 10, 20):
     out = {}
-    for fused in (False, True):
+    for fused in (False, True, "pointwise"):
         curr, prev, vector = case(fused=fused, K=K)
         out[fused] = flat(hg.cg(vector, curr, prev, False))
     curr, prev, vector = case(K=K)
     chk = flat(horc.cg(vector, curr, prev, False))
-    line = f"CG K={K:2d}: declared vs undeclared {rel(out[True], out[False]):.2e}; undeclared vs the reference's algorithm on this GPU {rel(out[False], chk):.2e}, declared vs it {rel(out[True], chk):.2e}"
+    line = f"CG K={K:2d}: declared vs undeclared {rel(out[True], out[False]):.2e} (+ pointwise: {rel(out['pointwise'], out[False]):.2e}); undeclared vs the reference's algorithm on this GPU {rel(out[False], chk):.2e}, declared vs it {rel(out[True], chk):.2e}"
     if want64 and K in (5, 20):
         curr, prev, vector = case(torch.float64, K=K)
         t0 = time.time()
         truth = flat(horc.cg(vector, curr, prev, False))
-        line += f" | float64 truth ({time.time() - t0:.0f} s): reference algorithm fp32 {rel(chk, truth):.2e}, undeclared {rel(out[False], truth):.2e}, declared {rel(out[True], truth):.2e}"
+        line += (f" | float64 truth ({time.time() - t0:.0f} s): reference algorithm fp32 {rel(chk, truth):.2e}, undeclared {rel(out[False], truth):.2e}, declared {rel(out[True], truth):.2e}, "
+                 f"declared + pointwise {rel(out['pointwise'], truth):.2e}")
     print(line, flush=True)

@@ -37,6 +37,8 @@ if fused_bn:
     from betty_amd import nn as bnn
 
     print("declared batch-norm layers:", bnn.fuse_batchnorm_(inner))
+    if len(sys.argv) > 3 and sys.argv[3] == "pointwise":
+        print("declared 1x1 convolutions:", bnn.declare_pointwise_convs_(inner))
 for _ in range(2):
     hg.cg(vector, curr, prev, False)
 torch.cuda.synchronize()

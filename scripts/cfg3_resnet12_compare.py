@@ -35,6 +35,12 @@ got = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).doubl
 ours_bn = bench(lambda: hg.cg(vector, curr, prev, False))
 print(f"ResNet-12 cfg3 CG-20 with {n_bn} declared batch-norm layers: betty_amd {ours_bn:.2f} steps/s (x{ours_bn / ref:.2f} over the reference's algorithm on "
       f"this GPU, x{ours_bn / ours:.2f} over the undeclared product); result vs the undeclared product: rel {float((got - want).norm() / want.norm()):.2e}")
+# ... and the four 1 x 1 shortcut projections as matrix products (betty_amd.nn.declare_pointwise_convs_)
+n_pw = bnn.declare_pointwise_convs_(inner)
+got2 = torch.cat([t.reshape(-1) for t in hg.cg(vector, curr, prev, False)]).double()
+ours_pw = bench(lambda: hg.cg(vector, curr, prev, False))
+print(f"ResNet-12 cfg3 CG-20 with {n_bn} declared batch-norm layers and {n_pw} declared 1x1 convolutions: betty_amd {ours_pw:.2f} steps/s (x{ours_pw / ref:.2f} over the "
+      f"reference's algorithm on this GPU); result vs the undeclared product: rel {float((got2 - want).norm() / want.norm()):.2e}")
 zoo.attach_prox_structure(curr)
 ours_struct = bench(lambda: hg.cg(vector, curr, prev, False))
 print(f"ResNet-12 cfg3 CG-20, opaque HVP: betty_amd {ours:.2f} steps/s | reference algorithm on the same GPU {ref:.2f} steps/s"

@@ -226,3 +226,50 @@ def test_module_on_the_gpu_matches_nn_batchnorm_gradient_and_hvp():
     print(f"FusedBatchNorm2d vs nn.BatchNorm2d on the GPU: gradient {e_g:.2e}, Hessian-vector product {e_h:.2e}")
     assert e_g <= 1e-5 and e_h <= 1e-4, (e_g, e_h)
     torch.testing.assert_close(res[True][2], res[False][2])
+
+
+# ---- PointwiseConv2d: a 1 x 1 convolution as the matrix product it is ---------------------------------------------------------------
+@pytest.mark.parametrize("bias", [False, True])
+def test_pointwise_conv_matches_conv2d_value_gradient_and_hessian_vector_product(bias):
+    torch.manual_seed(2)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(5, 7, 1, bias=bias), torch.nn.Tanh(), torch.nn.Conv2d(7, 3, 3, padding=1), torch.nn.Conv2d(3, 4, 1, stride=2)).double()
+    net = torch.nn.Sequential(torch.nn.Conv2d(5, 7, 1, bias=bias), torch.nn.Tanh(), torch.nn.Conv2d(7, 3, 3, padding=1), torch.nn.Conv2d(3, 4, 1, stride=2)).double()
+    net.load_state_dict(ref.state_dict())
+    assert bnn.declare_pointwise_convs_(net) == 1 and type(net[0]) is bnn.PointwiseConv2d and type(net[3]) is torch.nn.Conv2d   # (stride 2: left alone)
+    assert bnn.declare_layers_(net) == {"batchnorm": 0, "pointwise_conv": 0}
+    x = torch.randn(3, 5, 6, 4, dtype=torch.float64)
+    res = {}
+    for name, m in (("ref", ref), ("net", net)):
+        params = list(m.parameters())
+        g = torch.Generator().manual_seed(5)
+        vec = [torch.randn(p.shape, generator=g, dtype=torch.float64) for p in params]
+        y = m(x)
+        grads = torch.autograd.grad((y ** 2).sum(), params, create_graph=True)
+        hv = torch.autograd.grad(grads, params, grad_outputs=vec)
+        res[name] = (y.detach(), [t.detach() for t in grads], list(hv))
+    torch.testing.assert_close(res["net"][0], res["ref"][0], rtol=1e-12, atol=1e-12)
+    for a, b in zip(res["net"][1] + res["net"][2], res["ref"][1] + res["ref"][2]):
+        torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-12)
+    torch.nn.Conv2d(5, 7, 1, bias=bias).load_state_dict(bnn.PointwiseConv2d(5, 7, 1, bias=bias).state_dict())   # same keys
+
+
+@pytest.mark.gpu
+def test_pointwise_conv_on_the_gpu_matches_conv2d_gradient_and_hvp():
+    res = {}
+    for declared in (False, True):
+        torch.manual_seed(4)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(16, 24, 1, bias=False), torch.nn.Tanh(),
+                                  torch.nn.Conv2d(24, 8, 1), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(8, 3)).to(DEV)
+        if declared:
+            assert bnn.declare_pointwise_convs_(net) == 2
+        g = torch.Generator().manual_seed(4)
+        x, y = torch.randn(8, 3, 10, 10, generator=g).to(DEV), torch.randint(0, 3, (8,), generator=g).to(DEV)
+        params = list(net.parameters())
+        vec = [torch.randn(p.shape, generator=g).to(DEV) for p in params]
+        grads = torch.autograd.grad(F.cross_entropy(net(x), y), params, create_graph=True)
+        hv = torch.autograd.grad(grads, params, grad_outputs=vec)
+        res[declared] = ([t.detach().cpu().numpy() for t in grads], [t.cpu().numpy() for t in hv])
+    e_g, _ = rel_err(res[True][0], res[False][0])
+    e_h, _ = rel_err(res[True][1], res[False][1])
+    print(f"PointwiseConv2d vs nn.Conv2d on the GPU: gradient {e_g:.2e}, Hessian-vector product {e_h:.2e}")
+    assert e_g <= 1e-5 and e_h <= 1e-4, (e_g, e_h)
