@@ -762,7 +762,11 @@ def main():
     secondary = None
     if (world == 1 and args.algo == "cg" and K == 20 and fused and not args.no_secondary and not args.no_parity and not args.debug
             and not args.keep_solution):
-        secondary = secondary_lines(args, device, be, N)
+        try:   # evidence BESIDE the headline: a failure here is reported in the line, it does not take the headline with it
+            secondary = secondary_lines(args, device, be, N)
+        except (Exception, SystemExit) as exc:   # noqa: BLE001
+            secondary = {"error": f"{type(exc).__name__}: {exc}"[:2000]}
+            print(f"bench.py: the secondary lines failed: {secondary['error']}", file=sys.stderr)
     out = None
     one_pass_solves = 0
     if args.mode == "global":
