@@ -539,6 +539,8 @@ def main():
                          "sustained state before the first timed region (0 = off)")
     ap.add_argument("--reps", type=int, default=5,
                     help="timed regions of `--steps` steps each (full and, interleaved, K/2): the line reports the MEDIAN region and the spread")
+    ap.add_argument("--own-stream", action="store_true",
+                    help="A/B: run every step on a stream created for the run instead of the process's default (null) stream")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (Neumann K = 10 and the opaque path's k_cg_resident, ~2 s after the timed regions)")
     ap.add_argument("--no-parity", action="store_true",
@@ -627,10 +629,18 @@ def main():
     # (hipExtLaunchKernelGGL / hipEventRecord inside libbhg; bhg_timing_enable/read in include/bhg.h)
     timing_on = not args.no_kernel_timing
 
+    own_stream = torch.cuda.Stream(device) if args.own_stream else None
+    if own_stream is not None:
+        own_stream.wait_stream(torch.cuda.current_stream(device))
+
     def step():
         for p in prev.parameters():
             p.grad = None
-        out = jvp_fn(vector, curr, prev, True)
+        if own_stream is not None:
+            with torch.cuda.stream(own_stream):
+                out = jvp_fn(vector, curr, prev, True)
+        else:
+            out = jvp_fn(vector, curr, prev, True)
         assert out is None
 
     def timed_region(n):
