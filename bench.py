@@ -539,6 +539,16 @@ def main():
                          "sustained state before the first timed region (0 = off)")
     ap.add_argument("--reps", type=int, default=5,
                     help="timed regions of `--steps` steps each (full and, interleaved, K/2): the line reports the MEDIAN region and the spread")
+    ap.add_argument("--hw-queues", type=int, default=-1,
+                    help="GPU_MAX_HW_QUEUES for this process (how many hardware queues ROCclr maps the HIP streams onto), set before the first HIP "
+                         "call.  -1 (default): 1 when the run has more than one rank (or emulates a collective) and the variable is not set in the "
+                         "environment, else untouched; 0: never touch it.  Why: a process-group collective runs on a stream of its own, and once a "
+                         "SECOND hardware queue has been active in a step every dependent launch of the solver costs ~1 us more (measured at N = 1 with "
+                         "an emulated per-step collective: 678 vs 755 steps/s, DESIGN 4b)")
+    ap.add_argument("--emulate-collective", choices=["none", "blocking", "deferred"], default="none",
+                    help="A/B at N = 1: after every step touch the M-float result on ANOTHER stream the way a process-group collective does "
+                         "(blocking: the main stream waits at once, like dist.all_reduce; deferred: it waits at the next step's hop) — what a second "
+                         "hardware queue costs the K loop")
     ap.add_argument("--own-stream", action="store_true",
                     help="A/B: run every step on a stream created for the run instead of the process's default (null) stream")
     ap.add_argument("--no-secondary", action="store_true",
@@ -564,6 +574,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one hardware queue for a run whose steps contain a collective (see --hw-queues); must happen before the HIP runtime comes up
+    hwq_note = "runtime default"
+    if args.hw_queues > 0 or (args.hw_queues == -1 and (world > 1 or args.emulate_collective != "none") and "GPU_MAX_HW_QUEUES" not in os.environ):
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues if args.hw_queues > 0 else 1)
+        hwq_note = "set by bench.py"
+    elif "GPU_MAX_HW_QUEUES" in os.environ:
+        hwq_note = "from the environment"
+    gpu_max_hw_queues = os.environ.get("GPU_MAX_HW_QUEUES")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; betty_amd has no CPU path"
     if os.environ.get("BHG_ALL_RANKS_ON_GPU0") == "1":  # debug: exercise the N>1 code path on a 1-GPU box (gloo)
         local_rank = 0
@@ -633,7 +651,13 @@ def main():
     if own_stream is not None:
         own_stream.wait_stream(torch.cuda.current_stream(device))
 
+    coll_stream = torch.cuda.Stream(device) if args.emulate_collective != "none" else None
+    pending = []
+
     def step():
+        if pending:   # deferred: the fence falls where .grad is next touched
+            torch.cuda.current_stream(device).wait_stream(coll_stream)
+            pending.clear()
         for p in prev.parameters():
             p.grad = None
         if own_stream is not None:
@@ -642,6 +666,15 @@ def main():
         else:
             out = jvp_fn(vector, curr, prev, True)
         assert out is None
+        if coll_stream is not None:
+            g = next(iter(prev.parameters())).grad
+            coll_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(coll_stream):
+                g.mul_(1.0)   # stands in for the M-float all-reduce
+            if args.emulate_collective == "blocking":
+                torch.cuda.current_stream(device).wait_stream(coll_stream)
+            else:
+                pending.append(1)
 
     def timed_region(n):
         torch.cuda.synchronize()
@@ -963,6 +996,8 @@ def main():
                 "debug_arms": args.debug or None,
                 "lib": "libbhg_ab.so (measurement build: A/B table compiled in)" if _native.is_ab() else "libbhg.so (product: no measurement arm in the code object)",
                 "lib_sha256": lib_sha256()[:16],
+                "gpu_max_hw_queues": f"{gpu_max_hw_queues or 'unset'} ({hwq_note})",
+                "emulated_collective": args.emulate_collective if args.emulate_collective != "none" else None,
             },
             "parity": parity,
             "secondary": secondary,
