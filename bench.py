@@ -17,7 +17,9 @@ loop; the M-sized hypergradient is averaged over the ranks when the ``sync=True`
 ONE flat all-reduce of the M floats over RCCL issued by the hop itself (the upper module is declared in
 closed form, SigmoidMLPWeightNet(average_over=True): csrc/bhg_mwn.hip), or — ``--upper autograd`` — by
 the DDP reducer when the backward through the wrapped module fires, as in the reference.  Weak scaling:
-value = N * steps / max-over-ranks time.
+value = N * steps / max-over-ranks time.  A run with more than one rank sets GPU_MAX_HW_QUEUES=1 for its processes unless the
+variable is already set (--hw-queues): a collective's stream is a second hardware queue, and that costs every dependent launch
+of the solver ~1 us on this runtime (--emulate-collective shows it at N = 1).
 
 Timing: W warm-up steps, an untimed settle phase (--settle-ms), then --reps pairs of timed regions of
 --steps steps (full K, then K / 2, interleaved), each bracketed by barrier + synchronize; the line
