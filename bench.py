@@ -488,6 +488,20 @@ def device_census(dist, world, rank, device, M):
             "allreduce_note": "%d back-to-back all-reduces of the M = %d float hypergradient, max over ranks: the only collective of a replica-mode step" % (n, M)}
 
 
+def resolve_hw_queues(flag, world, has_collective_stream, env):
+    """--hw-queues: (value of GPU_MAX_HW_QUEUES for this process or None, where it came from); writes `env` when bench.py decides.
+      flag > 0   that value, always;
+      flag == -1 1 when a step of the run involves a second stream (more than one rank, or an emulated collective) and the variable is not
+                 already set — a second active hardware queue costs every dependent launch of the solver ~1 us on this runtime (DESIGN 4b);
+      flag == 0  never touched."""
+    if flag > 0 or (flag == -1 and (world > 1 or has_collective_stream) and "GPU_MAX_HW_QUEUES" not in env):
+        env["GPU_MAX_HW_QUEUES"] = str(flag if flag > 0 else 1)
+        return env["GPU_MAX_HW_QUEUES"], "set by bench.py"
+    if "GPU_MAX_HW_QUEUES" in env:
+        return env["GPU_MAX_HW_QUEUES"], "from the environment"
+    return None, "runtime default"
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU over RCCL."""
     import socket
@@ -577,13 +591,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # one hardware queue for a run whose steps contain a collective (see --hw-queues); must happen before the HIP runtime comes up
-    hwq_note = "runtime default"
-    if args.hw_queues > 0 or (args.hw_queues == -1 and (world > 1 or args.emulate_collective != "none") and "GPU_MAX_HW_QUEUES" not in os.environ):
-        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues if args.hw_queues > 0 else 1)
-        hwq_note = "set by bench.py"
-    elif "GPU_MAX_HW_QUEUES" in os.environ:
-        hwq_note = "from the environment"
-    gpu_max_hw_queues = os.environ.get("GPU_MAX_HW_QUEUES")
+    gpu_max_hw_queues, hwq_note = resolve_hw_queues(args.hw_queues, world, args.emulate_collective != "none", os.environ)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; betty_amd has no CPU path"
     if os.environ.get("BHG_ALL_RANKS_ON_GPU0") == "1":  # debug: exercise the N>1 code path on a 1-GPU box (gloo)
         local_rank = 0

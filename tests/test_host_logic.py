@@ -851,3 +851,20 @@ def test_install_switches_auto_structure():
         assert structured.AUTO_STRUCTURE is False
     finally:
         structured.AUTO_STRUCTURE = saved
+
+
+def test_bench_sets_one_hardware_queue_only_for_runs_with_a_collective_stream():
+    """bench.py --hw-queues (round 6: a collective's stream is a second hardware queue — 6 us per iteration of the K loop)."""
+    import bench
+
+    assert bench.resolve_hw_queues(-1, 1, False, {}) == (None, "runtime default")            # the driver's N = 1 line: untouched
+    env = {}
+    assert bench.resolve_hw_queues(-1, 8, False, env) == ("1", "set by bench.py") and env == {"GPU_MAX_HW_QUEUES": "1"}
+    env = {}
+    assert bench.resolve_hw_queues(-1, 1, True, env) == ("1", "set by bench.py")             # --emulate-collective at N = 1
+    env = {"GPU_MAX_HW_QUEUES": "4"}
+    assert bench.resolve_hw_queues(-1, 8, False, env) == ("4", "from the environment") and env["GPU_MAX_HW_QUEUES"] == "4"   # the user's choice wins
+    env = {}
+    assert bench.resolve_hw_queues(0, 8, False, env) == (None, "runtime default") and env == {}
+    env = {"GPU_MAX_HW_QUEUES": "4"}
+    assert bench.resolve_hw_queues(2, 1, False, env) == ("2", "set by bench.py")
