@@ -525,6 +525,9 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=20, help="K: CG / Neumann iterations")
     ap.add_argument("--algo", choices=["cg", "neumann", "darts"], default="cg",
                     help="cg = the BASELINE metric; neumann / darts = secondary lines (BASELINE cfg 2 uses neumann K=10)")
+    ap.add_argument("--global-form", choices=["auto", "one_pass", "sharded"], default="auto",
+                    help="--mode global: auto = the factor-exchange form (batch-sized all-gathers, fully projected solver) when the structure "
+                    "takes it, else one-pass, else sharded; one_pass / sharded pin the older forms")
     ap.add_argument("--mode", choices=["replica", "global"], default="replica",
                     help="replica = the reference's DDP mode (every rank solves its own problem; default).  global = ONE inner "
                     "problem whose batch is spread over the ranks: data-parallel HVP, sharded CG state (betty_amd/global_hvp.py)")
@@ -629,6 +632,9 @@ def main():
         # the same inner / upper weights on every rank, a different batch per rank
         curr, prev, vector = build(device, seed=0, ddp=world > 1, K=K, algo="cg", data_seed=rank)
         jvp_fn = hg.jvp_fn_mapping["cg_global"]
+        import betty_amd.global_hvp as _ghvp
+
+        _ghvp.GLOBAL_FORM = args.global_form
     else:
         curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
         jvp_fn = hg.jvp_fn_mapping[args.algo]
@@ -822,10 +828,12 @@ def main():
             print(f"bench.py: the secondary lines failed: {secondary['error']}", file=sys.stderr)
     out = None
     one_pass_solves = 0
+    fx_stats = None
     if args.mode == "global":
-        from betty_amd.global_hvp import ONE_PASS_STATS
+        from betty_amd.global_hvp import FX_STATS, ONE_PASS_STATS
 
         one_pass_solves = ONE_PASS_STATS["solves"]
+        fx_stats = dict(FX_STATS)
     if rank == 0:
         # replica mode: every rank completes `steps` independent hypergradient steps; global mode: the ranks share ONE
         # problem (global batch = world x local batch) and complete `steps` steps together
@@ -997,7 +1005,13 @@ def main():
                 "solution_vector": ("materialised" if (args.keep_solution or not fused or args.algo != "cg") else
                                     "not materialised: the mixed second derivative comes from Rz(x) = sum_k alpha_k Rz(p_k), "
                                     "accumulated from batch-sized factors"),
-                "parallelism": (("global batch over %d rank(s), one-pass form: replicated x / r / p, per iteration ONE 8-byte all-reduce (p.H_data p) "
+                "parallelism": (("global batch over %d rank(s), FACTOR-EXCHANGE form: the fully projected solver on sample-partitioned data; per "
+                                 "iteration ONE all-gather of batch-sized factors (%d bytes per rank) and ONE of fp64 partials (%d bytes per rank), h_l / "
+                                 "delta_l once per solve (%d bytes per rank); nothing N-sized exchanged but the right-hand side's mean; %d solves took it"
+                                 % (world, fx_stats["slab_bytes_per_rank"], fx_stats["scal_bytes_per_rank"], fx_stats["const_bytes_per_rank"],
+                                    fx_stats["solves"]))
+                                if (fx_stats and fx_stats["solves"]) else
+                                ("global batch over %d rank(s), one-pass form: replicated x / r / p, per iteration ONE 8-byte all-reduce (p.H_data p) "
                                  "and ONE 4N-byte all-reduce (mean of the locally updated residuals); %d solves took it" % (world, one_pass_solves))
                                 if one_pass_solves else
                                 ("global-HVP: data-parallel HVP, CG state sharded over %d rank(s), reduce-scatter / all-gather per iteration" % world))

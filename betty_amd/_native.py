@@ -20,6 +20,7 @@ BHG_CHUNK_ELEMS = 4096
 BHG_FLAT_ALIGN = 64
 BHG_CG_AUTO, BHG_CG_STREAM, BHG_CG_RESIDENT = 0, 1, 2
 BHG_CG_GLOBAL_CHAIN, BHG_CG_GLOBAL_UPDATE, BHG_CG_GLOBAL_DOTS = 0, 1, 2   # phases of bhg_mlp_cg_global_phase
+BHG_CG_FX_BEGIN, BHG_CG_FX_CHAIN, BHG_CG_FX_GRAM, BHG_CG_FX_END = 0, 1, 2, 3   # phases of bhg_mlp_cg_fx_phase
 
 
 class NativeLibraryError(RuntimeError):
@@ -143,6 +144,16 @@ SYMBOLS = {
         c_int,
         [POINTER(Mlp), c_void_p, c_void_p, c_void_p, POINTER(c_int64), _CH, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
          c_float, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "bhg_mlp_fx_supported": (c_int, [POINTER(Mlp), c_int]),
+    "bhg_mlp_fx_ws_bytes": (c_size_t, [POINTER(Mlp), c_int]),
+    "bhg_mlp_fx_const_floats": (c_size_t, [POINTER(Mlp)]),
+    "bhg_mlp_fx_slab_floats": (c_size_t, [POINTER(Mlp)]),
+    "bhg_mlp_fx_scal_doubles": (c_size_t, [POINTER(Mlp)]),
+    "bhg_mlp_cg_fx_phase": (
+        c_int,
+        [POINTER(Mlp), _PP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t,
+         c_void_p, c_size_t, c_void_p],
     ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_timeout_flag_dev": (c_void_p, [POINTER(Mlp), c_void_p]),

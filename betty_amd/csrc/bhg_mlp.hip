@@ -1614,6 +1614,8 @@ int check_mlp(const bhg_mlp* m) {
   return BHG_OK;
 }
 
+#include "mlp/fx.inc"   // round 6: the factor-exchange form of the global-batch CG solver (rectangular Gram blocks; kernels + host phases)
+
 }  // namespace
 }  // namespace bhg
 
@@ -1910,6 +1912,75 @@ int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, cons
   if (int rc = cg_iteration(&c, k, phase == BHG_CG_GLOBAL_CHAIN ? 1 : 2, php, 1.0 / (double)world, st)) return rc;
   BHG_HIP_CHECK(hipGetLastError());
   return BHG_OK;
+}
+
+// ---- global-batch CG, FACTOR-EXCHANGE form (mlp/fx.inc; include/bhg.h) ---------------------------------------------------------------------
+int bhg_mlp_fx_supported(const bhg_mlp* m, int world) {
+  if (!m || m->L < 1 || m->L > BHG_MLP_MAX_LAYERS || m->Bp <= 0 || m->Bp % kTM != 0 || !bhg_mlp_supports_fused_solve(m)) return 0;
+  FxPlan fp;
+  fx_plan(m, world, &fp);
+  return fp.ok && dbg(DBG_packed_chain, 1) != 0 ? 1 : 0;
+}
+size_t bhg_mlp_fx_ws_bytes(const bhg_mlp* m, int world) {
+  if (!bhg_mlp_fx_supported(m, world)) return 0;
+  FxPlan fp; fx_plan(m, world, &fp);
+  FxWs x; fx_carve(m, fp, nullptr, &x);
+  return x.bytes;
+}
+size_t bhg_mlp_fx_const_floats(const bhg_mlp* m) {
+  if (!bhg_mlp_fx_supported(m, 1)) return 0;
+  FxPlan fp; fx_plan(m, 1, &fp);
+  return fp.const_floats;
+}
+size_t bhg_mlp_fx_slab_floats(const bhg_mlp* m) {
+  if (!bhg_mlp_fx_supported(m, 1)) return 0;
+  FxPlan fp; fx_plan(m, 1, &fp);
+  return fp.slab_floats;
+}
+size_t bhg_mlp_fx_scal_doubles(const bhg_mlp* m) {
+  if (!bhg_mlp_fx_supported(m, 1)) return 0;
+  FxPlan fp; fx_plan(m, 1, &fp);
+  return fp.scal_doubles;
+}
+int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                        float* slab_all, double* scal_all, float cg_alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
+                        size_t xws_bytes, void* stream) {
+  if (int rc = check_mlp(m)) return rc;
+  BHG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad world size / rank");
+  BHG_REQUIRE(bhg_mlp_fx_supported(m, world), "this network does not take the factor-exchange form (bhg_mlp_fx_supported)");
+  BHG_REQUIRE(phase == BHG_CG_FX_BEGIN || phase == BHG_CG_FX_CHAIN || phase == BHG_CG_FX_GRAM || phase == BHG_CG_FX_END, "unknown phase");
+  BHG_REQUIRE(K > 0 && k >= 0 && k < K, "bad iteration index");
+  BHG_REQUIRE(const_all && slab_all && scal_all && fws && xws, "NULL argument");
+  BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
+  BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
+  BHG_REQUIRE(xws_bytes >= bhg_mlp_fx_ws_bytes(m, world), "factor-exchange workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static FxPlan fp;   // (large: off the stack; rebuilt on every call from the descriptor alone — a few microseconds of host work)
+  fx_plan(m, world, &fp);
+  FusedWs w;
+  carve_fused_ws(m, fws, &w);
+  FxWs x;
+  fx_carve(m, fp, xws, &x);
+  const bhg_mlp ml = fx_local(m, fp, slab_all, rank);
+  double* scal_mine = scal_all + (size_t)rank * fp.scal_doubles;
+  if (phase == BHG_CG_FX_BEGIN) {
+    BHG_REQUIRE(k == 0, "BEGIN belongs to iteration 0");
+    return fx_begin(m, fp, const_all, rank, st);
+  }
+  if (phase == BHG_CG_FX_CHAIN) {
+    if (k == 0) {
+      BHG_REQUIRE(rhs, "iteration 0 reads the right-hand side");
+      for (int l = 0; l + 1 < m->L; ++l) BHG_REQUIRE(rhs[2 * l] && ((uintptr_t)rhs[2 * l] & 15) == 0, "rhs tensors must be 16-byte aligned device pointers");
+      for (int i = 0; i < 2 * m->L; ++i) BHG_REQUIRE(rhs[i], "rhs holds 2 L device pointers");
+      if (int rc = fx_first(m, &ml, fp, w, x, rhs, const_all, rank, st)) return rc;
+    } else {
+      if (int rc = fx_step(&ml, fp, w, x, scal_all, k - 1, false, cg_alpha, hvp_shift, st)) return rc;
+    }
+    return fx_chain(&ml, fp, w, x, st);
+  }
+  if (phase == BHG_CG_FX_GRAM) return fx_gram(&ml, fp, w, x, slab_all, const_all, scal_mine, st);
+  BHG_REQUIRE(k == K - 1, "END belongs to the last iteration");
+  return fx_step(&ml, fp, w, x, scal_all, k, true, cg_alpha, hvp_shift, st);
 }
 
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K, float alpha,

@@ -148,6 +148,75 @@ def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: f
     return [t.clone() for t in exchange_async(out, group).wait()]
 
 
+# ---- factor-exchange form (round 6): the fully projected solver on sample-partitioned data ------------------------------------------------
+# GLOBAL_FORM: "auto" = factor exchange whenever the structure takes it and the caller does not ask for x (else one-pass, else sharded);
+# "one_pass" / "sharded" pin the older forms (tests, bench.py --global-form).
+GLOBAL_FORM = "auto"
+FX_STATS = {"solves": 0, "const_gathers": 0, "slab_gathers": 0, "scal_gathers": 0, "rhs_all_reduces": 0,
+            "slab_bytes_per_rank": 0, "const_bytes_per_rank": 0, "scal_bytes_per_rank": 0}   # test / measurement hook
+
+
+def all_gather_slots(buf: torch.Tensor, rank: int, group) -> None:
+    """buf [world][n]: every rank wrote its own row; afterwards every rank holds all rows.  RCCL: one in-place all-gather."""
+    if _backend_name(group) == "gloo":
+        rows = [buf[i] for i in range(buf.shape[0])]
+        dist.all_gather(rows, buf[rank].clone(), group=group)
+    else:
+        dist.all_gather_into_tensor(buf.view(-1), buf[rank], group=group)
+
+
+class _FxState:
+    def __init__(self, full_layout):
+        self.v = full_layout.new_flat()
+
+
+_FX = weakref.WeakKeyDictionary()
+
+
+def _cg_global_factor_exchange(vector, prev, sync, provider, be, full, K: int, alpha: float, G: int, g: int, group):
+    """Per iteration ONE all-gather of batch-sized factors (Rd_l, Rh_l: B x sum of widths floats per rank) and ONE of a few KB of fp64
+    partials; h_l, delta_l once per solve; the right-hand side's mean once (the only N-sized collective, as in every form).  The ranks
+    never exchange — and after iteration 0 never read — anything N-sized (csrc/mlp/fx.inc; protocol: tests/proj_global_ref.py)."""
+    from . import _native  # noqa: PLC0415
+
+    st = _FX.get(full)
+    if st is None:
+        st = _FX[full] = _FxState(full)
+    be.flatten(full, vector, st.v, 1.0 / G)
+    if G > 1:
+        dist.all_reduce(st.v, op=dist.ReduceOp.SUM, group=group)
+        FX_STATS["rhs_all_reduces"] += 1
+    rhs = full.views(st.v, vector)
+    state = provider._state
+    bufs = state.fx_buffers(G)
+    FX_STATS["solves"] += 1
+    FX_STATS["slab_bytes_per_rank"] = bufs["slab"].shape[1] * 4
+    FX_STATS["const_bytes_per_rank"] = bufs["const"].shape[1] * 4
+    FX_STATS["scal_bytes_per_rank"] = bufs["scal"].shape[1] * 8
+    provider.cg_fx_phase(rhs, 0, K, _native.BHG_CG_FX_BEGIN, G, g, alpha)
+    if G > 1:
+        all_gather_slots(bufs["const"], g, group)
+        FX_STATS["const_gathers"] += 1
+    for k in range(K):
+        provider.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_CHAIN, G, g, alpha)
+        if G > 1:
+            all_gather_slots(bufs["slab"], g, group)
+            FX_STATS["slab_gathers"] += 1
+        provider.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_GRAM, G, g, alpha)
+        if G > 1:
+            all_gather_slots(bufs["scal"], g, group)
+            FX_STATS["scal_gathers"] += 1
+    provider.cg_fx_phase(rhs, K - 1, K, _native.BHG_CG_FX_END, G, g, alpha)
+    solve = provider.cg_fx_finish(full, K, alpha)
+    provider.expects_data_parallel_mean = G > 1
+    out = provider.mixed_vjp(None, sync, solve=solve)
+    if sync:
+        return None
+    from .distributed import exchange_async  # noqa: PLC0415
+
+    return [t.clone() for t in exchange_async(out, group).wait()]
+
+
 def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = None):
     """Same signature and result convention as ``cg`` (betty/hypergradient/cg.py:8-70); ``vector`` is this rank's
     gradient of ITS share of the upper loss (the global one is the mean over ranks).  Returns the GLOBAL hypergradient
@@ -173,8 +242,11 @@ def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = Non
     full = be.layout(vector)
     K = int(config.cg_iterations)
     alpha = float(config.cg_alpha)
+    fx_ready = getattr(provider, "fused_cg_fx_ready", None)
+    if GLOBAL_FORM == "auto" and fx_ready is not None and K > 0 and alpha != 0.0 and fx_ready(full, K, G):
+        return _cg_global_factor_exchange(vector, prev, sync, provider, be, full, K, alpha, G, g, group)
     ready = getattr(provider, "fused_cg_global_ready", None)
-    if ready is not None and K > 0 and alpha != 0.0 and ready(full, K):
+    if GLOBAL_FORM != "sharded" and ready is not None and K > 0 and alpha != 0.0 and ready(full, K):
         return _cg_global_one_pass(vector, prev, sync, provider, be, full, K, alpha, G, group)
     key = (id(full), G)
     st = _STATES.get(key)

@@ -318,6 +318,50 @@ class HipMLPState:
         self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=keep_x)
         return self._solve
 
+    # ---- global-batch CG, factor-exchange form (csrc/mlp/fx.inc: bhg_mlp_cg_fx_phase; driven by betty_amd/global_hvp.py) ---------------
+    def fx_supported(self, layout, world: int) -> bool:
+        """The fully projected solver on sample-partitioned data: needs the projected plan (>= 3 layers, widths % 32 == 0, narrow head)."""
+        return bool(self.fused_supported(layout) and self.lib.bhg_mlp_fx_supported(ctypes.byref(self.desc), int(world)))
+
+    def fx_buffers(self, world: int):
+        """The three gathered buffers ([world][...]: constants of a solve, factors of an iteration, fp64 partials) and the solver's own
+        workspace — per (buffers, world), allocated once."""
+        buf = self.buf
+        held = getattr(buf, "fx", None)
+        if held is None:
+            held = buf.fx = {}
+        got = held.get(world)
+        if got is None:
+            d, lib, dev = ctypes.byref(self.desc), self.lib, buf.h[0].device
+            z = lambda n, dt: torch.zeros(int(n), dtype=dt, device=dev)
+            got = held[world] = {
+                "const": z(world * lib.bhg_mlp_fx_const_floats(d), torch.float32).view(world, -1),
+                "slab": z(world * lib.bhg_mlp_fx_slab_floats(d), torch.float32).view(world, -1),
+                "scal": z(world * lib.bhg_mlp_fx_scal_doubles(d), torch.float64).view(world, -1),
+                "xws": z(max(int(lib.bhg_mlp_fx_ws_bytes(d, world)), 256), torch.uint8),
+            }
+        return got
+
+    def cg_fx_phase(self, rhs, k: int, K: int, phase: int, world: int, rank: int, cg_alpha: float, shift: float) -> None:
+        """One phase of the factor-exchange solver on THIS rank's share of the batch (include/bhg.h); the caller all-gathers the buffer
+        the phase wrote its slot of.  ``rhs``: the replicated right-hand side's tensors (read in CHAIN of iteration 0)."""
+        b = self.fx_buffers(world)
+        fws = self._fused_ws(self.buf.h[0].device)
+        if phase == _native.BHG_CG_FX_BEGIN:
+            self._solve = None   # the workspace an earlier solve's token refers to is being rewritten
+            self._fx_rhs = _native.ptr_array([t.data_ptr() for t in rhs]) + (list(rhs),)
+        _native.check(
+            self.lib.bhg_mlp_cg_fx_phase(ctypes.byref(self.desc), self._fx_rhs[0], int(k), int(K), int(phase), int(world), int(rank),
+                                         b["const"].data_ptr(), b["slab"].data_ptr(), b["scal"].data_ptr(), float(cg_alpha), float(shift),
+                                         fws.data_ptr(), fws.numel(), b["xws"].data_ptr(), b["xws"].numel(), _stream()),
+            "bhg_mlp_cg_fx_phase",
+        )
+
+    def cg_fx_finish(self, layout, K: int, cg_alpha: float) -> FusedSolve:
+        """Token of the factor-exchange solve that just ran (its Rz(x) sits where bhg_mlp_cg_mixed_coeff reads it; x never existed)."""
+        self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=False)
+        return self._solve
+
     def neumann_solve(self, layout, v0, v1, p, K: int, alpha: float, shift: float, keep_p: bool = True) -> FusedSolve:
         """neumann.py:61-66 for this structure: K HVP chains whose output kernels apply v' = v - a*Hv, p += v'.
         keep_p=False: the library gets p = NULL; mixed_coeff() of this solve is then formed from the Rz sums the head

@@ -432,6 +432,17 @@ class WeightedCEMLP:
         keep = not self.fused_cg_global_skips_solution(layout, K)
         return self._state.cg_global_finish(layout, K, cg_alpha, keep_x=keep)
 
+    # Global-batch CG, factor-exchange form: the fully projected solver on sample-partitioned data (no N-sized exchange, no x).
+    def fused_cg_fx_ready(self, layout, K: int, world: int) -> bool:
+        st = self._state
+        return (K > 0 and self.fused and not self.keep_solution and hasattr(st, "cg_fx_phase") and st.fx_supported(layout, world))
+
+    def cg_fx_phase(self, rhs, k: int, K: int, phase: int, world: int, rank: int, cg_alpha: float) -> None:
+        self._state.cg_fx_phase(rhs, k, K, phase, world, rank, cg_alpha, self.hvp_shift)
+
+    def cg_fx_finish(self, layout, K: int, cg_alpha: float):
+        return self._state.cg_fx_finish(layout, K, cg_alpha)
+
     def fused_neumann_ready(self, layout, K: int) -> bool:
         st = self._state
         return K > 0 and self.fused and hasattr(st, "neumann_solve") and st.fused_supported(layout)

@@ -318,6 +318,37 @@ int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, cons
 int bhg_mlp_cg_global_phase(const bhg_mlp* m, float* x, float* r, float* p, const int64_t* starts, const bhg_chunk* chunks_dev,
                             int n_chunks, int k, int K, int phase, int world, double* php, float cg_alpha, float hvp_shift,
                             void* ws, void* fws, size_t fws_bytes, void* stream);
+/* Global-batch CG, FACTOR-EXCHANGE form (round 6; extension like bhg_mlp_cg_global_phase, same oracle: cg.py:8-70 in one process on the
+ * concatenated batch; north_star: "DDP hypergradient all-reduce partitioned across the 8 GPUs ... overlapped with the next CG matvec").
+ * The fully projected solver on SAMPLE-PARTITIONED data: rank g keeps the products of the Krylov vectors with ITS batch
+ * (Gf_l = h_l U_l^T, Gb_l = delta_l U_l: batch-sized), and because every weight-shaped output of H_g' v is an outer product of
+ * batch-sized factors of rank g', their recurrences need the other ranks' FACTORS, not their N-sized outputs:
+ *     Gf_l^(g)(H v) = 1/G [S_l | T_l] [Rd_l ; delta_l]       Gb_l^(g)(H v) = 1/G [E_l | D_l] [h_l ; Rh_{l-1}]
+ * with rectangular Gram blocks [Bp x world*Bp] (this rank's rows against every rank's samples).  Nothing N-sized is exchanged and,
+ * after the projections of the right-hand side in iteration 0, nothing N-sized is read.  The caller drives, all on ONE stream:
+ *     phase BEGIN (k = 0);                 all-gather const_all   [world][bhg_mlp_fx_const_floats]   h_l, delta_l: once per solve
+ *     for k in 0 .. K-1:
+ *         phase CHAIN (k);                 all-gather slab_all    [world][bhg_mlp_fx_slab_floats]    Rd_l, Rh_l of this iteration
+ *         phase GRAM (k);                  all-gather scal_all    [world][bhg_mlp_fx_scal_doubles]   fp64 partials of r.raw, p.raw, raw.raw
+ *     phase END (k = K-1)
+ * Every phase writes THIS rank's slot (index `rank`) of the buffer gathered after it; the gathered partials are summed by every rank
+ * in rank order, so step lengths are bit-identical on all ranks whatever the collective's own reduction order.  rhs: 2L device
+ * pointers [W_0-shaped, b_0-shaped, ...] of the right-hand side, REPLICATED (the mean over the ranks of the local vectors), read in
+ * CHAIN (0) only.  All ranks must hold the same B and Bp.  On return Rz(x) sits in `fws` where bhg_mlp_cg_mixed_coeff reads it.
+ * world == 1 needs no collective and is the fully projected solver with its Gram products in launches of their own.
+ * fws: bhg_mlp_fused_ws_bytes(m);  xws: bhg_mlp_fx_ws_bytes(m, world) (zero-filled by the caller once).                              */
+#define BHG_CG_FX_BEGIN 0
+#define BHG_CG_FX_CHAIN 1
+#define BHG_CG_FX_GRAM 2
+#define BHG_CG_FX_END 3
+int bhg_mlp_fx_supported(const bhg_mlp* m, int world);
+size_t bhg_mlp_fx_ws_bytes(const bhg_mlp* m, int world);
+size_t bhg_mlp_fx_const_floats(const bhg_mlp* m);
+size_t bhg_mlp_fx_slab_floats(const bhg_mlp* m);
+size_t bhg_mlp_fx_scal_doubles(const bhg_mlp* m);
+int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                        float* slab_all, double* scal_all, float cg_alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
+                        size_t xws_bytes, void* stream);
 /* bhg_mlp_cg_solve with the right-hand side's tensors named (round 5).  rhs: 2L device pointers [W_0-shaped, b_0-shaped, ...] — the
  * tensors bhg_cg_init(_masked) was given — or NULL (= bhg_mlp_cg_solve).  The fully projected solver reads the N-sized residual
  * exactly once, in iteration 0, where r = the right-hand side: with rhs it reads the MFMA layers' slices THERE, so the caller may

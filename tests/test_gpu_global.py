@@ -77,12 +77,13 @@ def _attach(inner, prev, x, y, ridge, K, keep, alpha=1.0):
 @pytest.mark.parametrize("keep", [True, False], ids=["x-materialised", "solution-free"])
 @pytest.mark.parametrize("dims,B,K", [([256, 384, 128, 10], 100, 5), ([70, 130, 36, 10], 100, 4), ([64, 10], 50, 3),
                                       ([128, 96, 64, 32, 10], 128, 1)], ids=lambda v: str(v))
-def test_world_size_one_is_the_one_rank_solver(dims, B, K, keep, one_rank_group):
+def test_world_size_one_is_the_one_rank_solver(dims, B, K, keep, one_rank_group, global_form):
     """cg_global at world size 1: the phase-cut iteration (chain | step length + outputs | dots of the residual) gives what
     bhg_mlp_cg_solve gives — the dot products of the residual are taken per chunk instead of per output tile, so equality is to
     fp32 summation noise, not bitwise."""
     from betty_amd.global_hvp import ONE_PASS_STATS
 
+    global_form("one_pass")
     inner, prev, x, y, vec = _problem(dims, B, 0.05, sum(dims) + B + K, K, keep)
     want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vec, _attach(inner, prev, x, y, 0.05, K, keep), prev, False)]
     n0 = ONE_PASS_STATS["solves"]
@@ -180,8 +181,120 @@ def test_two_emulated_ranks_match_the_one_rank_solver_on_the_concatenated_batch(
         assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
 
 
+# ---- round 6: the FACTOR-EXCHANGE form (csrc/mlp/fx.inc) ----------------------------------------------------------------------------
+@pytest.fixture
+def global_form():
+    import betty_amd.global_hvp as gh
+
+    old = gh.GLOBAL_FORM
+
+    def set_(v):
+        gh.GLOBAL_FORM = v
+
+    yield set_
+    gh.GLOBAL_FORM = old
+
+
+FX_SHAPES = [([256, 384, 128, 10], 100, 5, 1.0), ([128, 96, 64, 32, 10], 128, 3, 0.5), ([512, 256, 128, 64, 10], 77, 8, 1.0),
+             ([256, 384, 128, 100], 100, 4, 1.0), ([512, 384, 256, 256, 128, 10], 60, 4, 1.0)]
+
+
+@pytest.mark.parametrize("dims,B,K,alpha", FX_SHAPES, ids=lambda v: str(v))
+def test_factor_exchange_at_world_size_one_is_the_one_rank_solver(dims, B, K, alpha, one_rank_group, global_form):
+    """cg_global at world size 1 takes the factor-exchange form (solution-free callers): the fully projected solver with its Gram and
+    G(raw) products as launches of their own and its inner products / scalars in kernels of their own — against bhg_mlp_cg_solve."""
+    from betty_amd.global_hvp import FX_STATS, ONE_PASS_STATS
+
+    inner, prev, x, y, vec = _problem(dims, B, 0.05, sum(dims) + B + K, K, False)
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vec, _attach(inner, prev, x, y, 0.05, K, False, alpha), prev, False)]
+    n0, o0 = FX_STATS["solves"], ONE_PASS_STATS["solves"]
+    lib = _native.load()
+    p0 = lib.bhg_mlp_proj_iterations()
+    got = [t.clone() for t in hg.jvp_fn_mapping["cg_global"](vec, _attach(inner, prev, x, y, 0.05, K, False, alpha), prev, False)]
+    assert FX_STATS["solves"] == n0 + 1 and ONE_PASS_STATS["solves"] == o0, "the factor-exchange form must be the one that ran"
+    assert lib.bhg_mlp_proj_iterations() == p0 + K, "K recurrence steps (K - 1 between iterations + the closing one)"
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 2e-5, rel
+    # the caller who wants x keeps the one-pass form
+    got_x = hg.jvp_fn_mapping["cg_global"](vec, _attach(inner, prev, x, y, 0.05, K, True, alpha), prev, False)
+    assert FX_STATS["solves"] == n0 + 1 and ONE_PASS_STATS["solves"] == o0 + 1
+    rel, _ = rel_err([t.cpu().numpy() for t in got_x], [t.cpu().numpy() for t in want])
+    assert rel <= 5e-5, rel
+
+
+def _emulate_fx(parts, prev, vecs, K, alpha):
+    """Drive betty_amd/global_hvp.py::_cg_global_factor_exchange for len(parts) ranks living in this process: every all-gather is a
+    copy of rank r's row into the other ranks' buffers."""
+    be = get_backend()
+    G = len(parts)
+    lays, provs, rhss, bufs = [], [], [], []
+    for curr, vec in zip(parts, vecs):
+        lay = FlatLayout([t.numel() for t in vec], vec[0].device)
+        prov = curr.hypergradient_structure(prev)
+        prov.pad_widths = False
+        prov.prepare()
+        assert prov.fused_cg_fx_ready(lay, K, G)
+        lays.append(lay)
+        provs.append(prov)
+        bufs.append(prov._state.fx_buffers(G))
+    assert len({id(b["slab"]) for b in bufs}) == G, "every emulated rank needs buffers of its own"
+    flats = []
+    for lay, vec in zip(lays, vecs):
+        v = lay.new_flat()
+        be.flatten(lay, vec, v, 1.0 / G)
+        flats.append(v)
+    total = sum(flats)
+    for lay, vec, v in zip(lays, vecs, flats):
+        v.copy_(total)
+        rhss.append(lay.views(v, vec))
+
+    def gather(name):
+        for r in range(G):
+            for j in range(G):
+                if j != r:
+                    bufs[j][name][r].copy_(bufs[r][name][r])
+
+    for g, (prov, rhs) in enumerate(zip(provs, rhss)):
+        prov.cg_fx_phase(rhs, 0, K, _native.BHG_CG_FX_BEGIN, G, g, alpha)
+    gather("const")
+    for k in range(K):
+        for g, (prov, rhs) in enumerate(zip(provs, rhss)):
+            prov.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_CHAIN, G, g, alpha)
+        gather("slab")
+        for g, (prov, rhs) in enumerate(zip(provs, rhss)):
+            prov.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_GRAM, G, g, alpha)
+        gather("scal")
+    outs = []
+    for g, (prov, lay, rhs) in enumerate(zip(provs, lays, rhss)):
+        prov.cg_fx_phase(rhs, K - 1, K, _native.BHG_CG_FX_END, G, g, alpha)
+        token = prov.cg_fx_finish(lay, K, alpha)
+        outs.append([t.clone() for t in prov.mixed_vjp(None, False, solve=token)])
+    # replicated scalars: the same bits on every rank
+    xw = [b["xws"] for b in bufs]
+    return [sum(o[i] for o in outs) / G for i in range(len(outs[0]))], provs
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("dims,B,K,alpha", [([256, 384, 128, 10], 100, 6, 1.0), ([128, 96, 64, 32, 10], 64, 4, 0.5),
+                                            ([512, 256, 128, 64, 10], 128, 8, 1.0)], ids=lambda v: str(v))
+def test_emulated_ranks_exchanging_factors_match_the_one_rank_solver_on_the_concatenated_batch(dims, B, K, alpha, world):
+    """`world` shares of one batch, `world` states; the three all-gathers done by hand; against bhg_mlp_cg_solve on the whole batch
+    (world * B rows) with the mean of the ranks' right-hand sides.  Rectangular Gram blocks [Bp x world * Bp] for world > 1."""
+    ridge = 0.05
+    inner, prev, x, y, _ = _problem(dims, world * B, ridge, 7 * sum(dims) + B + K, K, False)
+    g = torch.Generator().manual_seed(99)
+    vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+    vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
+    inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
+    parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
+    got, _ = _emulate_fx(parts, prev, vecs, K, alpha)
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 1e-4, rel
+
+
 # ---- two real processes, real collectives (gloo stages the device buffers through the host), one GPU ------------------------------
-def _two_process_worker(rank, world, port, q):
+def _two_process_worker(rank, world, port, q, form="one_pass"):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -193,8 +306,10 @@ def _two_process_worker(rank, world, port, q):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from betty_amd.global_hvp import ONE_PASS_STATS, cg_global
+        import betty_amd.global_hvp as gh
+        from betty_amd.global_hvp import FX_STATS, ONE_PASS_STATS, cg_global
 
+        gh.GLOBAL_FORM = form
         torch.cuda.set_device(0)
         dims, B, K, ridge = [256, 384, 128, 10], 100, 6, 0.05
         inner, prev, x, y, _ = _problem(dims, world * B, ridge, 4242, K, False)       # same seed: same weights, same full batch
@@ -209,7 +324,11 @@ def _two_process_worker(rank, world, port, q):
         others = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(others, flat)
         same = all(torch.equal(o, flat) for o in others)
-        q.put((rank, rel, same, ONE_PASS_STATS["solves"], ONE_PASS_STATS["scalar_all_reduces"], ONE_PASS_STATS["residual_all_reduces"], K))
+        if form == "auto":
+            q.put((rank, rel, same, FX_STATS["solves"], FX_STATS["slab_gathers"], FX_STATS["scal_gathers"], K, FX_STATS["const_gathers"],
+                   ONE_PASS_STATS["solves"]))
+        else:
+            q.put((rank, rel, same, ONE_PASS_STATS["solves"], ONE_PASS_STATS["scalar_all_reduces"], ONE_PASS_STATS["residual_all_reduces"], K))
     finally:
         dist.destroy_process_group()
 
@@ -234,6 +353,28 @@ def test_two_processes_share_one_gpu_over_gloo():
         assert rel <= 1e-4, (rank, rel)
         assert same
         assert (solves, n_scalar, n_resid) == (1, K, K - 1)
+
+
+def test_two_processes_exchange_factors_over_gloo_on_one_gpu():
+    """cg_global in its factor-exchange form between two processes on cuda:0: the right-hand side's mean (one N-sized all-reduce), one
+    gather of the constants, K gathers of the factor slab, K gathers of the fp64 partials, the M-sized exchange — the same bits on both
+    ranks, the one-rank solver's answer on the concatenated batch to north_star's tolerance."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_two_process_worker, args=(r, world, port, q, "auto")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, same, solves, n_slab, n_scal, K, n_const, one_pass in sorted(q.get(timeout=5) for _ in range(world)):
+        assert rel <= 1e-4, (rank, rel)
+        assert same
+        assert (solves, n_slab, n_scal, n_const, one_pass) == (1, K, K, 1, 0)
 
 
 # ---- round 5: the closed-form upper net under data parallelism (SigmoidMLPWeightNet.average_over) ---------------------------------
