@@ -280,15 +280,25 @@ def _emulate_fx(parts, prev, vecs, K, alpha):
 def test_emulated_ranks_exchanging_factors_match_the_one_rank_solver_on_the_concatenated_batch(dims, B, K, alpha, world):
     """`world` shares of one batch, `world` states; the three all-gathers done by hand; against bhg_mlp_cg_solve on the whole batch
     (world * B rows) with the mean of the ranks' right-hand sides.  Rectangular Gram blocks [Bp x world * Bp] for world > 1."""
+    import warnings
+
     ridge = 0.05
-    inner, prev, x, y, _ = _problem(dims, world * B, ridge, 7 * sum(dims) + B + K, K, False)
-    g = torch.Generator().manual_seed(99)
-    vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
-    vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
-    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
-    inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
-    parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
-    got, _ = _emulate_fx(parts, prev, vecs, K, alpha)
+    for attempt in range(4):   # an instance with a hidden pre-activation within 1e-6 of zero is not a test of the solver: the two sides
+        # round their forward passes differently (other tile counts), a ReLU mask flips, the Hessians differ — draw another one
+        inner, prev, x, y, _ = _problem(dims, world * B, ridge, 7 * sum(dims) + B + K + 1000 * attempt, K, False)
+        g = torch.Generator().manual_seed(99)
+        vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+        vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
+            inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
+            parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
+            got, _ = _emulate_fx(parts, prev, vecs, K, alpha)
+        if not any("ReLU-kink" in str(w.message) for w in caught):
+            break
+    else:
+        pytest.fail("four instances in a row sat on a ReLU kink")
     rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
     assert rel <= 1e-4, rel
 
