@@ -1976,9 +1976,9 @@ int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, 
     } else {
       if (int rc = fx_step(&ml, fp, w, x, scal_all, k - 1, false, cg_alpha, hvp_shift, st)) return rc;
     }
-    return fx_chain(&ml, fp, w, x, st);
+    return fx_chain(&ml, fp, w, x, k & 1, st);
   }
-  if (phase == BHG_CG_FX_GRAM) return fx_gram(&ml, fp, w, x, slab_all, const_all, scal_mine, st);
+  if (phase == BHG_CG_FX_GRAM) return fx_gram(&ml, fp, w, x, slab_all, const_all, scal_mine, k & 1, hvp_shift, st);
   BHG_REQUIRE(k == K - 1, "END belongs to the last iteration");
   return fx_step(&ml, fp, w, x, scal_all, k, true, cg_alpha, hvp_shift, st);
 }
