@@ -43,7 +43,7 @@ enum { S_RR_OLD = 0, S_PHP = 1, S_ALPHA = 2, S_RR_NEW = 3, S_BETA = 4, S_PP = 5 
   X(mlp_hoist) X(hoist_wgs) X(proj_step_alone) X(mlp_no_side) X(mlp_no_fuse) X(mlp_no_outer_all) X(neumann_side)             \
   X(hoist_staged_mink) X(proj_alpha_alone) X(proj_small_alone) X(outer_order_by_work) X(outer_no_pre) X(outer_stagger)       \
   X(mlp_no_fused_solve) X(cg_eager_p) X(cg_x_every_iter) X(neumann_p_every_iter) X(head_no_prefetch) X(cg_spin_limit)        \
-  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(alpha_in_hoist) X(graw_v2) X(wskp_ragged) X(pstep_v2) X(pstep_unroll) X(rnew_in_graw) X(graw_cols) X(lin_first) X(lin_prio) X(lin_nub) X(lin_order) X(lin_update_next) X(lin_withhold_beta) X(neumann_vnew) X(cg_rhs_direct) X(packed_prepare) X(lin_deep) X(graw_kloop) X(lin_update_in_head) X(xcd_pairs) X(headu_head_first)
+  X(packed_chain) X(packed_depth) X(packed_gram) X(proj_max_ratio) X(proj_ws_cap_mb) X(alpha_in_hoist) X(graw_v2) X(wskp_ragged) X(pstep_v2) X(pstep_unroll) X(rnew_in_graw) X(graw_cols) X(lin_first) X(lin_prio) X(lin_nub) X(lin_order) X(lin_update_next) X(lin_withhold_beta) X(neumann_vnew) X(cg_rhs_direct) X(packed_prepare) X(lin_deep) X(graw_kloop) X(lin_update_in_head) X(xcd_pairs) X(headu_head_first) X(fx_ksplit)
 enum DbgKey : int {
 #define BHG_DBG_ENUM(n) DBG_##n,
   BHG_DBG_KEYS(BHG_DBG_ENUM)

@@ -587,7 +587,12 @@ class _TorchMLPState:
                 Rd = self.masks[l - 1] * (self.deltas[l] @ Vs[l] + Rd @ self.Ws[l])
         return out
 
-    def mixed_coeff(self, dir_views):
+    def mixed_coeff(self, dir_views, solve=None):
+        if solve is not None:   # the factor-exchange solve: Rz(x) was accumulated, x = -cg_alpha * sum_k alpha_k p_k never existed
+            if solve is not getattr(self, "_fx_token", None):
+                raise RuntimeError("stale fused-solve token")
+            Rz = (-solve[1]) * self._fx["Rzx"].to(self.err.dtype)
+            return (self.err * Rz).sum(1) / self.B
         Rz, _ = self._r_forward(dir_views[0::2], dir_views[1::2])
         return (self.err * Rz).sum(1) / self.B
 
@@ -636,6 +641,149 @@ class _TorchMLPState:
 
     def cg_global_finish(self, layout, K, cg_alpha, keep_x=True):
         return True
+
+    # ---- global-batch CG, factor-exchange form: the math of csrc/mlp/fx.inc phase by phase, in ATen (tests: gloo, CPU).  Same slot
+    # conventions as HipMLPState: every phase writes THIS rank's row of the buffer the caller gathers after it.
+    def fx_supported(self, layout, world: int) -> bool:
+        return self.fused_supported(layout) and len(self.Ws) >= 3
+
+    def fx_buffers(self, world: int):
+        held = self.__dict__.setdefault("_fx_bufs", {})
+        if world not in held:
+            L, B = len(self.Ws), self.B
+            cf = sum(h.shape[1] for h in self.hs) * B + sum(d.shape[1] for d in self.deltas[1:]) * B
+            sf = sum(W.shape[0] for W in self.Ws) * B + sum(W.shape[0] for W in self.Ws[:-1]) * B
+            dev, dt = self.hs[0].device, self.hs[0].dtype
+            held[world] = {"const": torch.zeros(world, cf, dtype=dt, device=dev), "slab": torch.zeros(world, sf, dtype=dt, device=dev),
+                           "scal": torch.zeros(world, 3, dtype=torch.float64, device=dev), "xws": torch.zeros(1, dtype=torch.uint8, device=dev)}
+        return held[world]
+
+    def _fx_chain(self, st):
+        """The R-chain on products-with-the-batch (Gf_p, Gb_p) and the narrow slices of the direction; returns Rz, [Rh_l], [Rd_l]."""
+        L, Ws = len(self.Ws), self.Ws
+        Rhs, Rh = [], None
+        for l in range(L - 1):
+            Ra = st["Gf_p"][l] + st["p_c"][l]
+            if Rh is not None:
+                Ra = Ra + Rh @ Ws[l].t()
+            Rh = self.masks[l] * Ra
+            Rhs.append(Rh)
+        Rz = self.hs[L - 1] @ st["p_V"].t() + st["p_c"][L - 1] + Rh @ Ws[L - 1].t()
+        Rd = self.sd[:, None] * (self.p * Rz - self.p * (self.p * Rz).sum(1, keepdim=True))
+        Rds = [None] * L
+        Rds[L - 1] = Rd
+        for l in range(L - 1, 0, -1):
+            Gb = self.deltas[l] @ st["p_V"] if l == L - 1 else st["Gb_p"][l]
+            Rd = self.masks[l - 1] * (Gb + Rd @ Ws[l])
+            Rds[l - 1] = Rd
+        return Rz, Rhs, Rds
+
+    def cg_fx_phase(self, rhs, k, K, phase, world, rank, cg_alpha, shift):
+        L, B, G = len(self.Ws), self.B, world
+        bufs = self.fx_buffers(world)
+        dd = lambda a, b: float((a.double() * b.double()).sum())
+        f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+        wide = range(L - 1)
+        split_rows = lambda buf, widths: [list(torch.split(buf[g].view(B, -1), widths, 1)) for g in range(G)]
+        if phase == 0:      # BEGIN
+            bufs["const"][rank].copy_(torch.cat(self.hs + self.deltas[1:], 1).reshape(-1))
+            self._fx = {}
+            return
+        st = self._fx
+        if phase == 1:      # CHAIN
+            if k == 0:
+                widths = [h.shape[1] for h in self.hs] + [d.shape[1] for d in self.deltas[1:]]
+                rows = split_rows(bufs["const"], widths)
+                st["h_all"] = [torch.cat([rows[g][l] for g in range(G)], 0) for l in range(L)]
+                st["d_all"] = [None] + [torch.cat([rows[g][L + l - 1] for g in range(G)], 0) for l in range(1, L)]
+                vec = [t.detach() for t in rhs]
+                st["r_c"] = [vec[2 * l + 1].clone() for l in range(L)]
+                st["p_c"] = [t.clone() for t in st["r_c"]]
+                st["r_V"] = vec[2 * (L - 1)].clone()
+                st["p_V"] = st["r_V"].clone()
+                st["Gf_r"] = [self.hs[l] @ vec[2 * l].t() for l in wide]
+                st["Gb_r"] = [None] + [self.deltas[l] @ vec[2 * l] for l in range(1, L - 1)]
+                st["Gf_p"] = [t.clone() for t in st["Gf_r"]]
+                st["Gb_p"] = [None] + [t.clone() for t in st["Gb_r"][1:]]
+                st["rr_w"] = sum(dd(vec[2 * l], vec[2 * l]) for l in wide)
+                st["rp_w"] = st["pp_w"] = st["rr_w"]
+                st["Rzx"] = torch.zeros(B, self.Ws[-1].shape[0], dtype=torch.float64, device=self.hs[0].device)
+            else:
+                self._fx_step(bufs, G, cg_alpha, shift, last=False)
+            st["Rz"], st["Rhs"], st["Rds"] = self._fx_chain(st)
+            bufs["slab"][rank].copy_(torch.cat(st["Rds"] + st["Rhs"], 1).reshape(-1))
+            return
+        if phase == 2:      # GRAM
+            widths = [t.shape[1] for t in st["Rds"]] + [t.shape[1] for t in st["Rhs"]]
+            rows = split_rows(bufs["slab"], widths)
+            Rd_all = [torch.cat([rows[g][l] for g in range(G)], 0) for l in range(L)]
+            Rh_all = [torch.cat([rows[g][L + l] for g in range(G)], 0) for l in range(L - 1)]
+            h_all, d_all = st["h_all"], st["d_all"]
+            Gf_raw, Gb_raw = [], [None]
+            for l in wide:
+                t = (self.hs[l] @ h_all[l].t()) @ Rd_all[l]
+                if l >= 1:
+                    t = t + (self.hs[l] @ Rh_all[l - 1].t()) @ d_all[l]
+                Gf_raw.append(t / G)
+            for l in range(1, L - 1):
+                Gb_raw.append(((self.deltas[l] @ Rd_all[l].t()) @ h_all[l] + (self.deltas[l] @ d_all[l].t()) @ Rh_all[l - 1]) / G)
+            st["Gf_raw"], st["Gb_raw"] = Gf_raw, Gb_raw
+            st["raw_c"] = [Rd_all[l].sum(0) / G for l in range(L)]
+            st["raw_V"] = (Rd_all[L - 1].t() @ h_all[L - 1] + d_all[L - 1].t() @ Rh_all[L - 2]) / G
+
+            def share(Gf_u, Gb_u):
+                return sum(dd(st["Rds"][l], Gf_u[l]) for l in wide) + sum(dd(st["Rhs"][l - 1], Gb_u[l]) for l in range(1, L - 1))
+
+            bufs["scal"][rank].copy_(torch.tensor([share(st["Gf_r"], st["Gb_r"]), share(st["Gf_p"], st["Gb_p"]), share(Gf_raw, Gb_raw)],
+                                                  dtype=torch.float64))
+            return
+        self._fx_step(bufs, G, cg_alpha, shift, last=True)   # END
+
+    def _fx_step(self, bufs, G, cg_alpha, shift, last):
+        """k_fx_step: alpha from the gathered shares and the narrow slices; recurrences; beta (cg.py:42-53 on batch-sized quantities)."""
+        st, L = self._fx, len(self.Ws)
+        dd = lambda a, b: float((a.double() * b.double()).sum())
+        f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+        wide = range(L - 1)
+        tot = bufs["scal"].sum(0)
+        r_raw, p_raw, raw_raw = float(tot[0]) / G, float(tot[1]) / G, float(tot[2]) / G
+        p_raw_n = sum(dd(st["p_c"][l], st["raw_c"][l]) for l in range(L)) + dd(st["p_V"], st["raw_V"])
+        pp_n = sum(dd(t, t) for t in st["p_c"]) + dd(st["p_V"], st["p_V"])
+        rr_n = sum(dd(t, t) for t in st["r_c"]) + dd(st["r_V"], st["r_V"])
+        rr = st["rr_w"] + rr_n
+        den = float(cg_alpha) * ((p_raw + p_raw_n) + float(shift) * (st["pp_w"] + pp_n))
+        alpha = float(f32(rr) / f32(den))
+        st["Rzx"] += alpha * st["Rz"].double()
+        if last:
+            return
+        for l in range(L):
+            st["r_c"][l] = st["r_c"][l] - alpha * (st["raw_c"][l] + shift * st["p_c"][l])
+        st["r_V"] = st["r_V"] - alpha * (st["raw_V"] + shift * st["p_V"])
+        for l in wide:
+            st["Gf_r"][l] = st["Gf_r"][l] - alpha * (st["Gf_raw"][l] + shift * st["Gf_p"][l])
+        for l in range(1, L - 1):
+            st["Gb_r"][l] = st["Gb_r"][l] - alpha * (st["Gb_raw"][l] + shift * st["Gb_p"][l])
+        rHp = r_raw + shift * st["rp_w"]
+        pHp = p_raw + shift * st["pp_w"]
+        HpHp = raw_raw + 2.0 * shift * p_raw + shift * shift * st["pp_w"]
+        rr_w1 = st["rr_w"] - 2.0 * alpha * rHp + alpha * alpha * HpHp
+        rp_w1 = st["rp_w"] - alpha * pHp
+        rr_new = rr_w1 + sum(dd(t, t) for t in st["r_c"]) + dd(st["r_V"], st["r_V"])
+        beta = float(f32(rr_new) / f32(rr))
+        for l in range(L):
+            st["p_c"][l] = st["r_c"][l] + beta * st["p_c"][l]
+        st["p_V"] = st["r_V"] + beta * st["p_V"]
+        for l in wide:
+            st["Gf_p"][l] = st["Gf_r"][l] + beta * st["Gf_p"][l]
+        for l in range(1, L - 1):
+            st["Gb_p"][l] = st["Gb_r"][l] + beta * st["Gb_p"][l]
+        st["pp_w"] = rr_w1 + 2.0 * beta * rp_w1 + beta * beta * st["pp_w"]
+        st["rp_w"] = rr_w1 + beta * rp_w1
+        st["rr_w"] = rr_w1
+
+    def cg_fx_finish(self, layout, K, cg_alpha):
+        self._fx_token = ("cg_fx", float(cg_alpha))
+        return self._fx_token
 
 
 class LogisticRegressionL2:

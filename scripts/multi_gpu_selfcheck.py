@@ -11,7 +11,7 @@ tests/test_distributed_cpu.py pin):
   replica    the reference's DDP mode (problem.py:220-224, cg.py:58-63): every rank solves ITS problem; .grad after the sync=True hop
              = the mean over ranks of the local hypergradients — closed-form upper net with the deferred all-reduce
              (SigmoidMLPWeightNet(average_over=True, overlap=True)) and, second, the DDP wrapper with nothing declared
-  global     cg_global, one-pass fused form and sharded form (opaque HVP): equal on every rank, equal to the one-rank solve of the
+  global     cg_global, factor-exchange form, one-pass fused form and sharded form (opaque HVP): equal on every rank, equal to the one-rank solve of the
              concatenated batch
   exchange   betty_amd.distributed.exchange_async: one flat all-reduce = the mean
 and reports the measured latency of the M-float all-reduce.  Nothing here is a throughput claim."""
@@ -121,8 +121,15 @@ def worker(args):
 
         want_g = [t.clone() for t in hg.cg(vmean, attach(x, y, True), prevg, False)]
         sl = slice(rank * B, (rank + 1) * B)
-        for form, structured in (("one-pass", True), ("sharded", False)):
+        import betty_amd.global_hvp as gh
+
+        for form, structured in (("factor-exchange", True), ("one-pass", True), ("sharded", False)):
+            gh.GLOBAL_FORM = {"factor-exchange": "auto", "one-pass": "one_pass", "sharded": "sharded"}[form]
+            n_fx, n_op = gh.FX_STATS["solves"], gh.ONE_PASS_STATS["solves"]
             got = cg_global(vecs[rank], attach(x[sl], y[sl], structured), prevg, False)
+            took = (gh.FX_STATS["solves"] - n_fx, gh.ONE_PASS_STATS["solves"] - n_op)
+            if took != {"factor-exchange": (1, 0), "one-pass": (0, 1), "sharded": (0, 0)}[form]:
+                raise Fail(f"global mode ({form}): another form ran (factor-exchange, one-pass solves = {took})")
             e = rel(got, want_g)
             if not e <= 1e-4:
                 raise Fail(f"global mode ({form}): {e:.2e} from the one-rank solve of the concatenated batch")
@@ -147,7 +154,7 @@ def worker(args):
             print(f"SELFCHECK OK: world {world} over {args.backend}, devices " +
                   ", ".join(f"{d['name']}@{d['pci']}" for d in census["devices"]) +
                   (f"; all-reduce of 301 floats {lat:.1f} us" if lat else "") + "; replica (deferred all-reduce, DDP wrapper), global "
-                  "(one-pass, sharded), flat exchange: all equal to the one-process expectations", flush=True)
+                  "(factor-exchange, one-pass, sharded), flat exchange: all equal to the one-process expectations", flush=True)
         verdict = 0.0
     except Fail as f:
         reason = str(f)

@@ -435,8 +435,10 @@ def _global_worker(rank, world, port, case_name, structured, q):
 
         from betty_amd import Config
         from betty_amd.backend import use_backend
+        import betty_amd.global_hvp as gh
         from betty_amd.global_hvp import cg_global
 
+        gh.GLOBAL_FORM = {"onepass": "one_pass", "sharded": "sharded", "factor": "auto"}.get(structured, "auto")
         case = zoo.CASE_BY_NAME[case_name]
         inputs, _ = load_golden(case.family)
         full_inputs = dict(inputs)
@@ -454,13 +456,13 @@ def _global_worker(rank, world, port, case_name, structured, q):
         with use_backend(CpuCheckerBackend()):
             curr, prev, vector = zoo.build_case(case, mine, Config)
             if structured:
-                zoo.attach_mlp_structure(curr, case.family, impl="torch", fused=structured == "onepass")
+                zoo.attach_mlp_structure(curr, case.family, impl="torch", fused=structured in ("onepass", "factor"))
             got = cg_global(vector, curr, prev, False)
             got = torch.cat([t.reshape(-1) for t in got]).detach()
             # sync=True: lands in .grad through backward (no DDP wrapper here: the local share of the mean)
             curr2, prev2, vector2 = zoo.build_case(case, mine, Config)
             if structured:
-                zoo.attach_mlp_structure(curr2, case.family, impl="torch", fused=structured == "onepass")
+                zoo.attach_mlp_structure(curr2, case.family, impl="torch", fused=structured in ("onepass", "factor"))
             ret = cg_global(vector2, curr2, prev2, True)
             local = torch.cat([p.grad.reshape(-1) for p in prev2.trainable_parameters()]).detach()
             gathered = [torch.zeros_like(local) for _ in range(world)]
@@ -475,6 +477,9 @@ def _global_worker(rank, world, port, case_name, structured, q):
         from betty_amd.global_hvp import ONE_PASS_STATS
         K = int(curr.config.cg_iterations)
         stats = (ONE_PASS_STATS["solves"], ONE_PASS_STATS["scalar_all_reduces"], ONE_PASS_STATS["residual_all_reduces"], K)
+        if structured == "factor":
+            fx = gh.FX_STATS
+            stats = (fx["solves"], fx["const_gathers"], fx["slab_gathers"], fx["scal_gathers"], fx["rhs_all_reduces"], ONE_PASS_STATS["solves"], K)
         q.put((rank, rel, rel_sync, ret is None, same, stats))
     finally:
         dist.destroy_process_group()
@@ -482,7 +487,7 @@ def _global_worker(rank, world, port, case_name, structured, q):
 
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("case_name,structured", [("reweight_cg20", False), ("reweight_cg20", "sharded"), ("reweight_cg20", "onepass"),
-                                                  ("logreg_cg5", False), ("logreg_cg3_a01", False)])
+                                                  ("reweight_cg20", "factor"), ("logreg_cg5", False), ("logreg_cg3_a01", False)])
 def test_global_hvp_cg_matches_single_process_oracle(world, case_name, structured):
     """Sharded x, r, p; reduce-scatter of the data-parallel HVPs; partial-sum all-reduces between the CG phases;
     all-gather of the direction: the result equals the reference's cg on the concatenated batch.
@@ -501,6 +506,12 @@ def test_global_hvp_cg_matches_single_process_oracle(world, case_name, structure
         assert rel <= 1e-4, (rank, rel)            # north_star tolerance vs the single-process reference algorithm
         assert rel_sync <= 1e-4, (rank, rel_sync)  # sync=True: mean over ranks of what landed in .grad
         assert returned_none and same
+        if structured == "factor":
+            # round 6, the factor-exchange form (csrc/mlp/fx.inc's protocol, its math in ATen here): per solve ONE gather of the constants,
+            # K gathers of the batch-sized factors, K gathers of three fp64 shares, the right-hand side's mean — nothing else; two solves ran
+            solves, n_const, n_slab, n_scal, n_rhs, one_pass, K = stats
+            assert (solves, n_const, n_slab, n_scal, n_rhs, one_pass) == (2, 2, 2 * K, 2 * K, 2, 0), stats
+            continue
         solves, n_scalar, n_resid, K = stats
         if structured == "onepass":                # two solves ran (sync False / True)
             assert (solves, n_scalar, n_resid) == (2, 2 * K, 2 * (K - 1)), stats

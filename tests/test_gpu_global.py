@@ -303,6 +303,32 @@ def test_emulated_ranks_exchanging_factors_match_the_one_rank_solver_on_the_conc
     assert rel <= 1e-4, rel
 
 
+@pytest.mark.parametrize("ks", [2, 4])
+def test_k_split_gram_slabs_are_consumed_as_a_concatenated_reduction(ks, bhg_debug):
+    """Measurement arm fx_ksplit: T_l / E_l leave ks K-split slabs, never summed — the G(raw) product runs over [S | T_0 | .. | T_{ks-1}]
+    against [Rd ; delta ; .. ; delta] (csrc/mlp/fx.inc: fx_plan).  Two emulated ranks against the one-rank solver; and against the
+    default arm to summation noise."""
+    dims, B, K, alpha, world, ridge = [256, 384, 128, 10], 100, 6, 1.0, 2, 0.05
+    inner, prev, x, y, _ = _problem(dims, world * B, ridge, 31337, K, False)
+    g = torch.Generator().manual_seed(99)
+    vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+    vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
+    outs = {}
+    for arm in (None, ks):
+        if arm is None:
+            bhg_debug.delenv("fx_ksplit")
+        else:
+            bhg_debug.setenv("fx_ksplit", str(arm))
+        inners = [copy.deepcopy(inner) for _ in range(world)]   # fresh modules: fresh buffers, sized for this arm
+        parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
+        outs[arm], _ = _emulate_fx(parts, prev, vecs, K, alpha)
+        rel, _ = rel_err([t.cpu().numpy() for t in outs[arm]], [t.cpu().numpy() for t in want])
+        assert rel <= 1e-4, (arm, rel)
+    rel, _ = rel_err([t.cpu().numpy() for t in outs[ks]], [t.cpu().numpy() for t in outs[None]])
+    assert rel <= 2e-5, rel
+
+
 # ---- two real processes, real collectives (gloo stages the device buffers through the host), one GPU ------------------------------
 def _two_process_worker(rank, world, port, q, form="one_pass"):
     import sys
