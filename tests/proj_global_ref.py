@@ -2,8 +2,8 @@
 solve for the weighted-CE ReLU-MLP structure in which the ranks exchange BATCH-SIZED FACTORS instead of the N-sized residual
 (round-3 VERDICT item 8), restated in ATen so that its math and its communication pattern can be checked on CPU — gloo, world
 size 2 / 4 — against the reference's cg() run in ONE process on the concatenated batch (cg.py:25-68).  The HIP kernels of this
-form do not exist yet; the kernels of the one-rank projected solver implement the same
-recurrences with G = 1.
+form exist since round 6 (csrc/mlp/fx.inc, bhg_mlp_cg_fx_phase; DESIGN 3.22 — tested in tests/test_gpu_global.py); the kernels of the
+one-rank projected solver implement the same recurrences with G = 1.
 
 Setting.  G ranks, rank g holds B_g samples; the inner loss is the mean over the ranks of the local weighted-CE means, so
 H = mean_g H_g (+ shift I), exactly the global-batch mode of betty_amd/global_hvp.py.  Every weight-shaped output of H_g v is an
