@@ -311,7 +311,9 @@ def parity_check(args, device, jvp_fn, curr, prev, vector, K):
     import numpy as np
 
     key = {("cg", 20): "cg20", ("neumann", 10): "neumann10"}.get((args.algo, K))
-    if key is None or args.mode != "replica" or not os.path.exists(GOLDEN):
+    # (--mode global at world size 1 solves the very instance the goldens hold — seed 0, the whole batch on one rank: the call site runs
+    #  this check at world size 1 only, so the global-batch forms are held to the same goldens)
+    if key is None or not os.path.exists(GOLDEN):
         return None
     gold = np.load(GOLDEN)
 

@@ -246,3 +246,67 @@ def test_the_shipped_library_on_the_metric_instance_against_the_fp64_truth():
         print(f"cfg2 metric seed=0 {aname} libbhg.so (product): vs fp64 truth {e64:.2e}, vs reference-CPU fp32 {e32:.2e} (its own spread {spread:.2e})")
         assert e64 <= RTOL, (aname, e64)
         assert e32 <= max(RTOL, 3.0 * spread), (aname, e32, spread)
+
+
+# ---- round 6: the global-batch solver in its factor-exchange form (csrc/mlp/fx.inc) against the same goldens ---------------------------
+@pytest.fixture(scope="module")
+def one_rank_group():
+    import socket
+
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        yield None
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        yield None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", WELL_SEEDS)
+def test_the_factor_exchange_form_matches_the_reference_cpu_golden_at_full_size(seed, one_rank_group):
+    """Config(type="cg_global") on the metric workload's shapes, product library: at world size 1 (every phase kernel runs, no collective)
+    and with the batch of 100 split over TWO emulated ranks of 50 (rectangular Gram blocks, the gathers done by hand) — the reference's
+    own CPU output for the WHOLE batch is the oracle of both (cg.py:8-70 on the concatenated batch), rtol 1e-4 against fp32 and fp64."""
+    import test_gpu_global as tg
+    from betty_amd import _native
+    from betty_amd import hypergradient as hg
+    from betty_amd.global_hvp import FX_STATS
+
+    assert not _native.is_ab() and os.path.basename(_native.current_lib_path()) == "libbhg.so"
+    algo, K = mk.ALGOS["cg20"]
+    want32, want64 = GOLD[f"well/{seed}/cg20/fp32"], GOLD[f"well/{seed}/cg20/fp64"]
+    dev = torch.device("cuda:0")
+    curr, prev, vector = bench.build(dev, seed, K=K, algo=algo, ridge=mk.RIDGE_WELL)
+    bench.declare_structure(curr, "hip")
+    n0 = FX_STATS["solves"]
+    got = [t.detach().cpu().numpy() for t in hg.jvp_fn_mapping["cg_global"](vector, curr, prev, False)]
+    assert FX_STATS["solves"] == n0 + 1, "the factor-exchange form must be the one that ran"
+    e32, e64 = rel(got, want32), rel(got, want64)
+    print(f"cfg2 well seed={seed} cg20 factor exchange, world 1: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert e32 <= RTOL and e64 <= RTOL, (seed, e32, e64)
+    # two emulated ranks: the same weights and right-hand side, half of the batch each
+    parts, vecs, prev0 = [], [], None
+    for r in range(2):
+        c, p_, v = bench.build(dev, seed, K=K, algo=algo, ridge=mk.RIDGE_WELL)
+        x, y = c.cur_batch
+        h = x.shape[0] // 2
+        c.cur_batch = (x[r * h:(r + 1) * h].contiguous(), y[r * h:(r + 1) * h].contiguous())
+        if prev0 is None:
+            prev0 = p_
+        c._loss_fn = bench.make_loss(prev0, mk.RIDGE_WELL)   # (both ranks read ONE upper problem: the same meta-weight-net object)
+        bench.declare_structure(c, "hip")
+        parts.append(c)
+        vecs.append(v)
+    got2, _ = tg._emulate_fx(parts, prev0, vecs, K, 1.0)
+    e32, e64 = rel([t.detach().cpu().numpy() for t in got2], want32), rel([t.detach().cpu().numpy() for t in got2], want64)
+    print(f"cfg2 well seed={seed} cg20 factor exchange, 2 emulated ranks x 50 samples: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert e32 <= RTOL and e64 <= RTOL, (seed, e32, e64)
