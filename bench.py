@@ -530,6 +530,9 @@ def main():
     ap.add_argument("--global-form", choices=["auto", "one_pass", "sharded"], default="auto",
                     help="--mode global: auto = the factor-exchange form (batch-sized all-gathers, fully projected solver) when the structure "
                     "takes it, else one-pass, else sharded; one_pass / sharded pin the older forms")
+    ap.add_argument("--fx-always-gather", action="store_true",
+                    help="--mode global at world size 1: issue the factor-exchange form's all-gathers all the same (what the collectives cost "
+                    "an iteration before a byte crosses a link: host calls, the collective's stream / hardware queue)")
     ap.add_argument("--mode", choices=["replica", "global"], default="replica",
                     help="replica = the reference's DDP mode (every rank solves its own problem; default).  global = ONE inner "
                     "problem whose batch is spread over the ranks: data-parallel HVP, sharded CG state (betty_amd/global_hvp.py)")
@@ -637,6 +640,7 @@ def main():
         import betty_amd.global_hvp as _ghvp
 
         _ghvp.GLOBAL_FORM = args.global_form
+        _ghvp.FX_ALWAYS_GATHER = bool(args.fx_always_gather)
     else:
         curr, prev, vector = build(device, seed=rank, ddp=world > 1, K=K, algo=args.algo)
         jvp_fn = hg.jvp_fn_mapping[args.algo]

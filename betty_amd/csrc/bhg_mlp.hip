@@ -130,6 +130,7 @@ void launch_gemm_wsk(const WskArgs& a_in, hipStream_t st, bool staged = false) {
 #undef BHG_WSK
 }
 
+#ifdef BHG_AB
 void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // blocks: the tiles (+ 1 with do_alpha)
   const int lds = (int)(sizeof(float) * kWslWaveFloats * kWskWaves);
   static bool attr_done = false;
@@ -146,6 +147,7 @@ void launch_wsk_group(const WskGroupArgs& g, int blocks, hipStream_t st) {   // 
 #endif
   hipLaunchKernelGGL(k_wsk_group<2>, dim3(blocks), dim3(64 * kWskWaves), lds, st, g);
 }
+#endif
 
 // Grouped launch on packed operands (wskp.inc).  Block tables are rounded up to multiples of 8 so that a problem's tile t keeps
 // t % 8 == blockIdx.x % 8 (the XCD it runs on).
@@ -807,6 +809,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
   // the forward product through W_1; E_l and T_{l+1} with the backward product through W_l), so it ends when they do
   auto tsplit = [&](int K) { return gram_in_chain ? 1 : gram_ksplit(K); };
   auto esplit = [&](int l, int K) { (void)l; return gram_in_chain ? 1 : gram_ksplit(K); };
+  (void)tsplit; (void)esplit; (void)sd_in_chain;   // (read by the measurement build's Gram / G(raw) launches only)
   if (hp && do_chain) {
     float* hbase = cm.ws->hoist;
     HoistArgs ha{};
@@ -935,8 +938,13 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           else if (U == 1) hipLaunchKernelGGL(k_pstep<1>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
 #endif
           else hipLaunchKernelGGL(k_pstep<4>, dim3(rblk + sgrid), dim3(256), 0, st, ps);
-        } else
-        hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
+        } else {
+#ifdef BHG_AB
+          hipLaunchKernelGGL(k_proj_step, dim3(rblk + sgrid), dim3(256), 0, st, g);
+#else
+          BHG_REQUIRE(false, "internal: every plan of the product takes k_pstep (<= 16 small tensors, the packed closing launch)");
+#endif
+        }
       } else {
         hipLaunchKernelGGL(k_proj_update, dim3(rblk), dim3(256), 0, st, pa);
       }
@@ -1366,6 +1374,12 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
     }
     if (proj_iter) {   // projected CG: G(raw) of this iteration for the next one's recurrences
       float* hbase = cm.ws->hoist;
+#ifndef BHG_AB
+      // (product: the Gram products rode in the chain launches and the closing launch is k_graw / k_grawk in EVERY plan — the hoist plan
+      //  carves the packed operands whenever it is taken, the padded batch is a multiple of 128; round 3's Gram launch and its k_hoist
+      //  form of the G(raw) products live on in the measurement build)
+      BHG_REQUIRE(graw2, "internal: the packed closing launch must apply");
+#else
       WskGroupArgs g{};
       int blk = 0;
       for (int l = 1; l + 1 < L && !gram_in_chain; ++l) {
@@ -1383,10 +1397,11 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
           g.blk0[g.n++] = blk; blk += (Bp / 32) * (Bp / 32);
         }
       }
-      const bool full = cg && cm.proj >= 2;   // fully projected CG: r.raw, p.raw, raw.raw from batch-sized arrays (k_proj_step)
       g.blk0[g.n] = blk;
       if (alpha_in_gram) { g.do_alpha = 1; g.alpha = aa; }
       if (blk + (alpha_in_gram ? 1 : 0) > 0) launch_wsk_group(g, blk + (alpha_in_gram ? 1 : 0), st);
+#endif
+      const bool full = cg && cm.proj >= 2;   // fully projected CG: r.raw, p.raw, raw.raw from batch-sized arrays (k_pstep)
       SmallOutArgs so{};
       int small_blocks = 0;
       if (small_in_graw) {   // the small slices' outputs (head weight, biases) with their CG epilogue: block classes of the closing launch
@@ -1467,6 +1482,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
         } else if (cg) hipLaunchKernelGGL(k_graw<FUSE_CG>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
         else hipLaunchKernelGGL(k_graw<FUSE_NEUMANN>, dim3(gb), dim3(64 * kGrawWaves), 0, st, ka);
       }
+#ifdef BHG_AB
       HoistArgs ga{};
       int gblk = 0;
       const int ntm = Bp / kTM;
@@ -1508,6 +1524,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       if (graw2) {
       } else if (cg) hipLaunchKernelGGL(k_hoist<FUSE_CG>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
       else hipLaunchKernelGGL(k_hoist<FUSE_NEUMANN>, dim3(gblk + ga.dot_blocks + ga.small_blocks), dim3(256), 0, st, ga);
+#endif
     }
     // one launch for all outputs when every MFMA layer is all-interior
     // (fully projected CG: the MFMA layers' slices of r and p are not materialised — only the small slices' blocks launch)
@@ -1567,6 +1584,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       for (int l = L - 1; l >= 0; --l) launch_outer(l, st);
       launch_bias(st);
     }
+#ifdef BHG_AB
     if (proj_full && cg && !proj_step_merged()) {   // r'.r', beta, p'.p' of the iteration from batch-sized quantities (k_proj_scalars)
       BHG_REQUIRE(all_fast || small_in_graw, "the fully projected CG solver needs the single-launch output path");
       ProjScalArgs sa{};
@@ -1587,6 +1605,7 @@ int run_chain(const bhg_mlp* m, const void* const* dir, const ChainMode& cm, hip
       const int sgrid = small_total > 0 ? (small_total + kThreads - 1) / kThreads : 1;
       hipLaunchKernelGGL(k_proj_scalars, dim3(sgrid), dim3(kThreads), 0, st, sa);
     }
+#endif
     BHG_HIP_CHECK(hipGetLastError());
     return BHG_OK;
   }
@@ -1820,9 +1839,11 @@ static int cg_iteration(CgCtx* c, int k, int gphase, double* php, double inv_wor
   cm.rhs = c->rhs;
   if (int rc = run_chain(m, c->dir, cm, st)) return rc;
   if (timed) BHG_HIP_CHECK(hipEventRecord(tb, st));
+#ifdef BHG_AB   // (key cg_eager_p; the product's direction is always lazy)
   if (!lazy && k + 1 < K)   // the direction is not used after the last iteration (the reference computes and drops it)
     hipLaunchKernelGGL(k_cg_pdir, dim3(c->pgrid), dim3(kThreads), 0, st, c->chunks_dev, c->n_chunks, (const float*)c->r, c->p,
                        (const double*)w.partRR[(k + 1) & 1], w.nRR, w.partPP, c->scal);
+#endif
   if (timed_it) BHG_HIP_CHECK(hipEventRecord(td, st));
   return BHG_OK;
 }

@@ -152,6 +152,8 @@ def _cg_global_one_pass(vector, prev, sync, provider, be, full, K: int, alpha: f
 # GLOBAL_FORM: "auto" = factor exchange whenever the structure takes it and the caller does not ask for x (else one-pass, else sharded);
 # "one_pass" / "sharded" pin the older forms (tests, bench.py --global-form).
 GLOBAL_FORM = "auto"
+FX_ALWAYS_GATHER = False   # True: issue the all-gathers at world size 1 as well (scripts/multi_gpu_selfcheck.py: RCCL's in-place
+                           # all_gather_into_tensor on the very buffers, where a one-GPU box can reach it)
 FX_STATS = {"solves": 0, "const_gathers": 0, "slab_gathers": 0, "scal_gathers": 0, "rhs_all_reduces": 0,
             "slab_bytes_per_rank": 0, "const_bytes_per_rank": 0, "scal_bytes_per_rank": 0}   # test / measurement hook
 
@@ -193,17 +195,18 @@ def _cg_global_factor_exchange(vector, prev, sync, provider, be, full, K: int, a
     FX_STATS["slab_bytes_per_rank"] = bufs["slab"].shape[1] * 4
     FX_STATS["const_bytes_per_rank"] = bufs["const"].shape[1] * 4
     FX_STATS["scal_bytes_per_rank"] = bufs["scal"].shape[1] * 8
+    gather = G > 1 or FX_ALWAYS_GATHER
     provider.cg_fx_phase(rhs, 0, K, _native.BHG_CG_FX_BEGIN, G, g, alpha)
-    if G > 1:
+    if gather:
         all_gather_slots(bufs["const"], g, group)
         FX_STATS["const_gathers"] += 1
     for k in range(K):
         provider.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_CHAIN, G, g, alpha)
-        if G > 1:
+        if gather:
             all_gather_slots(bufs["slab"], g, group)
             FX_STATS["slab_gathers"] += 1
         provider.cg_fx_phase(rhs, k, K, _native.BHG_CG_FX_GRAM, G, g, alpha)
-        if G > 1:
+        if gather:
             all_gather_slots(bufs["scal"], g, group)
             FX_STATS["scal_gathers"] += 1
     provider.cg_fx_phase(rhs, K - 1, K, _native.BHG_CG_FX_END, G, g, alpha)

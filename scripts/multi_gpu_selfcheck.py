@@ -125,6 +125,7 @@ def worker(args):
 
         for form, structured in (("factor-exchange", True), ("one-pass", True), ("sharded", False)):
             gh.GLOBAL_FORM = {"factor-exchange": "auto", "one-pass": "one_pass", "sharded": "sharded"}[form]
+            gh.FX_ALWAYS_GATHER = True   # (world size 1 over RCCL: the in-place all-gathers are issued all the same)
             n_fx, n_op = gh.FX_STATS["solves"], gh.ONE_PASS_STATS["solves"]
             got = cg_global(vecs[rank], attach(x[sl], y[sl], structured), prevg, False)
             took = (gh.FX_STATS["solves"] - n_fx, gh.ONE_PASS_STATS["solves"] - n_op)
