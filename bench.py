@@ -795,6 +795,13 @@ def main():
         solver_form = ("projected Neumann solver (libbhg default without an accumulator vector): G(v') = G(v) - alpha (G(raw) + shift G(v)) "
                        "through B x B Gram matrices, nothing N-sized after the first iteration, closing half pass for Rz(v_K); "
                        "bhg_mlp_proj_iterations = %d" % n_proj) if n_proj == args.steps * K else "classic chain"
+    if args.mode == "global" and args.hvp == "analytic":
+        try:   # what the library's plan says this descriptor takes under Config(type="cg_global") (host logic only)
+            pd = _native.plan_describe([p_.shape[1] for p_ in list(curr.parameters())[0::2]] + [list(curr.parameters())[-1].shape[0]],
+                                       int(curr.cur_batch[0].shape[0]), "cg", args.keep_solution)
+            solver_form = "global-batch CG, %s form (bhg_mlp_plan_describe); requested --global-form %s" % (pd["global_form"], args.global_form)
+        except Exception as exc:   # noqa: BLE001
+            solver_form = f"global-batch CG (plan description unavailable: {type(exc).__name__})"
     # Region 2 — the same `steps` steps again with HIP events around the launch groups (recorded inside libbhg on the
     # launch stream) for the roofline objects.  Kept out of region 1 because every event record costs the stream a
     # ~4 us bubble (measured: 210 vs 192 steps/s with 4 records per CG iteration); its throughput is reported as

@@ -2413,10 +2413,15 @@ int bhg_mlp_plan_describe(const bhg_mlp* m, int algo, int keep_solution, char* b
     for (int l = 0; l + 1 < L; ++l) gram += (size_t)m->Bp * m->Bp * (l >= 1 ? (2 + 2 * kGramSplitMax + 6) : 2);
   const int n = snprintf(buf, buf_bytes,
                          "algo=%s keep_solution=%d fused=%d form=\"%s\" hoist=%d proj_level=%d lin=%d lin_head=%d upd_first=%d closing=%s "
-                         "plan_ok=%d proj_ok=%d lin_ok=%d hoist_products=%d hoist_wgs=%d gram_floats=%zu fused_ws_bytes=%zu narrow_head=%d packed_prepare=%d",
+                         "plan_ok=%d proj_ok=%d lin_ok=%d hoist_products=%d hoist_wgs=%d gram_floats=%zu fused_ws_bytes=%zu narrow_head=%d packed_prepare=%d "
+                         "global_form=%s fx_slab_bytes=%zu fx_ws_bytes_world8=%zu",
                          algo == 0 ? "cg" : "neumann", keep_solution ? 1 : 0, fused ? 1 : 0, form, hoist, proj_level, lin, lin_head, upd_first, closing,
                          hp.ok ? 1 : 0, hp.proj_ok ? 1 : 0, hp.lin_ok ? 1 : 0, hp.n, hp.ok ? hp.blk0[hp.n] : 0, gram,
-                         fused ? bhg_mlp_fused_ws_bytes(m) : (size_t)0, narrow_head(m) ? 1 : 0, bhg_mlp_supports_packed_prepare(m));
+                         fused ? bhg_mlp_fused_ws_bytes(m) : (size_t)0, narrow_head(m) ? 1 : 0, bhg_mlp_supports_packed_prepare(m),
+                         // Config(type="cg_global"): the form of the global-batch solve (round 6: factor exchange whenever the projected plan is
+                         // taken and the caller does not ask for x; else the one-pass form; without a fused solver the sharded form)
+                         (algo == 0 && !keep_solution && bhg_mlp_fx_supported(m, 1)) ? "factor-exchange" : (fused ? "one-pass" : "sharded"),
+                         sizeof(float) * bhg_mlp_fx_slab_floats(m), bhg_mlp_fx_ws_bytes(m, 8));
   BHG_REQUIRE(n > 0 && (size_t)n < buf_bytes, "output buffer too small");
   return BHG_OK;
 }

@@ -60,6 +60,15 @@ def test_shape_to_form(dims, B, cg_free, cg_x, neu_free, neu_acc, closing):
         assert d["gram_floats"] == 0, "no Gram region is carved when the plan does not project"
     # the packed once-per-step passes go with the hoisted plan
     assert d["packed_prepare"] == d["plan_ok"]
+    # round 6: the global-batch solve (Config(type="cg_global")) exchanges batch-sized factors exactly where the plan projects and the
+    # caller does not ask for x; the slab the ranks gather per iteration holds Rd_0 .. Rd_{L-1}, Rh_0 .. Rh_{L-2} of the padded batch
+    assert d["global_form"] == ("factor-exchange" if d["proj_level"] == 2 else "one-pass")
+    assert got[("cg", True)]["global_form"] == "one-pass"
+    if d["proj_level"] == 2:
+        Bp = (B + 127) // 128 * 128
+        assert d["fx_slab_bytes"] >= 4 * Bp * (sum(dims[1:]) + sum(dims[1:-1])) and d["fx_ws_bytes_world8"] > 0
+    else:
+        assert d["fx_slab_bytes"] == 0 and d["fx_ws_bytes_world8"] == 0
 
 
 def test_wide_head_has_no_fused_solver_and_the_twin_rounds_widths_up():
