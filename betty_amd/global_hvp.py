@@ -191,6 +191,13 @@ def _cg_global_factor_exchange(vector, prev, sync, provider, be, full, K: int, a
     rhs = full.views(st.v, vector)
     state = provider._state
     bufs = state.fx_buffers(G)
+    if G > 1 and not bufs.get("checked"):
+        # the Gram blocks are [Bp x G Bp] with the SAME B valid rows in every rank's slot: checked once per set of buffers
+        nb = torch.tensor([float(state.B), -float(state.B)], device=st.v.device if _backend_name(group) == "nccl" else "cpu")
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
+        if float(nb[0]) != -float(nb[1]):
+            raise ValueError(f"cg_global (factor-exchange form): every rank must hold the same batch size; got between {-int(nb[1])} and {int(nb[0])}")
+        bufs["checked"] = True
     FX_STATS["solves"] += 1
     FX_STATS["slab_bytes_per_rank"] = bufs["slab"].shape[1] * 4
     FX_STATS["const_bytes_per_rank"] = bufs["const"].shape[1] * 4

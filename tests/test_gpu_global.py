@@ -222,6 +222,22 @@ def test_factor_exchange_at_world_size_one_is_the_one_rank_solver(dims, B, K, al
     assert rel <= 5e-5, rel
 
 
+@pytest.mark.parametrize("K,ridge", [(1, 0.05), (2, 0.0), (3, 0.0)])
+def test_factor_exchange_edge_cases_one_iteration_and_no_ridge(K, ridge, one_rank_group):
+    """K = 1 (BEGIN, one CHAIN / GRAM pair, END: the closing step is also the first) and a loss without ridge (the shift terms of every
+    recurrence vanish): against the one-rank solver."""
+    from betty_amd.global_hvp import FX_STATS
+
+    dims, B = [256, 384, 128, 10], 100
+    inner, prev, x, y, vec = _problem(dims, B, ridge, 4711 + K, K, False)
+    want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vec, _attach(inner, prev, x, y, ridge, K, False), prev, False)]
+    n0 = FX_STATS["solves"]
+    got = [t.clone() for t in hg.jvp_fn_mapping["cg_global"](vec, _attach(inner, prev, x, y, ridge, K, False), prev, False)]
+    assert FX_STATS["solves"] == n0 + 1
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 2e-5, rel
+
+
 def _emulate_fx(parts, prev, vecs, K, alpha):
     """Drive betty_amd/global_hvp.py::_cg_global_factor_exchange for len(parts) ranks living in this process: every all-gather is a
     copy of rank r's row into the other ranks' buffers."""
@@ -295,6 +311,41 @@ def test_emulated_ranks_exchanging_factors_match_the_one_rank_solver_on_the_conc
             inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
             parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
             got, _ = _emulate_fx(parts, prev, vecs, K, alpha)
+        if not any("ReLU-kink" in str(w.message) for w in caught):
+            break
+    else:
+        pytest.fail("four instances in a row sat on a ReLU kink")
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 1e-4, rel
+
+
+SWEEP = [  # dims, per-rank batch, K, cg_alpha, world — odd world sizes (1 / G is not a power of two), batches beyond one row tile of 128
+    # (Bp = 256, 384), ragged batches, three to five layers, heads of 3 .. 100 classes
+    ([256, 384, 128, 10], 37, 5, 1.0, 3), ([256, 384, 128, 3], 130, 4, 1.0, 2), ([512, 256, 128, 64, 10], 200, 5, 0.5, 2),
+    ([384, 256, 256, 64, 100], 64, 4, 1.0, 3), ([512, 384, 256, 256, 128, 10], 60, 4, 1.0, 2), ([512, 512, 256, 256, 128, 10], 300, 3, 1.0, 1),
+    ([1024, 512, 256, 16], 96, 6, 0.25, 5), ([256, 384, 128, 10], 128, 7, 1.0, 6),
+]
+
+
+@pytest.mark.parametrize("dims,B,K,alpha,world", SWEEP, ids=lambda v: str(v))
+def test_factor_exchange_sweep_of_shapes_batches_and_world_sizes(dims, B, K, alpha, world):
+    import warnings
+
+    ridge = 0.05
+    lib = _native.load()
+    for attempt in range(4):
+        inner, prev, x, y, _ = _problem(dims, world * B, ridge, 97 * sum(dims) + B + K + 1000 * attempt, K, False)
+        g = torch.Generator().manual_seed(5)
+        vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+        vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            want = [t.clone() for t in hg.jvp_fn_mapping["cg"](vmean, _attach(inner, prev, x, y, ridge, K, True, alpha), prev, False)]
+            inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
+            parts = [_attach(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, False, alpha) for r in range(world)]
+            p0 = lib.bhg_mlp_proj_iterations()
+            got, _ = _emulate_fx(parts, prev, vecs, K, alpha)
+            assert lib.bhg_mlp_proj_iterations() - p0 == world * K
         if not any("ReLU-kink" in str(w.message) for w in caught):
             break
     else:
