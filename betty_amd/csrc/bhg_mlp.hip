@@ -1976,7 +1976,7 @@ int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, 
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
   BHG_REQUIRE(xws_bytes >= bhg_mlp_fx_ws_bytes(m, world), "factor-exchange workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static FxPlan fp;   // (large: off the stack; rebuilt on every call from the descriptor alone — a few microseconds of host work)
+  FxPlan fp;   // (rebuilt on every call from the descriptor alone — a few microseconds of host work; no state between calls: reentrant)
   fx_plan(m, world, &fp);
   FusedWs w;
   carve_fused_ws(m, fws, &w);
