@@ -356,9 +356,10 @@ def test_factor_exchange_sweep_of_shapes_batches_and_world_sizes(dims, B, K, alp
 
 @pytest.mark.parametrize("ks", [2, 4])
 def test_k_split_gram_slabs_are_consumed_as_a_concatenated_reduction(ks, bhg_debug):
-    """Measurement arm fx_ksplit: T_l / E_l leave ks K-split slabs, never summed — the G(raw) product runs over [S | T_0 | .. | T_{ks-1}]
-    against [Rd ; delta ; .. ; delta] (csrc/mlp/fx.inc: fx_plan).  Two emulated ranks against the one-rank solver; and against the
-    default arm to summation noise."""
+    """Key fx_ksplit: T_l / E_l leave ks K-split slabs, never summed — the G(raw) product runs over [S | T_0 | .. | T_{ks-1}]
+    against [Rd ; delta ; .. ; delta] (csrc/mlp/fx.inc: fx_plan; the product takes ks = 2 while the Gram launch would leave three quarters of
+    the chip idle — world size 1 at these shapes — and 1 otherwise).  Two emulated ranks (default there: 1) against the one-rank solver; and
+    against the default arm to summation noise."""
     dims, B, K, alpha, world, ridge = [256, 384, 128, 10], 100, 6, 1.0, 2, 0.05
     inner, prev, x, y, _ = _problem(dims, world * B, ridge, 31337, K, False)
     g = torch.Generator().manual_seed(99)
