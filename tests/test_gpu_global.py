@@ -285,8 +285,8 @@ def _emulate_fx(parts, prev, vecs, K, alpha):
         prov.cg_fx_phase(rhs, K - 1, K, _native.BHG_CG_FX_END, G, g, alpha)
         token = prov.cg_fx_finish(lay, K, alpha)
         outs.append([t.clone() for t in prov.mixed_vjp(None, False, solve=token)])
-    # replicated scalars: the same bits on every rank
-    xw = [b["xws"] for b in bufs]
+    for o in outs[1:]:   # the narrow state and every scalar are replicated: NaN or Inf anywhere would show on every rank alike
+        assert all(bool(torch.isfinite(t).all()) for t in o)
     return [sum(o[i] for o in outs) / G for i in range(len(outs[0]))], provs
 
 
