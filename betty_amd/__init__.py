@@ -28,6 +28,6 @@ def install(betty_hypergradient=None, auto_structure=None):
 
     if betty_hypergradient is None:
         import betty.hypergradient as betty_hypergradient  # noqa: PLC0415
-    for key in ("cg", "neumann", "darts", "sama", "cg_global"):   # cg_global: extension key (global-HVP mode)
+    for key in ("cg", "neumann", "darts", "sama", "cg_global", "neumann_global"):   # *_global: extension keys (global-batch mode)
         betty_hypergradient.jvp_fn_mapping[key] = hg.jvp_fn_mapping[key]
     return betty_hypergradient.jvp_fn_mapping

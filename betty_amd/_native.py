@@ -155,6 +155,11 @@ SYMBOLS = {
         [POINTER(Mlp), _PP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t,
          c_void_p, c_size_t, c_void_p],
     ),
+    "bhg_mlp_neumann_fx_phase": (
+        c_int,
+        [POINTER(Mlp), _PP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t,
+         c_void_p, c_size_t, c_void_p],
+    ),
     "bhg_mlp_cg_mixed_coeff": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "bhg_mlp_timeout_flag_dev": (c_void_p, [POINTER(Mlp), c_void_p]),
     "bhg_mlp_stage_batch": (c_int, [POINTER(Mlp), c_void_p, c_void_p, c_void_p, c_void_p]),

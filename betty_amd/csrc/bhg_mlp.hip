@@ -1963,14 +1963,17 @@ size_t bhg_mlp_fx_scal_doubles(const bhg_mlp* m) {
   FxPlan fp; fx_plan(m, 1, &fp);
   return fp.scal_doubles;
 }
-int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
-                        float* slab_all, double* scal_all, float cg_alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
-                        size_t xws_bytes, void* stream) {
+// algo 0: CG (cg.py:34-56; k = 0 .. K-1, END at k = K-1) | 1: Neumann (neumann.py:59-66; CHAIN for k = 0 .. K — the last one is the closing half
+// pass, forward chain + head only: Rz(v_K) — GRAM for k = 0 .. K-1, END at k = K)
+static int fx_phase(int algo, const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                    float* slab_all, double* scal_all, float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws, size_t xws_bytes,
+                    void* stream) {
   if (int rc = check_mlp(m)) return rc;
+  const bool neumann = algo == 1;
   BHG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad world size / rank");
   BHG_REQUIRE(bhg_mlp_fx_supported(m, world), "this network does not take the factor-exchange form (bhg_mlp_fx_supported)");
   BHG_REQUIRE(phase == BHG_CG_FX_BEGIN || phase == BHG_CG_FX_CHAIN || phase == BHG_CG_FX_GRAM || phase == BHG_CG_FX_END, "unknown phase");
-  BHG_REQUIRE(K > 0 && k >= 0 && k < K, "bad iteration index");
+  BHG_REQUIRE(K > 0 && k >= 0 && (k < K || (neumann && k == K && (phase == BHG_CG_FX_CHAIN || phase == BHG_CG_FX_END))), "bad iteration index");
   BHG_REQUIRE(const_all && slab_all && scal_all && fws && xws, "NULL argument");
   BHG_REQUIRE(m->partial && m->partial_floats >= bhg_mlp_partial_floats(m), "split-K scratch too small");
   BHG_REQUIRE(fws_bytes >= bhg_mlp_fused_ws_bytes(m), "fused workspace too small");
@@ -1993,15 +1996,28 @@ int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, 
       BHG_REQUIRE(rhs, "iteration 0 reads the right-hand side");
       for (int l = 0; l + 1 < m->L; ++l) BHG_REQUIRE(rhs[2 * l] && ((uintptr_t)rhs[2 * l] & 15) == 0, "rhs tensors must be 16-byte aligned device pointers");
       for (int i = 0; i < 2 * m->L; ++i) BHG_REQUIRE(rhs[i], "rhs holds 2 L device pointers");
-      if (int rc = fx_first(m, &ml, fp, w, x, rhs, const_all, rank, st)) return rc;
+      if (int rc = fx_first(m, &ml, fp, w, x, rhs, const_all, rank, st, neumann)) return rc;
     } else {
-      if (int rc = fx_step(&ml, fp, w, x, scal_all, k - 1, false, cg_alpha, hvp_shift, st)) return rc;
+      if (int rc = fx_step(&ml, fp, w, x, scal_all, k - 1, false, alpha, hvp_shift, st, neumann)) return rc;
     }
-    return fx_chain(&ml, fp, w, x, k & 1, st);
+    return fx_chain(&ml, fp, w, x, k & 1, st, neumann && k == K);
   }
-  if (phase == BHG_CG_FX_GRAM) return fx_gram(&ml, fp, w, x, slab_all, const_all, scal_mine, k & 1, hvp_shift, st);
-  BHG_REQUIRE(k == K - 1, "END belongs to the last iteration");
-  return fx_step(&ml, fp, w, x, scal_all, k, true, cg_alpha, hvp_shift, st);
+  if (phase == BHG_CG_FX_GRAM) {
+    BHG_REQUIRE(k < K, "GRAM belongs to iterations 0 .. K-1");
+    return fx_gram(&ml, fp, w, x, slab_all, const_all, scal_mine, k & 1, hvp_shift, st);
+  }
+  BHG_REQUIRE(k == (neumann ? K : K - 1), "END belongs to the last iteration");
+  return fx_step(&ml, fp, w, x, scal_all, k, true, alpha, hvp_shift, st, neumann);
+}
+int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                        float* slab_all, double* scal_all, float cg_alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
+                        size_t xws_bytes, void* stream) {
+  return fx_phase(0, m, rhs, k, K, phase, world, rank, const_all, slab_all, scal_all, cg_alpha, hvp_shift, fws, fws_bytes, xws, xws_bytes, stream);
+}
+int bhg_mlp_neumann_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                             float* slab_all, double* scal_all, float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
+                             size_t xws_bytes, void* stream) {
+  return fx_phase(1, m, rhs, k, K, phase, world, rank, const_all, slab_all, scal_all, alpha, hvp_shift, fws, fws_bytes, xws, xws_bytes, stream);
 }
 
 int bhg_mlp_neumann_solve(const bhg_mlp* m, float* v0, float* v1, float* p, const int64_t* starts, int K, float alpha,

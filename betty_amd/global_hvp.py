@@ -227,6 +227,64 @@ def _cg_global_factor_exchange(vector, prev, sync, provider, be, full, K: int, a
     return [t.clone() for t in exchange_async(out, group).wait()]
 
 
+def neumann_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = None):
+    """``neumann`` (betty/hypergradient/neumann.py:8-66) for ONE inner problem whose batch is spread over the ranks — extension key
+    ``Config(type="neumann_global")``, oracle = the reference's neumann in one process on the concatenated batch.  The series has no scalars,
+    so in the factor-exchange form the ranks exchange NOTHING but the batch-sized factor slab: one all-gather per iteration, no reduction
+    (csrc/mlp/fx.inc, bhg_mlp_neumann_fx_phase).  Needs a structure that takes that form (the weighted-CE MLP on the projected plan)."""
+    assert len(curr.paths) == 0, "neumann method is not supported for higher order MLO!"
+    assert dist.is_available() and dist.is_initialized(), "neumann_global needs an initialised process group"
+    from . import _native  # noqa: PLC0415
+
+    config = curr.config
+    be = get_backend()
+    vector = list(vector)
+    G, g = dist.get_world_size(group), dist.get_rank(group)
+    provider = structured_hvp_for(curr, prev)
+    if provider is None:
+        raise NotImplementedError("neumann_global needs a declared structure (hypergradient_structure): its form exchanges batch-sized factors")
+    provider.pad_widths = False
+    provider.prepare()
+    full = be.layout(vector)
+    K, alpha = int(config.neumann_iterations), float(config.neumann_alpha)
+    ready = getattr(provider, "fused_neumann_fx_ready", None)
+    if ready is None or K <= 0 or not ready(full, K, G):
+        raise NotImplementedError("neumann_global: this structure / shape does not take the factor-exchange form (>= 3 layers, widths % 32 == 0, "
+                                  "a head of <= 256 classes, no accumulator vector asked for)")
+    st = _FX.get(full)
+    if st is None:
+        st = _FX[full] = _FxState(full)
+    be.flatten(full, vector, st.v, 1.0 / G)
+    if G > 1:
+        dist.all_reduce(st.v, op=dist.ReduceOp.SUM, group=group)
+        FX_STATS["rhs_all_reduces"] += 1
+    rhs = full.views(st.v, vector)
+    bufs = provider._state.fx_buffers(G)
+    FX_STATS["solves"] += 1
+    FX_STATS["neumann_solves"] = FX_STATS.get("neumann_solves", 0) + 1
+    gather = G > 1 or FX_ALWAYS_GATHER
+    provider.neumann_fx_phase(rhs, 0, K, _native.BHG_CG_FX_BEGIN, G, g, alpha)
+    if gather:
+        all_gather_slots(bufs["const"], g, group)
+        FX_STATS["const_gathers"] += 1
+    for k in range(K):
+        provider.neumann_fx_phase(rhs, k, K, _native.BHG_CG_FX_CHAIN, G, g, alpha)
+        if gather:
+            all_gather_slots(bufs["slab"], g, group)
+            FX_STATS["slab_gathers"] += 1
+        provider.neumann_fx_phase(rhs, k, K, _native.BHG_CG_FX_GRAM, G, g, alpha)
+    provider.neumann_fx_phase(rhs, K, K, _native.BHG_CG_FX_CHAIN, G, g, alpha)   # the closing half pass: Rz(v_K)
+    provider.neumann_fx_phase(rhs, K, K, _native.BHG_CG_FX_END, G, g, alpha)
+    solve = provider.neumann_fx_finish(full, K, alpha)
+    provider.expects_data_parallel_mean = G > 1
+    out = provider.mixed_vjp(None, sync, solve=solve)
+    if sync:
+        return None
+    from .distributed import exchange_async  # noqa: PLC0415
+
+    return [t.clone() for t in exchange_async(out, group).wait()]
+
+
 def cg_global(vector, curr, prev, sync, group: Optional[dist.ProcessGroup] = None):
     """Same signature and result convention as ``cg`` (betty/hypergradient/cg.py:8-70); ``vector`` is this rank's
     gradient of ITS share of the upper loss (the global one is the mean over ranks).  Returns the GLOBAL hypergradient

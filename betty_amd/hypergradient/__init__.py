@@ -27,6 +27,15 @@ def cg_global(vector, curr, prev, sync):
     return impl(vector, curr, prev, sync)
 
 
+def neumann_global(vector, curr, prev, sync):
+    """Extension key (not in the reference): ``Config(type="neumann_global")`` — the Neumann series on ONE inner problem whose batch is
+    spread over the default process group, in the factor-exchange form (one all-gather of batch-sized factors per iteration, no reduction;
+    betty_amd/global_hvp.py)."""
+    from ..global_hvp import neumann_global as impl  # noqa: PLC0415
+
+    return impl(vector, curr, prev, sync)
+
+
 jvp_fn_mapping = {
     "darts": darts,
     "sama": sama,
@@ -34,6 +43,7 @@ jvp_fn_mapping = {
     "cg": cg,
     "reinforce": reinforce,
     "cg_global": cg_global,
+    "neumann_global": neumann_global,
 }
 
 

@@ -357,6 +357,26 @@ class HipMLPState:
             "bhg_mlp_cg_fx_phase",
         )
 
+    def neumann_fx_phase(self, rhs, k: int, K: int, phase: int, world: int, rank: int, alpha: float, shift: float) -> None:
+        """The same for the Neumann series (bhg_mlp_neumann_fx_phase): CHAIN for k = 0 .. K (the last one is the closing half pass),
+        GRAM for k = 0 .. K-1, END at k = K; the only buffer the caller gathers per iteration is the factor slab."""
+        b = self.fx_buffers(world)
+        fws = self._fused_ws(self.buf.h[0].device)
+        if phase == _native.BHG_CG_FX_BEGIN:
+            self._solve = None
+            self._fx_rhs = _native.ptr_array([t.data_ptr() for t in rhs]) + (list(rhs),)
+        _native.check(
+            self.lib.bhg_mlp_neumann_fx_phase(ctypes.byref(self.desc), self._fx_rhs[0], int(k), int(K), int(phase), int(world), int(rank),
+                                              b["const"].data_ptr(), b["slab"].data_ptr(), b["scal"].data_ptr(), float(alpha), float(shift),
+                                              fws.data_ptr(), fws.numel(), b["xws"].data_ptr(), b["xws"].numel(), _stream()),
+            "bhg_mlp_neumann_fx_phase",
+        )
+
+    def neumann_fx_finish(self, layout, K: int, alpha: float) -> FusedSolve:
+        """Token of the factor-exchange Neumann solve: sum_{k <= K} Rz(v_k) sits where bhg_mlp_neumann_mixed_coeff reads it (projected)."""
+        self._solve = FusedSolve("neumann", float(alpha), int(K), layout, v_last=None, materialised=False, projected=1)
+        return self._solve
+
     def cg_fx_finish(self, layout, K: int, cg_alpha: float) -> FusedSolve:
         """Token of the factor-exchange solve that just ran (its Rz(x) sits where bhg_mlp_cg_mixed_coeff reads it; x never existed)."""
         self._solve = FusedSolve("cg", float(cg_alpha), int(K), layout, materialised=False)
@@ -390,8 +410,11 @@ class HipMLPState:
                 raise RuntimeError("stale fused-solve token: another solve or a hand-driven HVP has reused this state's workspace")
             if solve.kind == "neumann" and not solve.materialised:
                 lay, v_last = solve.layout, solve.v_last
-                views = [v_last[s: s + n] for s, n in zip(lay.starts, lay.numels)]
-                tab, _keep = self._dir_table(views)
+                if v_last is None:   # the factor-exchange solve: v_K never existed N-sized; its Rz is already in the sum (projected = 1)
+                    tab, _keep = None, None
+                else:
+                    views = [v_last[s: s + n] for s, n in zip(lay.starts, lay.numels)]
+                    tab, _keep = self._dir_table(views)
                 _native.check(
                     self.lib.bhg_mlp_neumann_mixed_coeff(ctypes.byref(self.desc), tab, buf.labels.data_ptr(), buf.coeff.data_ptr(),
                                                          solve.alpha, solve.K, int(getattr(solve, "projected", 0)), buf.fws.data_ptr(),

@@ -443,6 +443,16 @@ class WeightedCEMLP:
     def cg_fx_finish(self, layout, K: int, cg_alpha: float):
         return self._state.cg_fx_finish(layout, K, cg_alpha)
 
+    def fused_neumann_fx_ready(self, layout, K: int, world: int) -> bool:
+        st = self._state
+        return (K > 0 and self.fused and not self.keep_solution and hasattr(st, "neumann_fx_phase") and st.fx_supported(layout, world))
+
+    def neumann_fx_phase(self, rhs, k: int, K: int, phase: int, world: int, rank: int, alpha: float) -> None:
+        self._state.neumann_fx_phase(rhs, k, K, phase, world, rank, alpha, self.hvp_shift)
+
+    def neumann_fx_finish(self, layout, K: int, alpha: float):
+        return self._state.neumann_fx_finish(layout, K, alpha)
+
     def fused_neumann_ready(self, layout, K: int) -> bool:
         st = self._state
         return K > 0 and self.fused and hasattr(st, "neumann_solve") and st.fused_supported(layout)
@@ -783,6 +793,30 @@ class _TorchMLPState:
 
     def cg_fx_finish(self, layout, K, cg_alpha):
         self._fx_token = ("cg_fx", float(cg_alpha))
+        return self._fx_token
+
+    def neumann_fx_phase(self, rhs, k, K, phase, world, rank, alpha, shift):
+        """neumann.py:59-66 on the global batch, factor-exchange form (bhg_mlp_neumann_fx_phase): no scalars; the direction lives in the
+        p slots of the state; Rzx = sum_{k <= K} Rz(v_k)."""
+        L = len(self.Ws)
+        if phase in (0, 2) or (phase == 1 and k == 0):      # BEGIN, GRAM, and the first CHAIN are the CG form's
+            return self.cg_fx_phase(rhs, k, K, phase, world, rank, alpha, shift)
+        st = self._fx
+        st["Rzx"] += st["Rz"].double()                      # Rz(v_{k-1}) (END: Rz(v_K))
+        if phase == 3:
+            return
+        for l in range(L):
+            st["p_c"][l] = st["p_c"][l] - alpha * (st["raw_c"][l] + shift * st["p_c"][l])
+        st["p_V"] = st["p_V"] - alpha * (st["raw_V"] + shift * st["p_V"])
+        for l in range(L - 1):
+            st["Gf_p"][l] = st["Gf_p"][l] - alpha * (st["Gf_raw"][l] + shift * st["Gf_p"][l])
+        for l in range(1, L - 1):
+            st["Gb_p"][l] = st["Gb_p"][l] - alpha * (st["Gb_raw"][l] + shift * st["Gb_p"][l])
+        st["Rz"], st["Rhs"], st["Rds"] = self._fx_chain(st)
+        self.fx_buffers(world)["slab"][rank].copy_(torch.cat(st["Rds"] + st["Rhs"], 1).reshape(-1))
+
+    def neumann_fx_finish(self, layout, K, alpha):
+        self._fx_token = ("neumann_fx", float(alpha))
         return self._fx_token
 
 

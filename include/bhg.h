@@ -349,6 +349,15 @@ size_t bhg_mlp_fx_scal_doubles(const bhg_mlp* m);
 int bhg_mlp_cg_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
                         float* slab_all, double* scal_all, float cg_alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
                         size_t xws_bytes, void* stream);
+/* The same form for the Neumann series (neumann.py:59-66 on the global batch: v' = v - alpha (H v), p = alpha sum_{k <= K} v_k) — the series
+ * has NO scalars, so the ranks exchange the factor slab ONLY: one all-gather per iteration, no reduction of any kind.  Phases as above with
+ *     BEGIN (k = 0) + gather of the constants;   for k in 0 .. K-1:  CHAIN (k), gather of the factor slab, GRAM (k);
+ *     CHAIN (K)  — the closing half pass (recurrences, forward chain and head: Rz(v_K));   END (k = K).
+ * scal_all is written (the G(raw) tiles emit their partials all the same) but never gathered nor read.  Afterwards
+ * bhg_mlp_neumann_mixed_coeff(m, NULL, labels, coeff, alpha, K, 1, fws, ...) gives the mixed coefficient of -alpha sum_k v_k.            */
+int bhg_mlp_neumann_fx_phase(const bhg_mlp* m, const void* const* rhs, int k, int K, int phase, int world, int rank, float* const_all,
+                             float* slab_all, double* scal_all, float alpha, float hvp_shift, void* fws, size_t fws_bytes, void* xws,
+                             size_t xws_bytes, void* stream);
 /* bhg_mlp_cg_solve with the right-hand side's tensors named (round 5).  rhs: 2L device pointers [W_0-shaped, b_0-shaped, ...] — the
  * tensors bhg_cg_init(_masked) was given — or NULL (= bhg_mlp_cg_solve).  The fully projected solver reads the N-sized residual
  * exactly once, in iteration 0, where r = the right-hand side: with rhs it reads the MFMA layers' slices THERE, so the caller may

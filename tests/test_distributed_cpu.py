@@ -485,6 +485,68 @@ def _global_worker(rank, world, port, case_name, structured, q):
         dist.destroy_process_group()
 
 
+def _neumann_global_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hypergrad_oracle as orc
+        import zoo
+        from _cpu_checker_backend import CpuCheckerBackend
+        from conftest import load_golden
+
+        import betty_amd.global_hvp as gh
+        from betty_amd import Config
+        from betty_amd.backend import use_backend
+
+        case = zoo.CASE_BY_NAME["reweight_neumann10"]
+        inputs, _ = load_golden(case.family)
+        full_inputs = dict(inputs)
+        n = (inputs["batch_x"].shape[0] // world) * world
+        full_inputs["batch_x"], full_inputs["batch_y"] = inputs["batch_x"][:n], inputs["batch_y"][:n]
+        share = n // world
+        mine = dict(full_inputs)
+        mine["batch_x"] = full_inputs["batch_x"][rank * share:(rank + 1) * share]
+        mine["batch_y"] = full_inputs["batch_y"][rank * share:(rank + 1) * share]
+        curr, prev, vector = zoo.build_case(case, full_inputs, Config)
+        want = torch.cat([t.reshape(-1) for t in orc.neumann(vector, curr, prev, False)]).detach()
+        with use_backend(CpuCheckerBackend()):
+            curr, prev, vector = zoo.build_case(case, mine, Config)
+            zoo.attach_mlp_structure(curr, case.family, impl="torch", fused=True)
+            got = torch.cat([t.reshape(-1) for t in gh.neumann_global(vector, curr, prev, False)]).detach()
+        rel = float((got - want).norm() / want.norm())
+        others = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(others, got)
+        fx = gh.FX_STATS
+        q.put((rank, rel, all(torch.equal(o, got) for o in others),
+               (fx["solves"], fx["const_gathers"], fx["slab_gathers"], fx["scal_gathers"], int(curr.config.neumann_iterations))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_neumann_global_exchanges_one_factor_slab_per_iteration_and_matches_the_oracle(world):
+    """Config(type="neumann_global") over real gloo collectives (the phases' math in ATen): against the reference's neumann run in ONE
+    process on the concatenated batch; per solve one gather of the constants, K gathers of the factors, NO scalar exchange."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_neumann_global_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    for rank, rel, same, (solves, n_const, n_slab, n_scal, K) in sorted(q.get(timeout=5) for _ in range(world)):
+        assert rel <= 1e-4, (rank, rel)
+        assert same
+        assert (solves, n_const, n_slab, n_scal) == (1, 1, K, 0)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("case_name,structured", [("reweight_cg20", False), ("reweight_cg20", "sharded"), ("reweight_cg20", "onepass"),
                                                   ("reweight_cg20", "factor"), ("logreg_cg5", False), ("logreg_cg3_a01", False)])

@@ -319,6 +319,92 @@ def test_emulated_ranks_exchanging_factors_match_the_one_rank_solver_on_the_conc
     assert rel <= 1e-4, rel
 
 
+# ---- the Neumann series in the factor-exchange form (Config(type="neumann_global"); bhg_mlp_neumann_fx_phase) ---------------------------
+def _attach_neumann(inner, prev, x, y, ridge, K, alpha):
+    curr = zoo.StubProblem("inner", inner, config=Config(type="neumann", neumann_iterations=K, neumann_alpha=alpha),
+                           loss_fn=zoo.make_reweight_loss(prev, ridge), batch=(x, y))
+    curr.hypergradient_structure = lambda prev_: WeightedCEMLP(
+        curr, prev_, layers=list(inner.layers), weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=ridge, impl="hip", fused=True)
+    return curr
+
+
+def _emulate_neumann_fx(parts, prev, vecs, K, alpha):
+    """betty_amd/global_hvp.py::neumann_global for len(parts) ranks living in this process: ONE gather per iteration (the factor slab)."""
+    be = get_backend()
+    G = len(parts)
+    provs, lays, rhss, bufs, flats = [], [], [], [], []
+    for curr, vec in zip(parts, vecs):
+        lay = FlatLayout([t.numel() for t in vec], vec[0].device)
+        prov = curr.hypergradient_structure(prev)
+        prov.pad_widths = False
+        prov.prepare()
+        assert prov.fused_neumann_fx_ready(lay, K, G)
+        v = lay.new_flat()
+        be.flatten(lay, vec, v, 1.0 / G)
+        provs.append(prov); lays.append(lay); flats.append(v); bufs.append(prov._state.fx_buffers(G))
+    total = sum(flats)
+    for lay, vec, v in zip(lays, vecs, flats):
+        v.copy_(total)
+        rhss.append(lay.views(v, vec))
+
+    def gather(name):
+        for r in range(G):
+            for j in range(G):
+                if j != r:
+                    bufs[j][name][r].copy_(bufs[r][name][r])
+
+    def phase(k, ph):
+        for g, (prov, rhs) in enumerate(zip(provs, rhss)):
+            prov.neumann_fx_phase(rhs, k, K, ph, G, g, alpha)
+
+    phase(0, _native.BHG_CG_FX_BEGIN); gather("const")
+    for k in range(K):
+        phase(k, _native.BHG_CG_FX_CHAIN); gather("slab")
+        phase(k, _native.BHG_CG_FX_GRAM)
+    phase(K, _native.BHG_CG_FX_CHAIN)
+    phase(K, _native.BHG_CG_FX_END)
+    outs = [[t.clone() for t in prov.mixed_vjp(None, False, solve=prov.neumann_fx_finish(lay, K, alpha))] for prov, lay in zip(provs, lays)]
+    return [sum(o[i] for o in outs) / G for i in range(len(outs[0]))]
+
+
+@pytest.mark.parametrize("dims,B,K,alpha,world", [([256, 384, 128, 10], 100, 5, 0.1, 1), ([256, 384, 128, 10], 100, 10, 0.1, 2),
+                                                  ([512, 256, 128, 64, 10], 77, 6, 0.05, 3), ([512, 384, 256, 256, 128, 10], 60, 4, 0.1, 2),
+                                                  ([256, 384, 128, 100], 130, 3, 0.1, 2), ([256, 384, 128, 10], 64, 1, 0.2, 4)], ids=lambda v: str(v))
+def test_neumann_in_the_factor_exchange_form_matches_the_one_rank_solver(dims, B, K, alpha, world, one_rank_group):
+    """neumann.py:59-66 on the global batch: emulated ranks exchanging NOTHING but the factor slab (one gather per iteration, no scalars)
+    against the one-rank Neumann solver on the concatenated batch; at world size 1 also through Config(type="neumann_global") itself."""
+    import warnings
+
+    ridge = 0.05
+    for attempt in range(4):
+        inner, prev, x, y, _ = _problem(dims, world * B, ridge, 13 * sum(dims) + B + K + 1000 * attempt, K, False)
+        g = torch.Generator().manual_seed(5)
+        vecs = [[0.1 * torch.randn(p.shape, generator=g).to(DEV) for p in inner.parameters()] for _ in range(world)]
+        vmean = [sum(v[i] for v in vecs) / world for i in range(len(vecs[0]))]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            want = [t.clone() for t in hg.jvp_fn_mapping["neumann"](vmean, _attach_neumann(inner, prev, x, y, ridge, K, alpha), prev, False)]
+            inners = [inner] + [copy.deepcopy(inner) for _ in range(world - 1)]
+            parts = [_attach_neumann(inners[r], prev, x[r * B:(r + 1) * B], y[r * B:(r + 1) * B], ridge, K, alpha) for r in range(world)]
+            got = _emulate_neumann_fx(parts, prev, vecs, K, alpha)
+        if not any("ReLU-kink" in str(w.message) for w in caught):
+            break
+    else:
+        pytest.fail("four instances in a row sat on a ReLU kink")
+    rel, _ = rel_err([t.cpu().numpy() for t in got], [t.cpu().numpy() for t in want])
+    assert rel <= 1e-4, rel
+    if world == 1:
+        from betty_amd.global_hvp import FX_STATS
+
+        n0 = FX_STATS.get("neumann_solves", 0)
+        c = _attach_neumann(inner, prev, x, y, ridge, K, alpha)
+        c.config.type = "neumann_global"
+        got2 = [t.clone() for t in hg.jvp_fn_mapping["neumann_global"](vmean, c, prev, False)]
+        assert FX_STATS.get("neumann_solves", 0) == n0 + 1
+        rel, _ = rel_err([t.cpu().numpy() for t in got2], [t.cpu().numpy() for t in want])
+        assert rel <= 1e-4, rel
+
+
 SWEEP = [  # dims, per-rank batch, K, cg_alpha, world — odd world sizes (1 / G is not a power of two), batches beyond one row tile of 128
     # (Bp = 256, 384), ragged batches, three to five layers, heads of 3 .. 100 classes
     ([256, 384, 128, 10], 37, 5, 1.0, 3), ([256, 384, 128, 3], 130, 4, 1.0, 2), ([512, 256, 128, 64, 10], 200, 5, 0.5, 2),

@@ -62,7 +62,7 @@ def test_sync_accumulates_and_returns_none(case, checker):
 
 def test_registry_and_get_grads(checker):
     # the reference's keys (betty/hypergradient/__init__.py:13-19); `reinforce` is a stub there and fails loudly here
-    assert set(hg.jvp_fn_mapping) == {"cg", "neumann", "darts", "sama", "reinforce", "cg_global"}   # cg_global: extension
+    assert set(hg.jvp_fn_mapping) == {"cg", "neumann", "darts", "sama", "reinforce", "cg_global", "neumann_global"}   # *_global: extensions
     with pytest.raises(NotImplementedError, match="reinforce"):
         hg.jvp_fn_mapping["reinforce"]([], None, None, False)
     case = zoo.CASE_BY_NAME["logreg_cg5"]
@@ -119,7 +119,7 @@ def test_install_mutates_registry_in_place():
     betty_amd.install(FakeRef)
     assert FakeRef.jvp_fn_mapping is mapping
     assert mapping["cg"] is hg.cg and mapping["neumann"] is hg.neumann and mapping["darts"] is hg.darts
-    assert mapping["sama"] is hg.sama and mapping["reinforce"] == 5 and mapping["cg_global"] is hg.cg_global
+    assert mapping["sama"] is hg.sama and mapping["reinforce"] == 5 and mapping["cg_global"] is hg.cg_global and mapping["neumann_global"] is hg.neumann_global
 
 
 @pytest.mark.parametrize("name", ["reweight_cg20", "reweight_neumann10", "deep_cg6", "deep_neumann6"])
