@@ -633,10 +633,10 @@ def main():
     be.cg_variant = {"auto": _native.BHG_CG_AUTO, "stream": _native.BHG_CG_STREAM, "resident": _native.BHG_CG_RESIDENT}[args.variant]
     K = args.cg_iters
     if args.mode == "global":
-        assert args.algo == "cg", "--mode global is the sharded CG solve"
+        assert args.algo in ("cg", "neumann"), "--mode global: cg (three forms) or neumann (the factor-exchange form)"
         # the same inner / upper weights on every rank, a different batch per rank
-        curr, prev, vector = build(device, seed=0, ddp=world > 1, K=K, algo="cg", data_seed=rank)
-        jvp_fn = hg.jvp_fn_mapping["cg_global"]
+        curr, prev, vector = build(device, seed=0, ddp=world > 1, K=K, algo=args.algo, data_seed=rank)
+        jvp_fn = hg.jvp_fn_mapping["cg_global" if args.algo == "cg" else "neumann_global"]
         import betty_amd.global_hvp as _ghvp
 
         _ghvp.GLOBAL_FORM = args.global_form

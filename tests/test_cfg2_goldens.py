@@ -310,3 +310,44 @@ def test_the_factor_exchange_form_matches_the_reference_cpu_golden_at_full_size(
     e32, e64 = rel([t.detach().cpu().numpy() for t in got2], want32), rel([t.detach().cpu().numpy() for t in got2], want64)
     print(f"cfg2 well seed={seed} cg20 factor exchange, 2 emulated ranks x 50 samples: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
     assert e32 <= RTOL and e64 <= RTOL, (seed, e32, e64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", WELL_SEEDS[:3])
+def test_neumann_global_matches_the_reference_cpu_golden_at_full_size(seed, one_rank_group):
+    """Config(type="neumann_global") — BASELINE cfg 2's own algorithm (Neumann K = 10) on the global batch, factor-exchange form, product
+    library: world size 1, and the batch of 100 split over two emulated ranks of 50 exchanging nothing but the factor slab; oracle of both:
+    the reference's own CPU output for the whole batch (neumann.py:8-66), rtol 1e-4 against fp32 and fp64."""
+    import test_gpu_global as tg
+    from betty_amd import _native
+    from betty_amd import hypergradient as hg
+    from betty_amd.global_hvp import FX_STATS
+
+    assert not _native.is_ab()
+    algo, K = mk.ALGOS["neumann10"]
+    want32, want64 = GOLD[f"well/{seed}/neumann10/fp32"], GOLD[f"well/{seed}/neumann10/fp64"]
+    dev = torch.device("cuda:0")
+    curr, prev, vector = bench.build(dev, seed, K=K, algo=algo, ridge=mk.RIDGE_WELL)
+    bench.declare_structure(curr, "hip")
+    n0 = FX_STATS.get("neumann_solves", 0)
+    got = [t.detach().cpu().numpy() for t in hg.jvp_fn_mapping["neumann_global"](vector, curr, prev, False)]
+    assert FX_STATS.get("neumann_solves", 0) == n0 + 1
+    e32, e64 = rel(got, want32), rel(got, want64)
+    print(f"cfg2 well seed={seed} neumann10 factor exchange, world 1: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert e32 <= RTOL and e64 <= RTOL, (seed, e32, e64)
+    parts, vecs, prev0 = [], [], None
+    for r in range(2):
+        c, p_, v = bench.build(dev, seed, K=K, algo=algo, ridge=mk.RIDGE_WELL)
+        x, y = c.cur_batch
+        h = x.shape[0] // 2
+        c.cur_batch = (x[r * h:(r + 1) * h].contiguous(), y[r * h:(r + 1) * h].contiguous())
+        if prev0 is None:
+            prev0 = p_
+        c._loss_fn = bench.make_loss(prev0, mk.RIDGE_WELL)
+        bench.declare_structure(c, "hip")
+        parts.append(c)
+        vecs.append(v)
+    got2 = tg._emulate_neumann_fx(parts, prev0, vecs, K, float(curr.config.neumann_alpha))
+    e32, e64 = rel([t.detach().cpu().numpy() for t in got2], want32), rel([t.detach().cpu().numpy() for t in got2], want64)
+    print(f"cfg2 well seed={seed} neumann10 factor exchange, 2 emulated ranks x 50 samples: vs reference-CPU fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert e32 <= RTOL and e64 <= RTOL, (seed, e32, e64)
