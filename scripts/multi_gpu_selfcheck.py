@@ -140,6 +140,27 @@ def worker(args):
             if not all(torch.equal(o, flat) for o in every):
                 raise Fail(f"global mode ({form}): the ranks returned different bits")
 
+        # the Neumann series on the global batch (factor-exchange form: one gather per iteration, no reduction)
+        from betty_amd.global_hvp import neumann_global
+
+        def attach_n(xb, yb):
+            c = zoo.StubProblem("inner", inner, config=Config(type="neumann", neumann_iterations=K, neumann_alpha=0.1),
+                                loss_fn=zoo.make_reweight_loss(prevg, ridge), batch=(xb, yb))
+            c.hypergradient_structure = lambda prev_: WeightedCEMLP(
+                c, prev_, layers=list(inner.layers), weight_fn=lambda ce: prev_.fwd(ce.reshape(-1, 1)), ridge=ridge, impl="hip", fused=True)
+            return c
+
+        want_n = [t.clone() for t in hg.neumann(vmean, attach_n(x, y), prevg, False)]
+        got = neumann_global(vecs[rank], attach_n(x[sl], y[sl]), prevg, False)
+        e = rel(got, want_n)
+        if not e <= 1e-4:
+            raise Fail(f"global mode (neumann, factor-exchange): {e:.2e} from the one-rank solve of the concatenated batch")
+        flat = torch.cat([t.reshape(-1) for t in got])
+        every = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(every, flat)
+        if not all(torch.equal(o, flat) for o in every):
+            raise Fail("global mode (neumann, factor-exchange): the ranks returned different bits")
+
         # ---- flat asynchronous exchange -----------------------------------------------------------------------------------------------
         gl = torch.Generator().manual_seed(1000 + rank)
         mine = [torch.randn(257, 33, generator=gl).to(device), torch.randn(1001, generator=gl).to(device)]
@@ -155,7 +176,7 @@ def worker(args):
             print(f"SELFCHECK OK: world {world} over {args.backend}, devices " +
                   ", ".join(f"{d['name']}@{d['pci']}" for d in census["devices"]) +
                   (f"; all-reduce of 301 floats {lat:.1f} us" if lat else "") + "; replica (deferred all-reduce, DDP wrapper), global "
-                  "(factor-exchange, one-pass, sharded), flat exchange: all equal to the one-process expectations", flush=True)
+                  "(cg: factor-exchange, one-pass, sharded; neumann: factor-exchange), flat exchange: all equal to the one-process expectations", flush=True)
         verdict = 0.0
     except Fail as f:
         reason = str(f)
