@@ -2471,16 +2471,17 @@ int bhg_debug_stamps_read(unsigned long long* host, size_t count) {
 // size of the instruction cache two CUs share) is sensitive to WHERE it starts: the same instruction stream 512 bytes further on ran 0.43 us
 // slower per launch (same-box A/B, profiles/r06_code_placement_of_the_k_loop_kernels.txt: 56.8-57.0 vs 57.6-57.9 us per iteration, after an
 // unrelated kernel ahead of it had grown by 600 bytes).  So the template kernels are ANCHORED: this kernel is the last non-template one, it
-// starts on a 4 KB boundary whatever precedes it, and its size — BHG_LAYOUT_PAD units of 256 bytes of s_nop — was chosen by a sweep of the
-// sixteen residues modulo 4 KB (same file).  It is never launched.
+// starts on a 16 KB boundary whatever precedes it, and its size — BHG_LAYOUT_PAD units of 256 bytes of s_nop — was chosen by two sweeps (the
+// sixteen residues modulo 4 KB, then the better ones modulo 16 KB: 56.4 us per iteration at the best, 57.7 at the worst; same file).  It is
+// never launched.  tests/test_code_placement.py pins the four kernels' offsets from it.
 #ifndef BHG_LAYOUT_PAD
-#define BHG_LAYOUT_PAD 5   // (the sweep: 56.7-56.8 us per iteration at 5, 57.5-57.7 at 2 and 10 — where the unanchored layout had happened to land)
+#define BHG_LAYOUT_PAD 8
 #endif
 namespace bhg {
 namespace {
 #define BHG_STR2(x) #x
 #define BHG_STR(x) BHG_STR2(x)
-__global__ __attribute__((aligned(4096))) void k_layout_anchor() {
+__global__ __attribute__((aligned(16384))) void k_layout_anchor() {
 #if BHG_LAYOUT_PAD > 0
   asm volatile(".rept " BHG_STR(BHG_LAYOUT_PAD) " * 64 - 8\n s_nop 0\n .endr");
 #endif
